@@ -1,0 +1,67 @@
+"""Deterministic synthetic checkpoints and the flat packing `rip_load_model` eats.
+
+There is no network for real CARNOVEL checkpoints, so tests, golden fixtures
+and `bench.py` use weights drawn from `numpy.random.default_rng(seed)` (PCG64,
+bit-stable across machines) with the same keys/shapes as the reference
+`ImitativeModel.state_dict()` (oatomobile/torch/savers.py:45 saves bare
+state_dicts; README.md:57-58 loads them).  Only the seed travels; the GPU box
+regenerates identical tensors.
+"""
+
+import collections
+from typing import Mapping
+
+import numpy as np
+
+from oatomobile_amd import arch
+
+
+def synthetic_state_dict(seed: int, in_channels: int = 2) -> "collections.OrderedDict[str, np.ndarray]":
+  """Random but well-conditioned weights: fan-in scaled convs, BN statistics
+  away from identity (so BN folding is exercised), small GRU/head weights."""
+  rng = np.random.default_rng(seed)
+  out = collections.OrderedDict()
+  for key, shape in arch.state_dict_spec(in_channels):
+    if key.endswith("num_batches_tracked"):
+      out[key] = np.asarray(1000, dtype=np.int64)
+      continue
+    if key.endswith("running_mean"):
+      v = rng.normal(0.0, 0.05, size=shape)
+    elif key.endswith("running_var"):
+      v = rng.uniform(0.6, 1.4, size=shape)
+    elif ".features." in key and key.endswith(".bias"):  # BN beta
+      v = rng.normal(0.05, 0.05, size=shape)
+    elif ".features." in key and len(shape) == 1:  # BN gamma
+      v = rng.uniform(0.8, 1.2, size=shape)
+    elif len(shape) == 4:  # conv: keep activations O(1) through 52 layers
+      fan_in = shape[1] * shape[2] * shape[3]
+      v = rng.normal(0.0, np.sqrt(2.0 / fan_in), size=shape)
+    elif len(shape) == 2:
+      fan_in = shape[1]
+      scale = np.sqrt(1.0 / fan_in)
+      if "_decoder._locscale._model.2" in key:
+        scale *= 0.5
+      v = rng.uniform(-1.0, 1.0, size=shape) * scale * np.sqrt(3.0)
+    else:  # linear / GRU biases
+      v = rng.uniform(-0.1, 0.1, size=shape)
+    out[key] = np.ascontiguousarray(v, dtype=np.float32)
+  return out
+
+
+def pack_state_dict(state_dict: Mapping[str, "np.ndarray"], in_channels: int = 2) -> np.ndarray:
+  """Flattens a reference-layout state_dict into the fp32 blob `rip_load_model`
+  expects (order = `arch.packed_spec`).  Accepts numpy arrays or torch tensors;
+  raises `KeyError`/`ValueError` like `load_state_dict(strict=True)` would."""
+  parts = []
+  for key, shape in arch.packed_spec(in_channels):
+    if key not in state_dict:
+      raise KeyError("Missing key in state_dict: %s" % key)
+    t = state_dict[key]
+    if hasattr(t, "detach"):
+      t = t.detach().cpu().numpy()
+    t = np.asarray(t, dtype=np.float32)
+    if tuple(t.shape) != tuple(shape):
+      raise ValueError("size mismatch for %s: expected %s, got %s" %
+                       (key, tuple(shape), tuple(t.shape)))
+    parts.append(t.reshape(-1))
+  return np.ascontiguousarray(np.concatenate(parts))

@@ -1,0 +1,150 @@
+"""CPU: pin the oracle (oracle/reference_cpu.py) to the reference's own outputs
+(tests/golden/*.npz, produced by tools/make_golden.py from /root/reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oatomobile_amd import weights as W
+from oracle import reference_cpu as O
+from tests.helpers import synth_observation
+
+torch.set_num_threads(1)
+
+
+def model(seed):
+  return O.OracleImitativeModel.from_numpy_state_dict(W.synthetic_state_dict(seed))
+
+
+def ctx_from_obs(obs_list):
+  lid = torch.stack([torch.from_numpy(o["lidar"]).permute(2, 0, 1) for o in obs_list]).contiguous()
+  return dict(
+      visual_features=O.transform_visual(lid),
+      velocity=torch.stack([torch.from_numpy(o["velocity"]) for o in obs_list]),
+      is_at_traffic_light=torch.tensor([[float(o["is_at_traffic_light"])] for o in obs_list]),
+      traffic_light_state=torch.tensor([[float(o["traffic_light_state"])] for o in obs_list]),
+  )
+
+
+def test_g1_transform(golden):
+  g = golden("g1_transform.npz")
+  lidar = np.random.default_rng(0).random((2, 2, 200, 200)).astype(np.float32)
+  vis = O.transform_visual(torch.from_numpy(lidar)).numpy()
+  idx = g["idx"]
+  np.testing.assert_allclose(vis[:, :, idx[:, 0], idx[:, 1]], g["picked"], atol=1e-6)
+  np.testing.assert_allclose(vis[0, 1, 7, :], g["row7"], atol=1e-6)
+  np.testing.assert_allclose(vis[1, 0, :, 93], g["col93"], atol=1e-6)
+  assert abs(vis.astype(np.float64).sum() - float(g["checksum"])) < 1e-2
+  pf = torch.arange(2 * 40 * 3, dtype=torch.float32).view(2, 40, 3)
+  np.testing.assert_array_equal(O.downsample_target(pf, 4).numpy(), g["player_future"])
+
+
+def test_g2_flow(golden):
+  g = golden("g2_flow.npz")
+  m = model(int(g["weight_seed"]))
+  z, x = torch.from_numpy(g["z"]), torch.from_numpy(g["x"])
+  y, lad = O.flow_forward(m, x, z)
+  np.testing.assert_allclose(y.numpy(), g["y"], atol=2e-5)
+  np.testing.assert_allclose(lad.numpy(), g["lad_f"], atol=2e-5)
+  xi, lp, ladi = O.flow_inverse(m, torch.from_numpy(g["y"]), z)
+  np.testing.assert_allclose(xi.numpy(), g["x_inv"], atol=2e-5)
+  np.testing.assert_allclose(lp.numpy(), g["logp"], atol=1e-4)
+  np.testing.assert_allclose(ladi.numpy(), g["lad_i"], atol=2e-5)
+  xi, lp, ladi = O.flow_inverse(m, torch.from_numpy(g["y2"]), z)
+  np.testing.assert_allclose(xi.numpy(), g["x_inv2"], rtol=1e-5, atol=1e-4)
+  np.testing.assert_allclose(lp.numpy(), g["logp2"], rtol=1e-5, atol=1e-3)
+  np.testing.assert_allclose(ladi.numpy(), g["lad_i2"], atol=2e-5)
+
+
+def test_g3_merger(golden):
+  g = golden("g3_merger.npz")
+  m = model(int(g["weight_seed"]))
+  z = m._merger(torch.from_numpy(np.c_[g["feats"], g["vec"]]))
+  np.testing.assert_allclose(z.numpy(), g["z"], atol=1e-5)
+
+
+def test_g4_goal(golden):
+  g = golden("g4_goal.npz")
+  y, goal = torch.from_numpy(g["y"]), torch.from_numpy(g["goal"])
+  for eps in (0.5, 1.0):
+    rows = O.goal_log_likelihood_rows(y, goal, eps).numpy()
+    np.testing.assert_allclose(rows, g["rows_eps%g" % eps], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(O.goal_log_likelihood(y, goal, eps).numpy(), g["mean_eps%g" % eps], rtol=1e-5, atol=1e-4)
+
+
+def test_g5_params(golden):
+  g = golden("g5_params.npz")
+  for ws in (5, 6):
+    m = model(ws)
+    for os_ in (50, 51):
+      ob = synth_observation(np.random.default_rng(os_))
+      ctx = ctx_from_obs([ob])
+      z = O.params(m, **ctx).numpy()[0]
+      np.testing.assert_allclose(z, g["z_w%d_o%d" % (ws, os_)], atol=1e-5)
+      assert np.abs(z).max() > 1e-2  # non-degenerate context
+
+
+@pytest.mark.parametrize("algo", ["WCM", "MA", "BCM"])
+def test_g6_rip(golden, algo):
+  g = golden("g6_rip.npz")
+  models = [model(100 + k) for k in range(4)]
+  for os_ in (60, 61, 62):
+    tag = "%s_o%d" % (algo, os_)
+    ob = synth_observation(np.random.default_rng(os_))
+    out30, res = O.rip_call(models, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"],
+                            ob["goal"], x0=torch.zeros(1, 4, 2), algorithm=algo)
+    np.testing.assert_allclose(res["trace_post"].numpy()[:, :, 0], g["post_" + tag], rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(res["trace_x"].numpy()[:, 0], g["x_" + tag], atol=1e-4)
+    np.testing.assert_allclose(float(res["loss_best"][0]), float(g["loss_best_" + tag]), rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(res["plan"].numpy(), g["plan_" + tag], atol=1e-4)
+    np.testing.assert_allclose(out30, g["out30_" + tag], atol=1e-4)
+    assert out30.shape == (30, 3) and out30.dtype == np.float64
+
+
+def test_g6_as_written_matches_fair():
+  models = [model(100 + k) for k in range(2)]
+  ob = synth_observation(np.random.default_rng(60))
+  a, _ = O.rip_call(models, ob["lidar"], ob["velocity"], 0.0, 1.0, ob["goal"], torch.zeros(1, 4, 2), "WCM")
+  b, _ = O.rip_call(models, ob["lidar"], ob["velocity"], 0.0, 1.0, ob["goal"], torch.zeros(1, 4, 2), "WCM",
+                    as_written=True)
+  np.testing.assert_allclose(a, b, atol=1e-5)
+
+
+def test_g7_dim_forward(golden):
+  g = golden("g7_dim_forward.npz")
+  m = model(7)
+  for B, os_ in ((1, 70), (3, 71)):
+    obs_list = [synth_observation(np.random.default_rng(os_ + 10 * b)) for b in range(B)]
+    ctx = ctx_from_obs(obs_list)
+    z = O.params(m, **ctx)
+    np.testing.assert_allclose(z.numpy(), g["z_B%d" % B], atol=1e-5)
+    goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs_list])
+    for with_goal in (0, 1):
+      tag = "B%d_goal%d" % (B, with_goal)
+      x0 = torch.from_numpy(g["x0_" + tag]).repeat(B, 1).view(B, 4, 2)
+      y, _ = O.dim_forward(m, z, x0, num_steps=20, goal=goal if with_goal else None, lr=5e-2, epsilon=1.0)
+      np.testing.assert_allclose(y.numpy(), g["y_" + tag], atol=1e-4)
+
+
+def test_g8_scores(golden):
+  g = golden("g8_scores.npz")
+  models = [model(100 + k) for k in range(4)]
+  ob = synth_observation(np.random.default_rng(int(g["obs_seed"])))
+  ctx = ctx_from_obs([ob])
+  zs = [O.params(m, **ctx) for m in models]
+  np.testing.assert_allclose(np.stack([z.numpy()[0] for z in zs]), g["zs"], atol=1e-5)
+  y = torch.from_numpy(g["y"])
+  S = O.rip_scores(models, zs, y, None).numpy()
+  np.testing.assert_allclose(S, g["S"], rtol=1e-5, atol=1e-3)
+  goal = torch.from_numpy(ob["goal"][None, :, :2].copy())
+  SG = O.rip_scores(models, zs, y, goal).numpy()
+  np.testing.assert_allclose(SG, g["SG"], rtol=1e-5, atol=1e-3)
+
+
+def test_interpolate_plan_matches_scipy():
+  import scipy.interpolate
+  plan = np.random.default_rng(3).normal(size=(4, 2))
+  t = list(range(0, 40, 10))
+  ref = scipy.interpolate.interp1d(x=t, y=plan, axis=0)(np.arange(0, t[-1]))
+  out = O.interpolate_plan(plan)
+  np.testing.assert_allclose(out[:, :2], ref, atol=1e-12)
+  assert np.all(out[:, 2] == 0)
