@@ -1,0 +1,163 @@
+/*
+ * rip_hip.h — C ABI of librip_hip.so: the MI355X (gfx950) implementation of
+ * oatomobile's deep-imitative-model inference path.
+ *
+ * The reference has no FFI for this path: it is a Python class API
+ *   ImitativeModel  oatomobile/baselines/torch/dim/model.py:36-253
+ *   RIPAgent        oatomobile/baselines/torch/rip/agent.py:30-151
+ *   AutoregressiveFlow oatomobile/torch/networks/sequence.py:28-216
+ * whose tensor math dispatches to ATen.  Each entry point below replaces the
+ * ATen work of one reference method (cited per function) and is what a
+ * maintainer binds with ctypes.  oatomobile_amd/_lib.py is
+ * that binding.
+ *
+ * Conventions
+ *   - return 0 on success, a negative RIP_E* code otherwise; never throws.
+ *     rip_last_error() returns a thread-local message for the last failure.
+ *   - every `*_dev` pointer is caller-owned device memory (e.g. a PyTorch-ROCm
+ *     tensor's data_ptr()), contiguous fp32 unless stated otherwise.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
+ *     the call returns without synchronising.  NULL = the null stream.
+ *   - a handle is bound to one device and is not thread-safe.
+ *   - trajectory shape is fixed at T=4 steps x D=2, hidden size 64, like the
+ *     reference's ImitativeModel(output_shape=(4, 2)) (dim/model.py:41-68).
+ */
+#ifndef RIP_HIP_H_
+#define RIP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rip_handle rip_handle;
+typedef void* rip_stream_t;
+
+enum {
+  RIP_OK = 0,
+  RIP_EINVAL = -1,  /* bad argument (shape, NULL, range) */
+  RIP_EHIP = -2,    /* a HIP runtime call failed */
+  RIP_ESTATE = -3,  /* model k not loaded yet, workspace too small, ... */
+  RIP_ECOMM = -4    /* RCCL failure */
+};
+
+/* rip/agent.py:121-127 as coded: "WCM" = min_k(-posterior), "BCM" = max_k, "MA" = mean_k. */
+enum { RIP_ALGO_WCM = 0, RIP_ALGO_MA = 1, RIP_ALGO_BCM = 2 };
+/* encoder arithmetic: fp32 everywhere, or bf16 weights+activations with fp32 accumulate. */
+enum { RIP_ENC_FP32 = 0, RIP_ENC_BF16 = 1 };
+
+#define RIP_T 4
+#define RIP_D 2
+#define RIP_HIDDEN 64
+#define RIP_MAX_MODELS 8
+#define RIP_MAX_STEPS 64
+
+/* ABI version of this header (bumped on any signature change). */
+int rip_abi_version(void);
+const char* rip_last_error(void);
+
+/* Replaces ImitativeModel.__init__/.to(device) for K ensemble members
+ * (dim/model.py:36-74; rip/agent.py:49-50).  Allocates device weights for K
+ * models with `in_channels` BEV channels and an encoder workspace for up to
+ * `max_batch` observations per call on HIP device `device`. */
+int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int device);
+int rip_destroy(rip_handle* h);
+
+/* Replaces model.load_state_dict(torch.load(ckpt)) (README.md:57-58,
+ * torch/savers.py:45-55).  `packed_host` = the fp32 tensors of the reference
+ * state_dict in its own key order minus the int64 num_batches_tracked counters
+ * (oatomobile_amd/arch.py:packed_spec), `numel` floats.  BatchNorm (eps 1e-5,
+ * running statistics = eval mode) is folded into the preceding conv here. */
+int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel);
+
+/* R2 — ImitativeModel.transform on `lidar` (dim/model.py:245-251 ->
+ * torch/transforms.py:34-49): bilinear (H,W)->(out_hw,out_hw) with
+ * align_corners=True, then swap H and W.  in: [B,C,H,W] (channels_last=0) or
+ * [B,H,W,C] (channels_last=1, the sensor layout rip/agent.py:69 transposes on
+ * the host).  out: [B,C,out_hw,out_hw] NCHW fp32. */
+int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channels_last, int out_hw,
+                  float* out_dev, rip_stream_t stream);
+
+/* R3+R4 — ImitativeModel._params for models [k_begin, k_begin+k_count)
+ * (dim/model.py:173-219): MobileNetV2 encoder -> cat(feat128, vec5) -> merger.
+ * visual_dev [B,C,100,100] (output of rip_transform), vec_dev [B,5] =
+ * (velocity[3], is_at_traffic_light, traffic_light_state).
+ * z_dev [k_count,B,64]; feat_dev optional [k_count,B,128] encoder logits (NULL to skip).
+ * enc_dtype: RIP_ENC_FP32 | RIP_ENC_BF16. */
+int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
+               int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream);
+
+/* Fused R2+R3+R4 for the agent's hot loop: raw sensor BEV [B,200,200,C]
+ * (channels_last=1) or [B,C,200,200] -> z.  Same results as rip_transform + rip_encode. */
+int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, int B,
+                   int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream);
+
+/* R6 — AutoregressiveFlow._forward of model k (sequence.py:95-151).
+ * x_dev [N,4,2]; z_dev [z_rows,64] with z_rows == N or 1 (broadcast);
+ * y_dev [N,4,2]; logabsdet_dev [N] (NULL to skip). */
+int rip_flow_forward(rip_handle* h, int k, const float* x_dev, const float* z_dev, int N, int z_rows,
+                     float* y_dev, float* logabsdet_dev, rip_stream_t stream);
+
+/* R7 — AutoregressiveFlow._inverse of model k (sequence.py:153-216).
+ * y_dev [N,4,2] -> x_dev [N,4,2] (NULL to skip), log_prob_dev [N], logabsdet_dev [N]. */
+int rip_flow_inverse(rip_handle* h, int k, const float* y_dev, const float* z_dev, int N, int z_rows,
+                     float* x_dev, float* log_prob_dev, float* logabsdet_dev, rip_stream_t stream);
+
+/* R9 — ImitativeModel._goal_likelihood per plan row, before its mean(dim=0)
+ * (dim/model.py:143-171).  y_dev [N,4,2]; goal_dev [goal_rows,G,2] with
+ * goal_rows == N or 1; rows_dev [N]. */
+int rip_goal_likelihood(const float* y_dev, const float* goal_dev, int N, int goal_rows, int G, float epsilon,
+                        float* rows_dev, rip_stream_t stream);
+
+/* Scoring mode of R5 (rip/agent.py:109-119, per plan instead of batch mean):
+ * S[k,b,n] = log_prob_k - logabsdet_k (+ goal log-likelihood if goal_dev != NULL)
+ * for models [k_begin, k_begin+k_count).  z_dev [k_count,B,64]; y_dev [B,N,4,2];
+ * goal_dev [B,G,2] or NULL; S_dev [k_count,B,N].  This [K,N] matrix is what the
+ * multi-GPU all-gather carries. */
+int rip_score(rip_handle* h, int k_begin, int k_count, const float* z_dev, const float* y_dev,
+              const float* goal_dev, int B, int N, int G, float epsilon, float* S_dev, rip_stream_t stream);
+
+/* R5 — the RIPAgent.__call__ plan search (rip/agent.py:78-137) for B
+ * observations x N candidate latents, all K loaded models.
+ *   z_dev [K,B,64]; goal_dev [B,G,2]; x0_dev [B,N,4,2] (row n=0 zeros = the
+ *   reference start, rip/agent.py:85-90).
+ * Every candidate runs `num_steps` Adam(lr) steps on its own latent with its own
+ * loss/x_best bookkeeping (post-step x against pre-step loss, :131-135); the
+ * plan of the candidate with the lowest best-loss wins.  N=1 is the reference.
+ * Outputs (any may be NULL): plan_dev [B,4,2]; plans_dev [B,N,4,2];
+ * loss_best_dev [B,N]; best_index_dev [B] int32;
+ * trace_post_dev [num_steps,K,B,N] per-step posteriors;
+ * trace_x_dev [num_steps,B,N,4,2] post-step latents. */
+int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
+               int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
+               float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
+               rip_stream_t stream);
+
+/* R10 — ImitativeModel.forward mode search for model k (dim/model.py:76-141):
+ * z_dev [B,64] (= _params), x0_dev [B,4,2] (the caller draws the base sample,
+ * :100-104), goal_dev [B,G,2] or NULL.  One scalar loss (batch mean) and one
+ * x_best for the whole batch (:124-137).  y_dev [B,4,2];
+ * trace_loss_dev [num_steps] optional. */
+int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_dev, const float* x0_dev, int B,
+                    int G, int num_steps, float lr, float epsilon, float* y_dev, float* trace_loss_dev,
+                    rip_stream_t stream);
+
+/* Whole act() for B observations in one call: rip_encode_raw + rip_search.
+ * lidar_dev [B,200,200,C] (channels_last=1) or [B,C,200,200]; vec_dev [B,5];
+ * goal_dev [B,G,2]; x0_dev [B,N,4,2]; plan_dev [B,4,2].  Scratch lives in the
+ * handle (B <= max_batch). */
+int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, const float* goal_dev,
+            const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr, float epsilon,
+            int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
+
+/* Introspection used by bench.py / tests. */
+int rip_num_models(const rip_handle* h);
+int rip_in_channels(const rip_handle* h);
+int rip_max_batch(const rip_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIP_HIP_H_ */

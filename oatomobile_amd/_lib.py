@@ -1,0 +1,121 @@
+"""ctypes binding of librip_hip.so (C ABI: include/rip_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or does
+not load, importing a symbol from here raises — run `python -c "import
+__graft_entry__ as g; g.build()"` (hipcc, gfx950) first.
+"""
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librip_hip.so")
+
+# (name, restype, argtypes) — must list every symbol include/rip_hip.h declares.
+SIGNATURES = [
+    ("rip_abi_version", c_int, []),
+    ("rip_last_error", c_char_p, []),
+    ("rip_create", c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    ("rip_destroy", c_int, [c_void_p]),
+    ("rip_load_model", c_int, [c_void_p, c_int, c_void_p, c_size_t]),
+    ("rip_transform", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("rip_encode", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("rip_encode_raw", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("rip_flow_forward", c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("rip_flow_inverse", c_int,
+     [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("rip_goal_likelihood", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    ("rip_score", c_int,
+     [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    ("rip_search", c_int, [
+        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p,
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p
+    ]),
+    ("rip_dim_forward", c_int,
+     [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+      c_void_p]),
+    ("rip_act", c_int, [
+        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+        c_int, c_void_p, c_void_p, c_void_p
+    ]),
+    ("rip_num_models", c_int, [c_void_p]),
+    ("rip_in_channels", c_int, [c_void_p]),
+    ("rip_max_batch", c_int, [c_void_p]),
+]
+
+ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
+ENC_DTYPES = {"fp32": 0, "bf16": 1}
+
+_lib = None
+
+
+class RipError(RuntimeError):
+  """A librip_hip.so entry point returned a negative code."""
+
+
+def load() -> ctypes.CDLL:
+  """Loads librip_hip.so once and types every entry point; raises if it is absent."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "oatomobile_amd: %s is missing — the HIP extension is not built "
+        "(run `python -c \"import __graft_entry__ as g; g.build()\"`). There is no CPU fallback." % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, restype, argtypes in SIGNATURES:
+    fn = getattr(lib, name)  # AttributeError if the .so is stale
+    fn.restype = restype
+    fn.argtypes = argtypes
+  _lib = lib
+  return lib
+
+
+def check(rc: int) -> None:
+  if rc != 0:
+    msg = load().rip_last_error()
+    raise RipError("librip_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t) -> c_void_p:
+  """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or NULL for None."""
+  if t is None:
+    return c_void_p(0)
+  assert t.is_cuda and t.is_contiguous(), "expected a contiguous device tensor"
+  return c_void_p(t.data_ptr())
+
+
+def current_stream() -> c_void_p:
+  import torch
+  return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Handle:
+  """Owns one `rip_handle*` (K models on one device)."""
+
+  def __init__(self, num_models: int, in_channels: int, max_batch: int, device_index: int) -> None:
+    self._lib = load()
+    self._h = c_void_p(0)
+    check(self._lib.rip_create(ctypes.byref(self._h), num_models, in_channels, max_batch, device_index))
+    self.num_models, self.in_channels, self.max_batch, self.device_index = num_models, in_channels, max_batch, device_index
+
+  @property
+  def raw(self) -> c_void_p:
+    return self._h
+
+  def load_model(self, k: int, packed) -> None:
+    import numpy as np
+    packed = np.ascontiguousarray(packed, dtype=np.float32)
+    check(self._lib.rip_load_model(self._h, k, packed.ctypes.data_as(c_void_p), packed.size))
+
+  def close(self) -> None:
+    if self._h:
+      self._lib.rip_destroy(self._h)
+      self._h = c_void_p(0)
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass

@@ -1,0 +1,216 @@
+"""Agents: `RIPAgent`, `DIMAgent` and the CARLA-free part of `SetPointAgent`.
+
+Mirrors oatomobile/baselines/torch/rip/agent.py, .../dim/agent.py and
+oatomobile/baselines/base.py.  `__call__(observation) -> [30, 3]` ego-frame
+plan is the hot path (HIP); `act()` additionally needs CARLA's PID controller
+and map, which the reference imports from the CARLA PythonAPI (base.py:71-77) —
+with `environment=None` the agents run offline and `act()` returns the
+setpoint/target-speed pair the PID would consume.
+"""
+
+import copy
+from typing import Any, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from oatomobile_amd import _lib
+from oatomobile_amd import arch
+from oatomobile_amd.model import ImitativeModel
+
+SIMULATOR_FPS = 20  # base.py:31
+
+
+def interpolate_plan(plan: np.ndarray, player_future_length: int = 40) -> np.ndarray:
+  """rip/agent.py:141-151 == dim/agent.py:74-84: `[T,2]` -> `[(T-1)*inc, 3]` float64.
+  Linear interpolation between knots every `inc = 40 // T` ticks (what
+  `scipy.interpolate.interp1d` does there), evaluated at 0..knots[-1]-1, z = 0."""
+  plan = np.asarray(plan)
+  T = plan.shape[0]
+  inc = player_future_length // T
+  knots = np.arange(0, player_future_length, inc)[:T]  # time_index, rip/agent.py:145
+  q = np.arange(0, int(knots[-1]))
+  # scipy 1-D linear interpolation: the segment is found with a left-sided search (a query that sits on
+  # a knot uses the segment ending there) and evaluated in slope form; (y_hi - y_lo) keeps the plan's
+  # dtype (float32 from the device), the rest promotes to float64.
+  hi = np.clip(np.searchsorted(knots, q), 1, T - 1)
+  lo = hi - 1
+  slope = (plan[hi] - plan[lo]) / (knots[hi] - knots[lo])[:, None]
+  xy = slope * (q - knots[lo])[:, None] + plan[lo]
+  return np.c_[xy, np.zeros((xy.shape[0], 1))].astype(np.float64)
+
+
+def rot2mat(rotation: np.ndarray) -> np.ndarray:
+  """utils/carla.py:642-649: `transforms3d.euler.euler2mat(roll, pitch, yaw).T` (static 'sxyz'),
+  rotation given as (pitch, yaw, roll) in degrees like `carla.Rotation`."""
+  pitch, yaw, roll = np.deg2rad(np.asarray(rotation, dtype=np.float64))
+  ci, si = np.cos(roll), np.sin(roll)
+  cj, sj = np.cos(pitch), np.sin(pitch)
+  ck, sk = np.cos(yaw), np.sin(yaw)
+  cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+  m = np.array([[cj * ck, sj * sc - cs, sj * cc + ss], [cj * sk, sj * ss + cc, sj * cs - sc], [-sj, cj * si, cj * ci]])
+  return m.T
+
+
+def world2local(*, current_location: np.ndarray, current_rotation: np.ndarray, world_locations: np.ndarray) -> np.ndarray:
+  """utils/carla.py:652-674."""
+  assert current_location.shape == (3,) and current_rotation.shape == (3,) and world_locations.ndim < 3
+  world_locations = np.atleast_2d(world_locations)
+  R = rot2mat(current_rotation)
+  return np.squeeze(np.dot(R, (world_locations - current_location).T).T)
+
+
+def local2world(*, current_location: np.ndarray, current_rotation: np.ndarray, local_locations: np.ndarray) -> np.ndarray:
+  """utils/carla.py:677-700."""
+  assert current_location.shape == (3,) and current_rotation.shape == (3,) and local_locations.ndim < 3
+  local_locations = np.atleast_2d(local_locations)
+  R_inv = np.linalg.inv(rot2mat(current_rotation))
+  return np.dot(R_inv, local_locations.T).T + current_location
+
+
+class SetPointAgent:
+  """CARLA-free restatement of base.py:46-176: replan/buffer logic, ego->world
+  transform and target speed.  With a CARLA `environment` the caller wires the
+  returned setpoint into `VehiclePIDController.run_step` exactly as base.py:162-174."""
+
+  def __init__(self, environment: Any = None, *, setpoint_index: int = 5, replan_every_steps: int = 1,
+               lateral_control_dict: Optional[Mapping[str, Any]] = None,
+               longitudinal_control_dict: Optional[Mapping[str, Any]] = None,
+               fixed_delta_seconds_between_setpoints: Optional[float] = None) -> None:
+    self._environment = environment
+    self._setpoint_index = setpoint_index
+    self._replan_every_steps = replan_every_steps
+    self._lateral_control_dict = dict(lateral_control_dict or {"K_P": 1.95, "K_D": 0.01, "K_I": 1.4})
+    self._longitudinal_control_dict = dict(longitudinal_control_dict or {"K_P": 1.0, "K_D": 0, "K_I": 1.0})
+    self._fixed_delta_seconds_between_setpoints = fixed_delta_seconds_between_setpoints or 1.0 / SIMULATOR_FPS
+    self._setpoints_buffer = None
+    self._steps_counter = 0
+
+  def __call__(self, observation, *args, **kwargs) -> np.ndarray:
+    raise NotImplementedError
+
+  def act(self, observation: Mapping[str, np.ndarray], *args, **kwargs):
+    """base.py:116-176 up to the PID call: returns dict(setpoint [3] world frame, target_speed m/s,
+    plan_world [T,3])."""
+    current_location = np.asarray(observation["location"], dtype=np.float64)
+    current_rotation = np.asarray(observation["rotation"], dtype=np.float64)
+    if self._setpoints_buffer is None or self._steps_counter % self._replan_every_steps == 0:
+      plan_ego = self(copy.deepcopy(dict(observation)), *args, **kwargs)  # base.py:128
+      self._setpoints_buffer = local2world(current_location=current_location, current_rotation=current_rotation,
+                                           local_locations=plan_ego)
+    else:
+      self._setpoints_buffer = self._setpoints_buffer[1:]  # base.py:142
+    self._steps_counter += 1
+    target_speed = np.linalg.norm(np.diff(self._setpoints_buffer[:self._setpoint_index], axis=0),
+                                  axis=1).mean() / self._fixed_delta_seconds_between_setpoints  # base.py:156-159
+    if self._steps_counter <= 100:  # base.py:166-167
+      target_speed = 20.0 / 3.6
+    return dict(setpoint=self._setpoints_buffer[self._setpoint_index], target_speed=target_speed,
+                plan_world=self._setpoints_buffer)
+
+  def update(self, *args, **kwargs) -> None:  # core/agent.py:39-48
+    return None
+
+
+def _prepare_observation(observation: Mapping[str, Any], in_channels: int):
+  """rip/agent.py:59-69 on the host (only the keys the model reads): float32 casts, goal[..., :2]."""
+  lidar = np.ascontiguousarray(observation["lidar"], dtype=np.float32)
+  if lidar.ndim != 3 or lidar.shape[-1] != in_channels:
+    raise ValueError("observation['lidar'] must be [H,W,%d], got %s" % (in_channels, lidar.shape))
+  vec = np.concatenate([
+      np.atleast_1d(np.asarray(observation["velocity"], dtype=np.float32)).reshape(3),
+      np.atleast_1d(np.asarray(observation["is_at_traffic_light"], dtype=np.float32)).reshape(1),
+      np.atleast_1d(np.asarray(observation["traffic_light_state"], dtype=np.float32)).reshape(1),
+  ])
+  goal = np.ascontiguousarray(np.asarray(observation["goal"], dtype=np.float32)[..., :2])
+  return lidar, vec, goal
+
+
+class RIPAgent(SetPointAgent):
+  """The robust imitative planning agent (rip/agent.py:30-151) on one MI355X.
+
+  Extra keyword arguments (defaults reproduce rip/agent.py:78-80,85-90):
+    num_candidates: N latent starts searched in parallel (row 0 = zeros = the reference start,
+      rows 1.. ~ N(0, I) from `seed`); each runs the reference recipe independently and the
+      candidate with the lowest best-loss wins.  N = 1 is the reference algorithm.
+    num_steps / lr / epsilon: hard-coded 10 / 0.1 / 1.0 in the reference.
+    max_batch: observations per `plan_batch` call.
+  """
+
+  def __init__(self, environment: Any = None, *, algorithm: str, models: Sequence[ImitativeModel],
+               num_candidates: int = 1, num_steps: int = 10, lr: float = 1e-1, epsilon: float = 1.0, seed: int = 0,
+               max_batch: int = 1, device: Optional[torch.device] = None, **kwargs) -> None:
+    assert algorithm in ("WCM", "MA", "BCM")  # rip/agent.py:43
+    self._algorithm = algorithm
+    super().__init__(environment=environment, **kwargs)
+    if not torch.cuda.is_available():
+      raise RuntimeError("oatomobile_amd.RIPAgent needs a ROCm device; there is no CPU path.")
+    self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    self._models = [model.to(self._device) for model in models]  # rip/agent.py:50
+    self._in_channels = self._models[0]._in_channels
+    self._num_candidates, self._num_steps, self._lr, self._epsilon = int(num_candidates), int(num_steps), float(lr), float(epsilon)
+    self._max_batch = int(max_batch)
+    self._handle = _lib.Handle(len(self._models), self._in_channels, self._max_batch,
+                               self._device.index if self._device.index is not None else torch.cuda.current_device())
+    for k, m in enumerate(self._models):
+      self._handle.load_model(k, m.packed_weights())
+    rng = np.random.default_rng(seed)
+    x0 = rng.standard_normal((self._num_candidates, arch_T(), 2)).astype(np.float32)
+    x0[0] = 0.0  # base distribution mean (rip/agent.py:85)
+    self._x0_rows = torch.from_numpy(x0).to(self._device)
+    self._x0_cache = {}
+
+  def _x0(self, batch: int) -> torch.Tensor:
+    if batch not in self._x0_cache:
+      self._x0_cache[batch] = self._x0_rows.unsqueeze(0).expand(batch, -1, -1, -1).contiguous()
+    return self._x0_cache[batch]
+
+  def plan_batch(self, lidar: torch.Tensor, vec: torch.Tensor, goal: torch.Tensor,
+                 return_loss: bool = False):
+    """Device-resident batched planning: lidar [B,200,200,C] (sensor layout), vec [B,5], goal [B,G,2]
+    -> plans [B,4,2] (and best losses [B,N]).  One rip_act call (transform + K encoders + search)."""
+    b = lidar.shape[0]
+    plan = torch.empty(b, arch_T(), 2, device=self._device, dtype=torch.float32)
+    loss = torch.empty(b, self._num_candidates, device=self._device, dtype=torch.float32) if return_loss else None
+    lib = _lib.load()
+    _lib.check(lib.rip_act(self._handle.raw, _lib.ptr(lidar), 1, _lib.ptr(vec), _lib.ptr(goal), _lib.ptr(self._x0(b)), b,
+                           self._num_candidates, goal.shape[1], _lib.ALGORITHMS[self._algorithm], self._num_steps,
+                           self._lr, self._epsilon, 0, _lib.ptr(plan), _lib.ptr(loss), _lib.current_stream()))
+    return (plan, loss) if return_loss else plan
+
+  def __call__(self, observation: Mapping[str, np.ndarray]) -> np.ndarray:
+    """Returns the imitative-prior plan [30, 3] in ego coordinates (rip/agent.py:52-151)."""
+    lidar, vec, goal = _prepare_observation(observation, self._in_channels)
+    lidar_d = torch.from_numpy(lidar).to(self._device, non_blocking=True).unsqueeze(0)
+    vec_d = torch.from_numpy(vec).to(self._device, non_blocking=True).unsqueeze(0)
+    goal_d = torch.from_numpy(goal).to(self._device, non_blocking=True).unsqueeze(0)
+    plan = self.plan_batch(lidar_d, vec_d, goal_d).cpu().numpy()[0]  # rip/agent.py:139
+    return interpolate_plan(plan)
+
+
+class DIMAgent(SetPointAgent):
+  """The deep imitative model agent (dim/agent.py:31-84): single-model mode search."""
+
+  def __init__(self, environment: Any = None, *, model: ImitativeModel, device: Optional[torch.device] = None,
+               **kwargs) -> None:
+    super().__init__(environment=environment, **kwargs)
+    if not torch.cuda.is_available():
+      raise RuntimeError("oatomobile_amd.DIMAgent needs a ROCm device; there is no CPU path.")
+    self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    self._model = model.to(self._device)
+
+  def __call__(self, observation: Mapping[str, np.ndarray], **kwargs) -> np.ndarray:
+    lidar, vec, goal = _prepare_observation(observation, self._model._in_channels)
+    from oatomobile_amd.model import transform_visual
+    lidar_d = torch.from_numpy(lidar).to(self._device).unsqueeze(0)
+    vis = transform_visual(lidar_d, channels_last=True)
+    vec_d = torch.from_numpy(vec).to(self._device).unsqueeze(0)
+    plan = self._model(num_steps=kwargs.get("num_steps", 20), epsilon=kwargs.get("epsilon", 1.0),
+                       lr=kwargs.get("lr", 5e-2), x0=kwargs.get("x0"), goal=torch.from_numpy(goal).to(self._device).unsqueeze(0),
+                       visual_features=vis, velocity=vec_d[:, :3], is_at_traffic_light=vec_d[:, 3:4],
+                       traffic_light_state=vec_d[:, 4:5]).cpu().numpy()[0]  # dim/agent.py:69-72
+    return interpolate_plan(plan)
+
+
+def arch_T() -> int:
+  return 4

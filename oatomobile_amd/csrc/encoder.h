@@ -1,0 +1,51 @@
+// Internal C++ interface between the C ABI (rip_abi.hip) and the encoder kernels (encoder.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace rip {
+
+enum LayerKind { L_STEM = 0, L_DW = 1, L_PW = 2 };
+
+// One conv layer of the BN-folded MobileNetV2 (torchvision v0.6.0 layout; reference call site
+// oatomobile/torch/networks/perception.py:36-51).  Offsets are in floats into the per-model
+// encoder blob; activations are NHWC fp32, [K][B][H][W][C].
+struct Layer {
+  int kind;
+  int cin, cout;
+  int h_in, h_out, stride;
+  int relu6;      // ReLU6 after the folded BN
+  int residual;   // add the block input (projection layers of stride-1, equal-width blocks)
+  size_t w_off, b_off;
+  int src, dst, res;  // workspace buffer ids (0..3); src == -1 -> the [B,C,100,100] network input
+};
+
+struct EncoderPlan {
+  int in_channels;
+  std::vector<Layer> layers;
+  size_t cls_w_off, cls_b_off;     // classifier.1  [128][1280], [128]
+  size_t mrg_w_off[3], mrg_b_off[3];  // merger Linear 133->64, 64->64, 64->64
+  size_t blob_floats;              // per-model folded blob size
+  size_t max_act_floats;           // largest activation per image
+  int final_buf;                   // buffer holding features.18 output [16][1280]
+  int final_hw;                    // 4
+};
+
+EncoderPlan build_encoder_plan(int in_channels);
+
+// Folds BN and re-lays the packed reference tensors (arch.py:packed_spec order) into the encoder blob
+// and the flow blob (flow.h layout).  Returns false (and a message) on size mismatch.
+bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc_blob,
+                   std::vector<float>& flow_blob, const char** err);
+
+hipError_t launch_transform(const float* in, int B, int C, int H, int W, int channels_last, int out_hw, float* out,
+                            hipStream_t s);
+
+// Runs the encoder + merger for models [k0, k0+kc) on B observations.
+//   enc_w: [K_total][plan.blob_floats]; visual [B,C,100,100]; vec [B,5]; bufs[4]: each >= kc*B*max_act floats.
+hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
+                          const float* vec, int B, float* const bufs[4], float* z, float* feat, hipStream_t s);
+
+}  // namespace rip

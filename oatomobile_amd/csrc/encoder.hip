@@ -1,0 +1,487 @@
+// MobileNetV2 BEV encoder + merger for gfx950, BN folded, NHWC fp32 activations.
+//
+// Replaces the ATen work of ImitativeModel._params (oatomobile/baselines/torch/dim/model.py:173-219):
+//   K1 transform          torch/transforms.py:34-49   -> transform_kernel
+//   K2 stem 3x3 s2        perception.py:43-51 / torchvision features.0     -> stem_kernel
+//   K3 depthwise 3x3      torchvision features.{1..17}.conv.*              -> dw_kernel (HBM-bound, float4/lane)
+//   K4 pointwise 1x1      torchvision features.*.conv.*, features.18       -> pw_kernel (fp32-input MFMA 32x32x2)
+//   K5/K6 pool+classifier+merger  dim/model.py:203-217                     -> tail_kernel
+// All K ensemble members run in the same launches (blockIdx.z = model).
+#include "encoder.h"
+#include "flow.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace rip {
+
+namespace {
+
+constexpr int IR_SETTING[7][4] = {{1, 16, 1, 1}, {6, 24, 2, 2}, {6, 32, 3, 2}, {6, 64, 4, 2},
+                                  {6, 96, 3, 1}, {6, 160, 3, 2}, {6, 320, 1, 1}};
+constexpr int STEM_C = 32, LAST_C = 1280, FEAT = 128, VEC = 5, HID = 64, IN_HW = 100;
+constexpr double BN_EPS = 1e-5;
+
+inline int conv_out(int h, int stride) { return (h + 2 - 3) / stride + 1; }
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+
+// ------------------------------------------------------------------------------------------------
+// K1: bilinear (H,W)->(O,O), align_corners=True, then swap H/W.  out[b][c][i][j] = interp[b][c][j][i].
+// ATen computes scale=(in-1)/(out-1) and src=scale*dst in fp32 (UpSample.h area_pixel_compute_*).
+// ------------------------------------------------------------------------------------------------
+__global__ void transform_kernel(const float* __restrict__ in, int B, int C, int H, int W, int channels_last, int O,
+                                 float* __restrict__ out) {
+  const int total = B * C * O * O;
+  const float sh = O > 1 ? (float)(H - 1) / (float)(O - 1) : 0.f;
+  const float sw = O > 1 ? (float)(W - 1) / (float)(O - 1) : 0.f;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx % O;          // output column  == interpolated row
+    const int i = (idx / O) % O;    // output row     == interpolated column
+    const int c = (idx / (O * O)) % C;
+    const int b = idx / (O * O * C);
+    const float fy = sh * (float)j, fx = sw * (float)i;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v00, v01, v10, v11;
+    if (channels_last) {
+      const float* p = in + (size_t)b * H * W * C + c;
+      v00 = p[((size_t)y0 * W + x0) * C];
+      v01 = p[((size_t)y0 * W + x1) * C];
+      v10 = p[((size_t)y1 * W + x0) * C];
+      v11 = p[((size_t)y1 * W + x1) * C];
+    } else {
+      const float* p = in + ((size_t)b * C + c) * H * W;
+      v00 = p[(size_t)y0 * W + x0];
+      v01 = p[(size_t)y0 * W + x1];
+      v10 = p[(size_t)y1 * W + x0];
+      v11 = p[(size_t)y1 * W + x1];
+    }
+    out[idx] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: stem conv 3x3 stride 2 pad 1 (+folded BN, ReLU6).  in: [B][C][Hin][Hin] NCHW (shared by all
+// models), w: [tap][c][32], out: [K][B][Ho][Ho][32].  thread = (pixel, 4 output channels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                    size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
+                                                    int C, int Hin, int Ho, float* __restrict__ out) {
+  const int k = blockIdx.z;
+  const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const int total = B * Ho * Ho * 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int oc4 = idx & 7;
+  const int pix = idx >> 3;
+  const int ox = pix % Ho, oy = (pix / Ho) % Ho, b = pix / (Ho * Ho);
+  float4 acc = *reinterpret_cast<const float4*>(bias + oc4 * 4);
+  for (int c = 0; c < C; ++c) {
+    const float* ip = in + ((size_t)b * C + c) * Hin * Hin;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= Hin) continue;
+        const float v = ip[(size_t)iy * Hin + ix];
+        const float4 wv = *reinterpret_cast<const float4*>(w + ((ky * 3 + kx) * C + c) * 32 + oc4 * 4);
+        acc.x = fmaf(v, wv.x, acc.x);
+        acc.y = fmaf(v, wv.y, acc.y);
+        acc.z = fmaf(v, wv.z, acc.z);
+        acc.w = fmaf(v, wv.w, acc.w);
+      }
+    }
+  }
+  acc.x = relu6f(acc.x);
+  acc.y = relu6f(acc.y);
+  acc.z = relu6f(acc.z);
+  acc.w = relu6f(acc.w);
+  float* op = out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * 32 + oc4 * 4;
+  *reinterpret_cast<float4*>(op) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: depthwise 3x3 (+folded BN, ReLU6), NHWC.  w: [9][C].  thread = (output pixel, 4 channels):
+// every global access is a float4 with the channel index fastest -> fully coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                  size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
+                                                  int C, int Hin, int Ho, int stride, float* __restrict__ out) {
+  const int k = blockIdx.z;
+  const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const int C4 = C >> 2;
+  const long total = (long)B * Ho * Ho * C4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  const long pix = idx / C4;
+  const int ox = (int)(pix % Ho), oy = (int)((pix / Ho) % Ho), b = (int)(pix / ((long)Ho * Ho));
+  const float* ip = in + ((size_t)k * B + b) * Hin * Hin * C + c4 * 4;
+  float4 acc = *reinterpret_cast<const float4*>(bias + c4 * 4);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * stride - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * stride - 1 + kx;
+      if (ix < 0 || ix >= Hin) continue;
+      const float4 v = *reinterpret_cast<const float4*>(ip + ((size_t)iy * Hin + ix) * C);
+      const float4 wv = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c4 * 4);
+      acc.x = fmaf(v.x, wv.x, acc.x);
+      acc.y = fmaf(v.y, wv.y, acc.y);
+      acc.z = fmaf(v.z, wv.z, acc.z);
+      acc.w = fmaf(v.w, wv.w, acc.w);
+    }
+  }
+  acc.x = relu6f(acc.x);
+  acc.y = relu6f(acc.y);
+  acc.z = relu6f(acc.z);
+  acc.w = relu6f(acc.w);
+  float* op = out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * C + c4 * 4;
+  *reinterpret_cast<float4*>(op) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: pointwise conv as GEMM  out[M][Cout] = act(in[M][Cin] * W[Cout][Cin]^T + bias) (+ residual),
+// M = B*H*W rows of one model.  fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, bitwise an fmaf
+// chain).  Block = 4 waves, tile 64x64, each wave one 32x32 accumulator; K tiles of 32 through LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int PW_BM = 64, PW_BN = 64, PW_BK = 32, PW_LD = PW_BK + 1;
+
+__global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                  size_t model_stride, int k0, size_t w_off, size_t b_off,
+                                                  const float* __restrict__ res, float* __restrict__ out, int M,
+                                                  int Cin, int Cout, int relu6, size_t act_model_stride_in,
+                                                  size_t act_model_stride_out) {
+  __shared__ float As[PW_BM * PW_LD];
+  __shared__ float Ws[PW_BN * PW_LD];
+  const int k = blockIdx.z;
+  const float* A = in + (size_t)k * act_model_stride_in;
+  const float* Wg = wbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  float* O = out + (size_t)k * act_model_stride_out;
+  const float* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
+  const int m0 = blockIdx.x * PW_BM, n0 = blockIdx.y * PW_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  for (int kt = 0; kt < Cin; kt += PW_BK) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256;
+      const int row = e >> 3, c4 = (e & 7) * 4;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
+      if (m0 + row < M && kt + c4 < Cin) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * Cin + kt + c4);
+      if (n0 + row < Cout && kt + c4 < Cin)
+        vw = *reinterpret_cast<const float4*>(Wg + (size_t)(n0 + row) * Cin + kt + c4);
+      float* pa = As + row * PW_LD + c4;
+      pa[0] = va.x;
+      pa[1] = va.y;
+      pa[2] = va.z;
+      pa[3] = va.w;
+      float* pw = Ws + row * PW_LD + c4;
+      pw[0] = vw.x;
+      pw[1] = vw.y;
+      pw[2] = vw.z;
+      pw[3] = vw.w;
+    }
+    __syncthreads();
+    const float* ar = As + (wr * 32 + (lane & 31)) * PW_LD + (lane >> 5);
+    const float* br = Ws + (wc * 32 + (lane & 31)) * PW_LD + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < PW_BK / 2; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * kk], br[2 * kk], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int n = n0 + wc * 32 + (lane & 31);
+  if (n < Cout) {
+    const float bv = bias[n];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      if (m < M) {
+        float v = acc[reg] + bv;
+        if (R != nullptr) v += R[(size_t)m * Cout + n];
+        if (relu6) v = relu6f(v);
+        O[(size_t)m * Cout + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5+K6: global average pool -> classifier Linear(1280,128) -> cat(vec5) -> merger 3x(Linear+ReLU).
+// One block per (model, observation).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act, const float* __restrict__ wbase,
+                                                    size_t model_stride, int k0, size_t cls_w, size_t cls_b,
+                                                    size_t m0w, size_t m0b, size_t m1w, size_t m1b, size_t m2w,
+                                                    size_t m2b, const float* __restrict__ vec, int B, int HW,
+                                                    float* __restrict__ z, float* __restrict__ feat_out) {
+  __shared__ float pooled[LAST_C];
+  __shared__ float v133[FEAT + VEC + 3];
+  __shared__ float hbuf[2][HID];
+  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* W = wbase + (size_t)(k0 + k) * model_stride;
+  const float* a = act + ((size_t)k * B + b) * HW * LAST_C;
+  for (int c = tid; c < LAST_C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += a[(size_t)p * LAST_C + c];
+    pooled[c] = s / (float)HW;
+  }
+  __syncthreads();
+  // classifier: 128 outputs, each wave takes 32 of them; lanes stride the 1280 inputs (coalesced rows)
+  for (int o = wave; o < FEAT; o += 4) {
+    const float* wr = W + cls_w + (size_t)o * LAST_C;
+    float s = 0.f;
+    for (int i = lane; i < LAST_C; i += 64) s = fmaf(wr[i], pooled[i], s);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) {
+      const float f = s + W[cls_b + o];
+      v133[o] = f;
+      if (feat_out != nullptr) feat_out[((size_t)k * B + b) * FEAT + o] = f;
+    }
+  }
+  if (tid < VEC) v133[FEAT + tid] = vec[(size_t)b * VEC + tid];
+  __syncthreads();
+  if (tid < HID) {
+    const float* wr = W + m0w + (size_t)tid * (FEAT + VEC);
+    float s = W[m0b + tid];
+    for (int i = 0; i < FEAT + VEC; ++i) s = fmaf(wr[i], v133[i], s);
+    hbuf[0][tid] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  if (tid < HID) {
+    const float* wr = W + m1w + (size_t)tid * HID;
+    float s = W[m1b + tid];
+    for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[0][i], s);
+    hbuf[1][tid] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  if (tid < HID) {
+    const float* wr = W + m2w + (size_t)tid * HID;
+    float s = W[m2b + tid];
+    for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[1][i], s);
+    z[((size_t)k * B + b) * HID + tid] = fmaxf(s, 0.f);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host: plan, BN folding, launch sequence
+// ------------------------------------------------------------------------------------------------
+EncoderPlan build_encoder_plan(int in_channels) {
+  EncoderPlan p;
+  p.in_channels = in_channels;
+  size_t off = 0;
+  size_t max_act = 0;
+  auto add = [&](int kind, int cin, int cout, int h_in, int stride, int relu6, int residual, int src, int dst,
+                 int res) {
+    Layer l;
+    l.kind = kind;
+    l.cin = cin;
+    l.cout = cout;
+    l.h_in = h_in;
+    l.stride = stride;
+    l.h_out = kind == L_PW ? h_in : conv_out(h_in, stride);
+    l.relu6 = relu6;
+    l.residual = residual;
+    l.src = src;
+    l.dst = dst;
+    l.res = res;
+    const size_t wn = kind == L_STEM ? (size_t)9 * cin * cout : (kind == L_DW ? (size_t)9 * cout : (size_t)cin * cout);
+    l.w_off = off;
+    off += (wn + 3) / 4 * 4;
+    l.b_off = off;
+    off += ((size_t)cout + 3) / 4 * 4;
+    const size_t act = (size_t)l.h_out * l.h_out * cout;
+    if (act > max_act) max_act = act;
+    p.layers.push_back(l);
+    return l.h_out;
+  };
+  int h = add(L_STEM, in_channels, STEM_C, IN_HW, 2, 1, 0, -1, 0, -1);
+  int cur = 0, inp = STEM_C;
+  for (int s = 0; s < 7; ++s) {
+    const int t = IR_SETTING[s][0], c = IR_SETTING[s][1], n = IR_SETTING[s][2], st = IR_SETTING[s][3];
+    for (int i = 0; i < n; ++i) {
+      const int stride = i == 0 ? st : 1;
+      const int hidden = inp * t;
+      const int e = (cur + 1) & 3, d = (cur + 2) & 3, o = (cur + 3) & 3;
+      int src = cur;
+      if (t != 1) {
+        add(L_PW, inp, hidden, h, 1, 1, 0, cur, e, -1);
+        src = e;
+      }
+      const int h2 = add(L_DW, hidden, hidden, h, stride, 1, 0, src, d, -1);
+      const int residual = (stride == 1 && inp == c) ? 1 : 0;
+      add(L_PW, hidden, c, h2, 1, 0, residual, d, o, residual ? cur : -1);
+      cur = o;
+      inp = c;
+      h = h2;
+    }
+  }
+  const int last = (cur + 1) & 3;
+  add(L_PW, inp, LAST_C, h, 1, 1, 0, cur, last, -1);
+  p.final_buf = last;
+  p.final_hw = h;
+  auto lin = [&](size_t n) {
+    const size_t o = off;
+    off += (n + 3) / 4 * 4;
+    return o;
+  };
+  p.cls_w_off = lin((size_t)FEAT * LAST_C);
+  p.cls_b_off = lin(FEAT);
+  const int sizes[4] = {FEAT + VEC, HID, HID, HID};
+  for (int i = 0; i < 3; ++i) {
+    p.mrg_w_off[i] = lin((size_t)sizes[i + 1] * sizes[i]);
+    p.mrg_b_off[i] = lin(sizes[i + 1]);
+  }
+  p.blob_floats = off;
+  p.max_act_floats = max_act;
+  return p;
+}
+
+bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc,
+                   std::vector<float>& flow, const char** err) {
+  enc.assign(plan.blob_floats, 0.f);
+  flow.assign(FW_SIZE, 0.f);
+  size_t pos = 0;
+  auto need = [&](size_t n) { return pos + n <= numel; };
+  for (const Layer& l : plan.layers) {
+    const size_t per_out = l.kind == L_STEM ? (size_t)l.cin * 9 : (l.kind == L_DW ? 9 : (size_t)l.cin);
+    const size_t wn = per_out * l.cout;
+    if (!need(wn + 4 * (size_t)l.cout)) {
+      *err = "packed state_dict too short (encoder)";
+      return false;
+    }
+    const float* w = packed + pos;
+    const float* gamma = w + wn;
+    const float* beta = gamma + l.cout;
+    const float* mean = beta + l.cout;
+    const float* var = mean + l.cout;
+    pos += wn + 4 * (size_t)l.cout;
+    for (int oc = 0; oc < l.cout; ++oc) {
+      const double scale = (double)gamma[oc] / std::sqrt((double)var[oc] + BN_EPS);
+      enc[l.b_off + oc] = (float)((double)beta[oc] - (double)mean[oc] * scale);
+      for (size_t i = 0; i < per_out; ++i) {
+        const float v = (float)((double)w[(size_t)oc * per_out + i] * scale);
+        if (l.kind == L_STEM) {
+          // reference [oc][c][ky][kx] -> [tap][c][oc]
+          const int c = (int)(i / 9), tap = (int)(i % 9);
+          enc[l.w_off + ((size_t)tap * l.cin + c) * l.cout + oc] = v;
+        } else if (l.kind == L_DW) {
+          enc[l.w_off + i * l.cout + oc] = v;  // [oc][1][ky][kx] -> [tap][oc]
+        } else {
+          enc[l.w_off + (size_t)oc * l.cin + i] = v;  // [oc][cin] kept
+        }
+      }
+    }
+  }
+  auto copy = [&](size_t dst_off, size_t n) {
+    if (!need(n)) return false;
+    std::memcpy(enc.data() + dst_off, packed + pos, n * sizeof(float));
+    pos += n;
+    return true;
+  };
+  bool ok = copy(plan.cls_w_off, (size_t)FEAT * LAST_C) && copy(plan.cls_b_off, FEAT);
+  const int sizes[4] = {FEAT + VEC, HID, HID, HID};
+  for (int i = 0; i < 3 && ok; ++i)
+    ok = copy(plan.mrg_w_off[i], (size_t)sizes[i + 1] * sizes[i]) && copy(plan.mrg_b_off[i], sizes[i + 1]);
+  if (!ok) {
+    *err = "packed state_dict too short (classifier/merger)";
+    return false;
+  }
+  // ---- flow: GRUCell + head, re-laid lane-major (flow.h) ----
+  const size_t fl = 192 * 2 + 192 * 64 + 192 + 192 + 32 * 64 + 32 + 4 * 32 + 4;
+  if (pos + fl != numel) {
+    *err = "packed state_dict has the wrong length";
+    return false;
+  }
+  const float* wih = packed + pos;
+  const float* whh = wih + 192 * 2;
+  const float* bih = whh + 192 * 64;
+  const float* bhh = bih + 192;
+  const float* w1 = bhh + 192;
+  const float* b1 = w1 + 32 * 64;
+  const float* w2 = b1 + 32;
+  const float* b2 = w2 + 4 * 32;
+  for (int g = 0; g < 3; ++g)
+    for (int i4 = 0; i4 < 16; ++i4)
+      for (int j = 0; j < 64; ++j)
+        for (int q = 0; q < 4; ++q)
+          flow[FW_WHH + (((size_t)(g * 16 + i4) * 64 + j) * 4) + q] = whh[(size_t)(g * 64 + j) * 64 + 4 * i4 + q];
+  for (int g = 0; g < 3; ++g)
+    for (int j = 0; j < 64; ++j) {
+      flow[FW_WIH + (g * 2 + 0) * 64 + j] = wih[(g * 64 + j) * 2 + 0];
+      flow[FW_WIH + (g * 2 + 1) * 64 + j] = wih[(g * 64 + j) * 2 + 1];
+      flow[FW_BIH + g * 64 + j] = bih[g * 64 + j];
+      flow[FW_BHH + g * 64 + j] = bhh[g * 64 + j];
+    }
+  for (int j = 0; j < 64; ++j) {
+    flow[FW_B1 + j] = b1[j & 31];
+    flow[FW_W2 + j] = w2[(2 * (j >> 5) + 0) * 32 + (j & 31)];
+    flow[FW_W2 + 64 + j] = w2[(2 * (j >> 5) + 1) * 32 + (j & 31)];
+  }
+  for (int c = 0; c < 4; ++c) flow[FW_B2 + c] = b2[c];
+  std::memcpy(flow.data() + FW_W1, w1, 32 * 64 * sizeof(float));
+  return true;
+}
+
+hipError_t launch_transform(const float* in, int B, int C, int H, int W, int channels_last, int out_hw, float* out,
+                            hipStream_t s) {
+  const int total = B * C * out_hw * out_hw;
+  int grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(transform_kernel, dim3(grid), dim3(256), 0, s, in, B, C, H, W, channels_last, out_hw, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
+                          const float* vec, int B, float* const bufs[4], float* z, float* feat, hipStream_t s) {
+  const size_t ms = plan.blob_floats;
+  for (const Layer& l : plan.layers) {
+    float* dst = bufs[l.dst];
+    if (l.kind == L_STEM) {
+      const int total = B * l.h_out * l.h_out * 8;
+      hipLaunchKernelGGL(stem_kernel, dim3((total + 255) / 256, 1, kc), dim3(256), 0, s, visual, enc_w, ms, k0,
+                         l.w_off, l.b_off, B, l.cin, l.h_in, l.h_out, dst);
+    } else if (l.kind == L_DW) {
+      const long total = (long)B * l.h_out * l.h_out * (l.cout / 4);
+      hipLaunchKernelGGL(dw_kernel, dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), 0, s,
+                         (const float*)bufs[l.src], enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out,
+                         l.stride, dst);
+    } else {
+      const int M = B * l.h_out * l.h_out;
+      const size_t sin = (size_t)M * l.cin, sout = (size_t)M * l.cout;
+      const float* res = l.residual ? bufs[l.res] : nullptr;
+      hipLaunchKernelGGL(pw_kernel, dim3((M + PW_BM - 1) / PW_BM, (l.cout + PW_BN - 1) / PW_BN, kc), dim3(256), 0, s,
+                         (const float*)bufs[l.src], enc_w, ms, k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout,
+                         l.relu6, sin, sout);
+    }
+  }
+  hipLaunchKernelGGL(tail_kernel, dim3(B, kc), dim3(256), 0, s, (const float*)bufs[plan.final_buf], enc_w, ms, k0,
+                     plan.cls_w_off, plan.cls_b_off, plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1],
+                     plan.mrg_b_off[1], plan.mrg_w_off[2], plan.mrg_b_off[2], vec, B,
+                     plan.final_hw * plan.final_hw, z, feat);
+  return hipGetLastError();
+}
+
+}  // namespace rip

@@ -1,0 +1,57 @@
+// Internal C++ interface between the C ABI (rip_abi.hip) and the flow kernels (flow.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rip {
+
+// ---- per-model flow weights, device blob (floats), lane-major for coalesced register loads ----
+// Reference tensors: _decoder._decoder.{weight_ih,weight_hh,bias_ih,bias_hh},
+// _decoder._locscale._model.{0,2}.{weight,bias}  (torch/networks/sequence.py:53-65)
+constexpr int FW_WHH = 0;       // [48 chunks][64 lanes][4]: lane j, chunk c=(g*16+i4) -> W_hh[g*64+j][4*i4..4*i4+3]
+constexpr int FW_WIH = 12288;   // [(g*2+d)][64 lanes]      -> W_ih[g*64+j][d]
+constexpr int FW_BIH = 12672;   // [g][64]
+constexpr int FW_BHH = 12864;   // [g][64]
+constexpr int FW_B1 = 13056;    // [64]: b1[j & 31]
+constexpr int FW_W2 = 13120;    // [q][64]: W2[2*(j>>5)+q][j & 31]
+constexpr int FW_B2 = 13248;    // [4]
+constexpr int FW_W1 = 13252;    // [32][64] row-major (staged to LDS)
+constexpr int FW_SIZE = 15300;
+constexpr int MAX_MODELS = 8;
+enum { ALGO_WCM = 0, ALGO_MA = 1, ALGO_BCM = 2 };
+
+struct SearchArgs {
+  const float* flow_w;   // [K_total][FW_SIZE]
+  int k0;                // first model
+  int K;                 // models in this search
+  const float* z;        // [K][B][64]
+  const float* goal;     // [B][G][2] or nullptr
+  const float* x0;       // [B][N][8]
+  int B, N, G;
+  int algorithm;
+  int num_steps;
+  float lr, epsilon;
+  float grad_scale;      // 1 for RIP; 1/B for ImitativeModel.forward's batch-mean loss
+  float* plans;          // [B][N][8] or nullptr
+  float* loss_best;      // [B][N] or nullptr
+  float* trace_post;     // [steps][K][B][N] or nullptr
+  float* trace_x;        // [steps][B][N][8] or nullptr
+  float* trace_loss;     // [steps][B][N] or nullptr
+};
+
+hipError_t launch_flow_forward(const float* flow_w_k, const float* x, const float* z, int N, int z_rows, float* y,
+                               float* lad, hipStream_t s);
+hipError_t launch_flow_inverse(const float* flow_w_k, const float* y, const float* z, int N, int z_rows, float* x,
+                               float* logp, float* lad, hipStream_t s);
+hipError_t launch_goal_rows(const float* y, const float* goal, int N, int goal_rows, int G, float eps, float* rows,
+                            hipStream_t s);
+hipError_t launch_score(const float* flow_w, int k0, int K, const float* z, const float* y, const float* goal, int B,
+                        int N, int G, float eps, float* S, hipStream_t s);
+hipError_t launch_search(const SearchArgs& a, hipStream_t s);
+hipError_t launch_select_best(const float* plans, const float* loss_best, int B, int N, float* plan, int32_t* best,
+                              hipStream_t s);
+hipError_t launch_dim_select(const float* flow_w_k, const float* z, const float* x0, const float* trace_loss,
+                             const float* trace_x, int B, int num_steps, float* y, float* trace_mean, hipStream_t s);
+size_t search_lds_bytes(int K);
+
+}  // namespace rip

@@ -1,0 +1,802 @@
+// Autoregressive-flow kernels for gfx950 (CDNA4): forward / inverse / scoring and the fused
+// RIP plan search (forward + K inverses + hand-written adjoint + Adam, all steps in one launch).
+//
+// Mapping: ONE 64-lane wavefront per (candidate plan, model) chain; lane j owns hidden unit j.
+//   * GRU W_hh rows (3 x 64 floats per lane) live in registers for the whole launch;
+//     h is broadcast lane->SGPR with v_readlane, so W_hh*h is 192 FMAs + 64 readlanes.
+//   * the transposed products of the adjoint (W_hh^T dgh, W1^T da1) reuse the SAME row-resident
+//     weights: every lane forms its 64 partial products and a 6-stage reduce-scatter
+//     (v_permlane32_swap, v_permlane16_swap, then 8/4/2/1-lane shuffles) leaves sum_i in lane i.
+//   * the per-step "tape" (h, r, z, n, gh_n, a1 per lane + a few uniform scalars) and the head's
+//     W1 rows are staged in LDS; the K waves of a workgroup exchange y / scores / dL/dy through LDS.
+//
+// What it restates (reference file:line):
+//   chain_forward<FWD>  AutoregressiveFlow._forward   torch/networks/sequence.py:95-151
+//   chain_forward<INV>  AutoregressiveFlow._inverse   torch/networks/sequence.py:153-216
+//   goal term           ImitativeModel._goal_likelihood   baselines/torch/dim/model.py:143-171
+//   search_kernel       RIPAgent.__call__ loop        baselines/torch/rip/agent.py:78-137
+//                       ImitativeModel.forward loop   baselines/torch/dim/model.py:98-141
+//   adam                torch.optim.Adam defaults     rip/agent.py:96,131
+#include "flow.h"
+
+namespace rip {
+
+namespace {
+
+constexpr int T = 4;
+constexpr int W1_STRIDE = 68;                 // floats (272 B rows): conflict-free ds_read_b128 across rows
+constexpr int W1_LDS = 32 * W1_STRIDE;        // floats per model
+constexpr int TAPE_Q = 6;                     // hprev, r, zg, n, ghn, a1
+constexpr int TAPE_LANE = T * TAPE_Q * 64;
+constexpr int TAPE_UNI = T * 8;               // x0,x1,s0,s1,sg0,sg1,pad,pad
+constexpr int TAPE = TAPE_LANE + TAPE_UNI;    // floats per slot
+constexpr float LOG_2PI = 1.8378770664093453f;
+
+enum { MODE_FWD = 0, MODE_INV = 1 };
+
+// ------------------------------------------------------------------------------------------
+// cross-lane helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over each row of 16 lanes, result replicated in the row
+__device__ __forceinline__ float row_sum16(float x) {
+  x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp<0x141>(x);  // row_half_mirror
+  x += dpp<0x140>(x);  // row_mirror
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+  x = row_sum16(x);
+  return (rl(x, 0) + rl(x, 16)) + (rl(x, 32) + rl(x, 48));
+}
+// x[lane] + x[lane ^ 32]
+__device__ __forceinline__ float xor32_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// reduce-scatter stages: `lo`/`hi` are this lane's partial sums for two target indices whose lane ids
+// differ in bit D; afterwards the lane holds the pair-sum for the index matching its own bit D.
+__device__ __forceinline__ float rs32(float lo, float hi) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rs16(float lo, float hi) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int D>
+__device__ __forceinline__ float rs_small(float lo, float hi, int lane) {
+  const bool up = (lane & D) != 0;
+  const float send = up ? lo : hi;
+  const float keep = up ? hi : lo;
+  return keep + __shfl_xor(send, D, 64);
+}
+
+// ------------------------------------------------------------------------------------------
+// scalar math (fp32; tolerances of the parity tests are 1e-4 absolute)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly for large |x|
+  return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+}
+// F.softplus(beta=1, threshold=20) (sequence.py:133,193)
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_gradf_(float x) { return x > 20.0f ? 1.0f : sigmoidf_(x); }
+
+// ------------------------------------------------------------------------------------------
+// register-resident weights of one model, as seen by lane j
+// ------------------------------------------------------------------------------------------
+struct FlowRegs {
+  float whh[3][64];  // W_hh[g*64+j][0..63]
+  float wih[3][2];   // W_ih[g*64+j][d]
+  float bih[3], bhh[3];
+  float b1;          // b1[j&31]
+  float w2a, w2b;    // W2[2*half+{0,1}][j&31]
+  float b2[4];
+};
+
+__device__ __forceinline__ void load_flow_regs(FlowRegs& W, const float* __restrict__ blob, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(blob + FW_WHH);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int i4 = 0; i4 < 16; ++i4) {
+      const float4 v = p[(g * 16 + i4) * 64 + lane];
+      W.whh[g][4 * i4 + 0] = v.x;
+      W.whh[g][4 * i4 + 1] = v.y;
+      W.whh[g][4 * i4 + 2] = v.z;
+      W.whh[g][4 * i4 + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    W.wih[g][0] = blob[FW_WIH + (g * 2 + 0) * 64 + lane];
+    W.wih[g][1] = blob[FW_WIH + (g * 2 + 1) * 64 + lane];
+    W.bih[g] = blob[FW_BIH + g * 64 + lane];
+    W.bhh[g] = blob[FW_BHH + g * 64 + lane];
+  }
+  W.b1 = blob[FW_B1 + lane];
+  W.w2a = blob[FW_W2 + lane];
+  W.w2b = blob[FW_W2 + 64 + lane];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) W.b2[c] = blob[FW_B2 + c];
+}
+
+// stage W1 [32][64] of one model into LDS rows of W1_STRIDE floats (all `nthreads` threads cooperate)
+__device__ __forceinline__ void stage_w1(float* lds_w1, const float* __restrict__ blob, int tid, int nthreads) {
+  const float4* src = reinterpret_cast<const float4*>(blob + FW_W1);
+  for (int e = tid; e < 32 * 16; e += nthreads) {
+    const int m = e >> 4, c = e & 15;
+    *reinterpret_cast<float4*>(lds_w1 + m * W1_STRIDE + 4 * c) = src[e];
+  }
+}
+
+// gh[g] = b_hh[g] + W_hh[g] h   and/or   a1 = b1 + W1[m] h    (one broadcast sweep over h)
+template <bool WITH_GH, bool WITH_A1>
+__device__ __forceinline__ void matvec(const FlowRegs& W, const float* w1row, float h, float (&gh)[3], float& a1) {
+  if (WITH_GH) {
+    gh[0] = W.bhh[0];
+    gh[1] = W.bhh[1];
+    gh[2] = W.bhh[2];
+  }
+  if (WITH_A1) a1 = W.b1;
+#pragma unroll
+  for (int i4 = 0; i4 < 16; ++i4) {
+    float4 w1v;
+    if (WITH_A1) w1v = *reinterpret_cast<const float4*>(w1row + 4 * i4);
+    const float w1a[4] = {w1v.x, w1v.y, w1v.z, w1v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * i4 + q;
+      const float hi = rl(h, i);
+      if (WITH_GH) {
+        gh[0] = fmaf(W.whh[0][i], hi, gh[0]);
+        gh[1] = fmaf(W.whh[1][i], hi, gh[1]);
+        gh[2] = fmaf(W.whh[2][i], hi, gh[2]);
+      }
+      if (WITH_A1) a1 = fmaf(w1a[q], hi, a1);
+    }
+  }
+}
+
+// lane i <- sum over lanes j of ( W1[m_j][i]*da1h_j + W_hh[.*64+j][i] . (dpr,dpz,dghn)_j )
+__device__ __forceinline__ float transposed_matvec(const FlowRegs& W, const float* w1row, float da1h, float dpr,
+                                                   float dpz, float dghn, int lane) {
+  float v[32];
+#pragma unroll
+  for (int i4 = 0; i4 < 8; ++i4) {
+    const float4 wa = *reinterpret_cast<const float4*>(w1row + 4 * i4);
+    const float4 wb = *reinterpret_cast<const float4*>(w1row + 32 + 4 * i4);
+    const float a4[4] = {wa.x, wa.y, wa.z, wa.w};
+    const float b4[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * i4 + q;
+      float lo = a4[q] * da1h;
+      lo = fmaf(W.whh[0][i], dpr, lo);
+      lo = fmaf(W.whh[1][i], dpz, lo);
+      lo = fmaf(W.whh[2][i], dghn, lo);
+      float hi = b4[q] * da1h;
+      hi = fmaf(W.whh[0][i + 32], dpr, hi);
+      hi = fmaf(W.whh[1][i + 32], dpz, hi);
+      hi = fmaf(W.whh[2][i + 32], dghn, hi);
+      v[i] = rs32(lo, hi);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = rs16(v[i], v[i + 16]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = rs_small<8>(v[i], v[i + 8], lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = rs_small<4>(v[i], v[i + 4], lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) v[i] = rs_small<2>(v[i], v[i + 2], lane);
+  return rs_small<1>(v[0], v[1], lane);
+}
+
+struct ChainOut {
+  float lad;  // sum_t log(s_t0 * s_t1)
+  float sq;   // sum x^2 (INV)
+};
+
+// One pass over the T steps of a chain.
+//   MODE_FWD: reads x from `xin` (LDS/any float[8]), writes y to `yout`.
+//   MODE_INV: reads y from `yin`, writes x to `xout` (may be null).
+// `tape` (LDS, TAPE floats) receives what the adjoint needs when SAVE.
+template <bool SAVE>
+__device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, const float* w1row, float h0,
+                                                  const float* in8, float* out8, float* tape, int lane) {
+  float h = h0;
+  float gh[3];
+  float a1 = 0.f;
+  matvec<true, false>(W, w1row, h, gh, a1);
+  float yp0 = 0.f, yp1 = 0.f;
+  ChainOut o;
+  o.lad = 0.f;
+  o.sq = 0.f;
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    // ---- GRUCell (sequence.py:128 / :188), gate order r, z, n ----
+    const float gir = fmaf(W.wih[0][1], yp1, fmaf(W.wih[0][0], yp0, W.bih[0]));
+    const float giz = fmaf(W.wih[1][1], yp1, fmaf(W.wih[1][0], yp0, W.bih[1]));
+    const float gin = fmaf(W.wih[2][1], yp1, fmaf(W.wih[2][0], yp0, W.bih[2]));
+    const float r = sigmoidf_(gir + gh[0]);
+    const float zg = sigmoidf_(giz + gh[1]);
+    const float n = tanhf_(fmaf(r, gh[2], gin));
+    const float hn = fmaf(zg, h - n, n);  // (1-z)*n + z*h
+    if (SAVE) {
+      float* tl = tape + t * TAPE_Q * 64 + lane;
+      tl[0 * 64] = h;
+      tl[1 * 64] = r;
+      tl[2 * 64] = zg;
+      tl[3 * 64] = n;
+      tl[4 * 64] = gh[2];
+    }
+    h = hn;
+    // ---- head layer 1 on h_t fused with W_hh h_t for the next step ----
+    if (t < T - 1) {
+      matvec<true, true>(W, w1row, h, gh, a1);
+    } else {
+      matvec<false, true>(W, w1row, h, gh, a1);
+    }
+    if (SAVE) tape[t * TAPE_Q * 64 + 5 * 64 + lane] = a1;
+    // ---- head layer 2: lanes <32 own outputs 0,1 (dloc); lanes >=32 own outputs 2,3 (scale) ----
+    const float a = fmaxf(a1, 0.f);
+    const float p0 = row_sum16(W.w2a * a);
+    const float p1 = row_sum16(W.w2b * a);
+    const float o0 = (rl(p0, 0) + rl(p0, 16)) + W.b2[0];
+    const float o1 = (rl(p1, 0) + rl(p1, 16)) + W.b2[1];
+    const float o2 = (rl(p0, 32) + rl(p0, 48)) + W.b2[2];
+    const float o3 = (rl(p1, 32) + rl(p1, 48)) + W.b2[3];
+    const float s0 = softplusf_(o2) + 1e-3f;  // sequence.py:133
+    const float s1 = softplusf_(o3) + 1e-3f;
+    float x0, x1, y0, y1;
+    if (mode == MODE_FWD) {
+      x0 = in8[2 * t];
+      x1 = in8[2 * t + 1];
+      y0 = (yp0 + o0) + s0 * x0;  // sequence.py:136
+      y1 = (yp1 + o1) + s1 * x1;
+      if (lane == 0) {
+        out8[2 * t] = y0;
+        out8[2 * t + 1] = y1;
+      }
+    } else {
+      y0 = in8[2 * t];
+      y1 = in8[2 * t + 1];
+      x0 = (y0 - (yp0 + o0)) / s0;  // sequence.py:196
+      x1 = (y1 - (yp1 + o1)) / s1;
+      o.sq = fmaf(x0, x0, fmaf(x1, x1, o.sq));
+      if (out8 != nullptr && lane == 0) {
+        out8[2 * t] = x0;
+        out8[2 * t + 1] = x1;
+      }
+    }
+    o.lad += logf(s0 * s1);  // sequence.py:211-214 (the :148-149 variant agrees to rounding)
+    if (SAVE && lane == 0) {
+      float* tu = tape + TAPE_LANE + t * 8;
+      tu[0] = x0;
+      tu[1] = x1;
+      tu[2] = s0;
+      tu[3] = s1;
+      tu[4] = softplus_gradf_(o2);
+      tu[5] = softplus_gradf_(o3);
+    }
+    yp0 = y0;
+    yp1 = y1;
+  }
+  return o;
+}
+
+// Adjoint of one chain pass.
+//   MODE_INV: q = -0.5|x|^2 - logabsdet  ->  writes dq/dy to out8.
+//   MODE_FWD: given dL/dy in in8          ->  writes dL/dx to out8.
+__device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, const float* w1row, const float* tape,
+                                               const float* in8, float* out8, int lane) {
+  const bool upper = lane >= 32;
+  float dhdir = 0.f, dpr = 0.f, dpz = 0.f, dghn = 0.f;
+  float carry0 = 0.f, carry1 = 0.f;
+#pragma unroll 1
+  for (int t = T - 1; t >= 0; --t) {
+    const float* tu = tape + TAPE_LANE + t * 8;
+    const float x0 = tu[0], x1 = tu[1], s0 = tu[2], s1 = tu[3], sg0 = tu[4], sg1 = tu[5];
+    float dd0, dd1, dos0, dos1, c0, c1;
+    if (mode == MODE_INV) {
+      const float i0 = 1.0f / s0, i1 = 1.0f / s1;
+      const float xs0 = x0 * i0, xs1 = x1 * i1;  // x/s
+      if (lane == 0) {
+        out8[2 * t] = carry0 - xs0;  // dq/dy_t: own -x/s plus what step t+1 sent back
+        out8[2 * t + 1] = carry1 - xs1;
+      }
+      c0 = xs0;  // dq/dy_{t-1} from x_t
+      c1 = xs1;
+      dd0 = xs0;  // dq/ddloc
+      dd1 = xs1;
+      dos0 = (x0 * x0 - 1.0f) * i0 * sg0;  // dq/ds = x^2/s - 1/s, through softplus
+      dos1 = (x1 * x1 - 1.0f) * i1 * sg1;
+    } else {
+      const float D0 = in8[2 * t] + carry0;
+      const float D1 = in8[2 * t + 1] + carry1;
+      if (lane == 0) {
+        out8[2 * t] = D0 * s0;
+        out8[2 * t + 1] = D1 * s1;
+      }
+      c0 = D0;
+      c1 = D1;
+      dd0 = D0;
+      dd1 = D1;
+      dos0 = D0 * x0 * sg0;
+      dos1 = D1 * x1 * sg1;
+    }
+    // ---- head adjoint ----
+    const float* tl = tape + t * TAPE_Q * 64 + lane;
+    const float part = W.w2a * (upper ? dos0 : dd0) + W.w2b * (upper ? dos1 : dd1);
+    float da1 = xor32_sum(part);
+    da1 = tl[5 * 64] > 0.f ? da1 : 0.f;
+    const float da1h = upper ? 0.f : da1;  // rows of W1 are duplicated in both halves
+    // ---- dh_t = W1^T da1_t + W_hh^T dgh_{t+1} + dh'_{t+1} * z_{t+1} ----
+    const float dh = transposed_matvec(W, w1row, da1h, dpr, dpz, dghn, lane) + dhdir;
+    // ---- GRUCell adjoint ----
+    const float hprev = tl[0 * 64], r = tl[1 * 64], zg = tl[2 * 64], n = tl[3 * 64], ghn = tl[4 * 64];
+    const float dn = dh * (1.0f - zg);
+    const float dzg = dh * (hprev - n);
+    dhdir = dh * zg;
+    const float dpn = dn * (1.0f - n * n);
+    const float dr = dpn * ghn;
+    dghn = dpn * r;
+    dpr = dr * r * (1.0f - r);
+    dpz = dzg * zg * (1.0f - zg);
+    if (t > 0) {
+      const float du0 = wave_sum(fmaf(W.wih[0][0], dpr, fmaf(W.wih[1][0], dpz, W.wih[2][0] * dpn)));
+      const float du1 = wave_sum(fmaf(W.wih[0][1], dpr, fmaf(W.wih[1][1], dpz, W.wih[2][1] * dpn)));
+      carry0 = c0 + du0;
+      carry1 = c1 + du1;
+    }
+  }
+}
+
+// goal log-likelihood of the last waypoint and (optionally) its gradient  (dim/model.py:163-171)
+__device__ __forceinline__ float goal_ll(const float* __restrict__ goal, int G, float eps, float y0, float y1,
+                                         float* g0, float* g1) {
+  const float inv2 = 1.0f / (2.0f * eps * eps);
+  float m = -INFINITY;
+  for (int j = 0; j < G; ++j) {
+    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
+    m = fmaxf(m, -(d0 * d0 + d1 * d1) * inv2);
+  }
+  float se = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int j = 0; j < G; ++j) {
+    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
+    const float e = expf(-(d0 * d0 + d1 * d1) * inv2 - m);
+    se += e;
+    a0 = fmaf(e, -d0, a0);
+    a1 = fmaf(e, -d1, a1);
+  }
+  if (g0 != nullptr) {
+    const float sc = 2.0f * inv2 / se;  // d/dy logsumexp = sum_j softmax_j * (g_j - y)/eps^2
+    *g0 = a0 * sc;
+    *g1 = a1 * sc;
+  }
+  return m + logf(se) - 2.0f * logf(eps) - LOG_2PI - logf((float)G);
+}
+
+// ------------------------------------------------------------------------------------------
+// plain flow kernels: one wave per row, grid-stride over rows, weights loaded once per wave
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_rows_kernel(int mode, const float* __restrict__ blob,
+                                                         const float* __restrict__ in, const float* __restrict__ z,
+                                                         int N, int z_rows, float* __restrict__ out,
+                                                         float* __restrict__ logp, float* __restrict__ lad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1 = smem;                       // W1_LDS
+  float* io = smem + W1_LDS;              // per wave: 8 in + 8 out
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  stage_w1(w1, blob, tid, blockDim.x);
+  FlowRegs W;
+  load_flow_regs(W, blob, lane);
+  __syncthreads();
+  const float* w1row = w1 + (lane & 31) * W1_STRIDE;
+  float* my_in = io + wave * 16;
+  float* my_out = my_in + 8;
+  for (int row = blockIdx.x * nw + wave; row < N; row += gridDim.x * nw) {
+    if (lane < 8) my_in[lane] = in[(size_t)row * 8 + lane];
+    const float h0 = z[(size_t)(z_rows == 1 ? 0 : row) * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const ChainOut o = chain_forward<false>(mode, W, w1row, h0, my_in, my_out, nullptr, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (out != nullptr && lane < 8) out[(size_t)row * 8 + lane] = my_out[lane];
+    if (lane == 0) {
+      if (lad != nullptr) lad[row] = o.lad;
+      if (logp != nullptr) logp[row] = -0.5f * o.sq - 4.0f * LOG_2PI;  // MVN(0, I_8).log_prob, sequence.py:208
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void goal_rows_kernel(const float* __restrict__ y, const float* __restrict__ goal, int N, int goal_rows,
+                                 int G, float eps, float* __restrict__ rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float* g = goal + (size_t)(goal_rows == 1 ? 0 : i) * G * 2;
+  rows[i] = goal_ll(g, G, eps, y[(size_t)i * 8 + 6], y[(size_t)i * 8 + 7], nullptr, nullptr);
+}
+
+// S[k,b,n]: blockIdx.y = k (weights loaded once per wave), waves stride over the B*N rows
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ flow_w, int k0,
+                                                     const float* __restrict__ z, const float* __restrict__ y,
+                                                     const float* __restrict__ goal, int B, int N, int G, float eps,
+                                                     float* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1 = smem;
+  float* io = smem + W1_LDS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int k = blockIdx.y;
+  const float* blob = flow_w + (size_t)(k0 + k) * FW_SIZE;
+  stage_w1(w1, blob, tid, blockDim.x);
+  FlowRegs W;
+  load_flow_regs(W, blob, lane);
+  __syncthreads();
+  const float* w1row = w1 + (lane & 31) * W1_STRIDE;
+  float* my_in = io + wave * 8;
+  const int rows = B * N;
+  for (int row = blockIdx.x * nw + wave; row < rows; row += gridDim.x * nw) {
+    const int b = row / N;
+    if (lane < 8) my_in[lane] = y[(size_t)row * 8 + lane];
+    const float h0 = z[((size_t)k * B + b) * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const ChainOut o = chain_forward<false>(MODE_INV, W, w1row, h0, my_in, nullptr, nullptr, lane);
+    float s = (-0.5f * o.sq - 4.0f * LOG_2PI) - o.lad;
+    if (goal != nullptr) s += goal_ll(goal + (size_t)b * G * 2, G, eps, my_in[6], my_in[7], nullptr, nullptr);
+    if (lane == 0) S[((size_t)k * B + b) * N + (row - b * N)] = s;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused plan search: one workgroup per (observation b, candidate n); NW waves share the K models
+// ------------------------------------------------------------------------------------------
+struct SearchShared {
+  float xbuf[8];     // latent fed to F_0
+  float ybuf[8];     // y = F_0(x)
+  float gsum[8];     // dLoss/dy handed to the F_0 adjoint
+  float dxbuf[8];    // dLoss/dx
+  float gl[4];       // [0] goal log-likelihood, [1..2] its gradient wrt y_T
+  float q[MAX_MODELS];       // log_prob - logabsdet per model
+  float gk[MAX_MODELS][8];   // dq_k/dy
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = a.K;
+  float* w1_all = smem;                               // K * W1_LDS
+  float* tapes = w1_all + K * W1_LDS;                 // (1 + K) * TAPE
+  SearchShared& sh = *reinterpret_cast<SearchShared*>(tapes + (1 + K) * TAPE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bn = blockIdx.x;
+  const int b = bn / a.N;
+  const int R = (K + NW - 1) / NW;  // inverse rounds per step
+
+  for (int k = 0; k < K; ++k) stage_w1(w1_all + k * W1_LDS, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, tid, NW * 64);
+
+  FlowRegs W;
+  int loaded = wave < K ? wave : 0;
+  load_flow_regs(W, a.flow_w + (size_t)(a.k0 + loaded) * FW_SIZE, lane);
+
+  // Adam state of the 8 latent coordinates lives in lanes 0..7 of wave 0
+  float x = 0.f, am = 0.f, av = 0.f, xbest = 0.f;
+  if (lane < 8) x = a.x0[(size_t)bn * 8 + lane];
+  xbest = x;
+  float loss_best = 1000.0f;  // rip/agent.py:100
+  double b1p = 1.0, b2p = 1.0;
+  const float* goal = a.goal != nullptr ? a.goal + (size_t)b * a.G * 2 : nullptr;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int step = 0; step <= a.num_steps; ++step) {
+    const bool final_pass = step == a.num_steps;
+    if (wave == 0 && lane < 8) sh.xbuf[lane] = final_pass ? xbest : x;
+    __syncthreads();
+    // ---------------- forward phases: ph 0 = F_0 (wave 0), ph 1..R = inverses ----------------
+    const int nph = final_pass ? 0 : R;
+#pragma unroll 1
+    for (int ph = 0; ph <= nph; ++ph) {
+      int k = -1;
+      if (ph == 0) {
+        k = wave == 0 ? 0 : -1;
+      } else {
+        const int kk = wave + (ph - 1) * NW;
+        k = kk < K ? kk : -1;
+      }
+      if (k >= 0) {
+        if (k != loaded) {
+          load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
+          loaded = k;
+        }
+        const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;
+        const float h0 = a.z[((size_t)k * a.B + b) * 64 + lane];
+        const int mode = ph == 0 ? MODE_FWD : MODE_INV;
+        float* tape = tapes + (ph == 0 ? 0 : 1 + k) * TAPE;
+        const ChainOut o = chain_forward<true>(mode, W, w1row, h0, ph == 0 ? sh.xbuf : sh.ybuf,
+                                               ph == 0 ? sh.ybuf : nullptr, tape, lane);
+        if (ph == 0) {
+          if (goal != nullptr && !final_pass) {
+            float g0, g1;
+            __builtin_amdgcn_wave_barrier();
+            const float gl = goal_ll(goal, a.G, a.epsilon, sh.ybuf[6], sh.ybuf[7], &g0, &g1);
+            if (lane == 0) {
+              sh.gl[0] = gl;
+              sh.gl[1] = g0;
+              sh.gl[2] = g1;
+            }
+          } else if (lane == 0) {
+            sh.gl[0] = 0.f;
+            sh.gl[1] = 0.f;
+            sh.gl[2] = 0.f;
+          }
+        } else if (lane == 0) {
+          sh.q[k] = (-0.5f * o.sq - 4.0f * LOG_2PI) - o.lad;  // rip/agent.py:111-112
+        }
+      }
+      __syncthreads();
+    }
+    if (final_pass) break;
+
+    // ---------------- aggregate over the K models (rip/agent.py:121-127, as coded) ----------------
+    const float gl = sh.gl[0];
+    int ksel = 0;
+    float qsel = sh.q[0], qmean = sh.q[0];
+    for (int k = 1; k < K; ++k) {
+      const float qk = sh.q[k];
+      qmean += qk;
+      // WCM: min_k(-posterior) = the largest posterior; BCM: max_k(-posterior) = the smallest
+      const bool take = a.algorithm == ALGO_WCM ? (qk > qsel) : (qk < qsel);
+      if (take) {
+        qsel = qk;
+        ksel = k;
+      }
+    }
+    qmean /= (float)K;
+    const bool mean_mode = a.algorithm == ALGO_MA;
+    const float loss = -((mean_mode ? qmean : qsel) + gl);
+    if (a.trace_post != nullptr && lane == 0) {
+      for (int k = wave; k < K; k += NW)
+        a.trace_post[(((size_t)step * K + k) * a.B + b) * a.N + (bn - b * a.N)] = sh.q[k] + gl;
+    }
+
+    // ---------------- adjoint phases: inverses (reverse order), then F_0 ----------------
+#pragma unroll 1
+    for (int ph = R; ph >= 0; --ph) {
+      int k = -1;
+      if (ph == 0) {
+        k = wave == 0 ? 0 : -1;
+      } else {
+        const int kk = wave + (ph - 1) * NW;
+        k = kk < K ? kk : -1;
+      }
+      const bool needed = ph == 0 || mean_mode || k == ksel;
+      if (k >= 0 && !needed && lane < 8) sh.gk[k][lane] = 0.f;
+      if (k >= 0 && needed) {
+        if (k != loaded) {
+          load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
+          loaded = k;
+        }
+        const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;
+        if (ph == 0) {
+          // dLoss/dy = -sum_k w_k dq_k/dy - d gl/dy_T, scaled (ImitativeModel.forward's batch mean)
+          if (lane < 8) {
+            float g = 0.f;
+            if (mean_mode) {
+              for (int kk = 0; kk < K; ++kk) g += sh.gk[kk][lane];
+              g /= (float)K;
+            } else {
+              g = sh.gk[ksel][lane];
+            }
+            if (lane >= 6) g += sh.gl[lane - 5];
+            sh.gsum[lane] = -g * a.grad_scale;
+          }
+          __builtin_amdgcn_wave_barrier();
+          chain_backward(MODE_FWD, W, w1row, tapes, sh.gsum, sh.dxbuf, lane);
+        } else {
+          chain_backward(MODE_INV, W, w1row, tapes + (1 + k) * TAPE, nullptr, sh.gk[k], lane);
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---------------- Adam (torch.optim.Adam defaults) + bookkeeping, wave 0 ----------------
+    if (wave == 0) {
+      b1p *= 0.9;
+      b2p *= 0.999;
+      if (lane < 8) {
+        const float g = sh.dxbuf[lane];
+        am = am + (g - am) * 0.1f;                       // exp_avg.lerp_(grad, 1-beta1)
+        av = av * 0.999f + 0.001f * g * g;               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        const float step_size = (float)((double)a.lr / (1.0 - b1p));
+        const float bc2s = (float)sqrt(1.0 - b2p);
+        const float denom = sqrtf(av) / bc2s + 1e-8f;
+        x = x - step_size * (am / denom);
+        if (loss < loss_best) xbest = x;                 // post-step x vs pre-step loss (rip/agent.py:131-135)
+        if (a.trace_x != nullptr) a.trace_x[((size_t)step * a.B * a.N + bn) * 8 + lane] = x;
+      }
+      if (loss < loss_best) loss_best = loss;
+      if (a.trace_loss != nullptr && lane == 0) a.trace_loss[(size_t)step * a.B * a.N + bn] = loss;
+    }
+  }
+  // plan = F_0(x_best) is in ybuf (rip/agent.py:137)
+  if (wave == 0) {
+    if (a.plans != nullptr && lane < 8) a.plans[(size_t)bn * 8 + lane] = sh.ybuf[lane];
+    if (a.loss_best != nullptr && lane == 0) a.loss_best[bn] = loss_best;
+  }
+}
+
+// per observation: the candidate with the lowest best-loss wins (first index on ties)
+__global__ void select_best_kernel(const float* __restrict__ plans, const float* __restrict__ loss_best, int N,
+                                   float* __restrict__ plan, int32_t* __restrict__ best) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float v = INFINITY;
+  int idx = 0x7fffffff;
+  for (int n = lane; n < N; n += 64) {
+    const float l = loss_best[(size_t)b * N + n];
+    if (l < v || (l == v && n < idx)) {
+      v = l;
+      idx = n;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float ov = __shfl_xor(v, d, 64);
+    const int oi = __shfl_xor(idx, d, 64);
+    if (ov < v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  if (idx == 0x7fffffff) idx = 0;  // all-NaN guard
+  if (plan != nullptr && lane < 8) plan[(size_t)b * 8 + lane] = plans[((size_t)b * N + idx) * 8 + lane];
+  if (best != nullptr && lane == 0) best[b] = idx;
+}
+
+// ImitativeModel.forward bookkeeping (dim/model.py:124-141): the loss is the batch mean, x_best is the
+// whole post-step x of the first step that reaches the running minimum; then y = F(x_best).
+__global__ __launch_bounds__(64) void dim_select_kernel(const float* __restrict__ blob, const float* __restrict__ z,
+                                                         const float* __restrict__ x0,
+                                                         const float* __restrict__ trace_loss,
+                                                         const float* __restrict__ trace_x, int B, int num_steps,
+                                                         float* __restrict__ y, float* __restrict__ trace_mean) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1 = smem;
+  float* io = smem + W1_LDS;
+  const int lane = threadIdx.x;
+  stage_w1(w1, blob, lane, 64);
+  FlowRegs W;
+  load_flow_regs(W, blob, lane);
+  float best = 1000.0f;
+  int best_step = -1;
+  for (int s = 0; s < num_steps; ++s) {
+    float acc = 0.f;
+    for (int i = lane; i < B; i += 64) acc += trace_loss[(size_t)s * B + i];
+    const float mean = wave_sum(acc) / (float)B;
+    if (trace_mean != nullptr && blockIdx.x == 0 && lane == 0) trace_mean[s] = mean;
+    if (mean < best) {
+      best = mean;
+      best_step = s;
+    }
+  }
+  __syncthreads();
+  const float* w1row = w1 + (lane & 31) * W1_STRIDE;
+  for (int row = blockIdx.x; row < B; row += gridDim.x) {
+    if (lane < 8)
+      io[lane] = best_step < 0 ? x0[(size_t)row * 8 + lane] : trace_x[((size_t)best_step * B + row) * 8 + lane];
+    const float h0 = z[(size_t)row * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    chain_forward<false>(MODE_FWD, W, w1row, h0, io, io + 8, nullptr, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8) y[(size_t)row * 8 + lane] = io[8 + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int rows_grid(int rows) {
+  int g = (rows + 3) / 4;
+  return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+hipError_t launch_flow_forward(const float* blob, const float* x, const float* z, int N, int z_rows, float* y,
+                               float* lad, hipStream_t s) {
+  const size_t lds = (W1_LDS + 4 * 16) * sizeof(float);
+  hipLaunchKernelGGL(flow_rows_kernel, dim3(rows_grid(N)), dim3(256), lds, s, MODE_FWD, blob, x, z, N, z_rows, y,
+                     (float*)nullptr, lad);
+  return hipGetLastError();
+}
+
+hipError_t launch_flow_inverse(const float* blob, const float* y, const float* z, int N, int z_rows, float* x,
+                               float* logp, float* lad, hipStream_t s) {
+  const size_t lds = (W1_LDS + 4 * 16) * sizeof(float);
+  hipLaunchKernelGGL(flow_rows_kernel, dim3(rows_grid(N)), dim3(256), lds, s, MODE_INV, blob, y, z, N, z_rows, x,
+                     logp, lad);
+  return hipGetLastError();
+}
+
+hipError_t launch_goal_rows(const float* y, const float* goal, int N, int goal_rows, int G, float eps, float* rows,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(goal_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, y, goal, N, goal_rows, G, eps, rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_score(const float* flow_w, int k0, int K, const float* z, const float* y, const float* goal, int B,
+                        int N, int G, float eps, float* S, hipStream_t s) {
+  const size_t lds = (W1_LDS + 4 * 8) * sizeof(float);
+  hipLaunchKernelGGL(score_kernel, dim3(rows_grid(B * N), K), dim3(256), lds, s, flow_w, k0, z, y, goal, B, N, G, eps,
+                     S);
+  return hipGetLastError();
+}
+
+size_t search_lds_bytes(int K) {
+  return (size_t)(K * W1_LDS + (1 + K) * TAPE) * sizeof(float) + sizeof(SearchShared);
+}
+
+hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
+  const size_t lds = search_lds_bytes(a.K);
+  const dim3 grid(a.B * a.N);
+  const int nw = a.K >= 4 ? 4 : a.K;
+  hipError_t e = hipSuccess;
+  switch (nw) {
+    case 1:
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(search_kernel<1>, grid, dim3(64), lds, s, a);
+      break;
+    case 2:
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(search_kernel<2>, grid, dim3(128), lds, s, a);
+      break;
+    case 3:
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(search_kernel<3>, grid, dim3(192), lds, s, a);
+      break;
+    default:
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(search_kernel<4>, grid, dim3(256), lds, s, a);
+      break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_select_best(const float* plans, const float* loss_best, int B, int N, float* plan, int32_t* best,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(64), 0, s, plans, loss_best, N, plan, best);
+  return hipGetLastError();
+}
+
+hipError_t launch_dim_select(const float* blob, const float* z, const float* x0, const float* trace_loss,
+                             const float* trace_x, int B, int num_steps, float* y, float* trace_mean, hipStream_t s) {
+  const size_t lds = (W1_LDS + 16) * sizeof(float);
+  int g = B < 256 ? B : 256;
+  hipLaunchKernelGGL(dim_select_kernel, dim3(g), dim3(64), lds, s, blob, z, x0, trace_loss, trace_x, B, num_steps, y,
+                     trace_mean);
+  return hipGetLastError();
+}
+
+}  // namespace rip

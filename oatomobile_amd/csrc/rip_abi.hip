@@ -1,0 +1,328 @@
+// C ABI of librip_hip.so (include/rip_hip.h): handle management, checkpoint folding, argument
+// validation and kernel launch sequencing.  No torch types cross this boundary.
+#include "../../include/rip_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "encoder.h"
+#include "flow.h"
+
+using namespace rip;
+
+static_assert(RIP_MAX_MODELS == rip::MAX_MODELS, "header / kernel constant mismatch");
+static_assert(RIP_ALGO_WCM == rip::ALGO_WCM && RIP_ALGO_MA == rip::ALGO_MA && RIP_ALGO_BCM == rip::ALGO_BCM, "algo ids");
+
+struct rip_handle {
+  int K = 0, C = 0, max_batch = 0, device = 0;
+  EncoderPlan plan;
+  float* enc_w = nullptr;   // [K][plan.blob_floats]
+  float* flow_w = nullptr;  // [K][FW_SIZE]
+  bool loaded[RIP_MAX_MODELS] = {false};
+  float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
+  size_t buf_floats = 0;
+  // scratch for the fused entry points
+  float* visual = nullptr;     // [max_batch][C][100][100]
+  float* z = nullptr;          // [K][max_batch][64]
+  float* plans = nullptr;      // grown on demand: [B][N][8]
+  float* loss_best = nullptr;  // [B][N]
+  float* trace_loss = nullptr; // [steps][B]
+  float* trace_x = nullptr;    // [steps][B][8]
+  size_t plans_cap = 0, trace_cap = 0;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(RIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define REQUIRE(cond, ...) \
+  do {                     \
+    if (!(cond)) return fail(RIP_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+static int check_models(const rip_handle* h, int k0, int kc) {
+  if (h == nullptr) return fail(RIP_EINVAL, "handle is NULL");
+  if (k0 < 0 || kc < 1 || k0 + kc > h->K) return fail(RIP_EINVAL, "model range [%d,%d) outside [0,%d)", k0, k0 + kc, h->K);
+  for (int k = k0; k < k0 + kc; ++k)
+    if (!h->loaded[k]) return fail(RIP_ESTATE, "model %d has no weights (call rip_load_model first)", k);
+  return RIP_OK;
+}
+
+extern "C" {
+
+int rip_abi_version(void) { return 1; }
+const char* rip_last_error(void) { return g_err; }
+
+int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int device) {
+  REQUIRE(out != nullptr, "out is NULL");
+  REQUIRE(K >= 1 && K <= RIP_MAX_MODELS, "K=%d outside [1,%d]", K, RIP_MAX_MODELS);
+  REQUIRE(in_channels >= 1 && in_channels <= 16, "in_channels=%d outside [1,16]", in_channels);
+  REQUIRE(max_batch >= 1, "max_batch=%d must be >= 1", max_batch);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  REQUIRE(device >= 0 && device < ndev, "device %d not in [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  rip_handle* h = new (std::nothrow) rip_handle();
+  if (h == nullptr) return fail(RIP_ESTATE, "out of host memory");
+  h->K = K;
+  h->C = in_channels;
+  h->max_batch = max_batch;
+  h->device = device;
+  h->plan = build_encoder_plan(in_channels);
+  h->buf_floats = (size_t)K * max_batch * h->plan.max_act_floats;
+#define ALLOC(ptr, n)                                                             \
+  do {                                                                            \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (n) * sizeof(float));               \
+    if (e_ != hipSuccess) {                                                       \
+      rip_destroy(h);                                                             \
+      return fail(RIP_EHIP, "hipMalloc(%zu B) failed: %s", (size_t)(n) * 4, hipGetErrorString(e_)); \
+    }                                                                             \
+  } while (0)
+  ALLOC(h->enc_w, (size_t)K * h->plan.blob_floats);
+  ALLOC(h->flow_w, (size_t)K * FW_SIZE);
+  for (int i = 0; i < 4; ++i) ALLOC(h->bufs[i], h->buf_floats);
+  ALLOC(h->visual, (size_t)max_batch * in_channels * 100 * 100);
+  ALLOC(h->z, (size_t)K * max_batch * 64);
+#undef ALLOC
+  *out = h;
+  return RIP_OK;
+}
+
+int rip_destroy(rip_handle* h) {
+  if (h == nullptr) return RIP_OK;
+  (void)hipSetDevice(h->device);
+  float* ptrs[] = {h->enc_w, h->flow_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+                   h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x};
+  for (float* p : ptrs)
+    if (p != nullptr) (void)hipFree(p);
+  delete h;
+  return RIP_OK;
+}
+
+int rip_num_models(const rip_handle* h) { return h ? h->K : RIP_EINVAL; }
+int rip_in_channels(const rip_handle* h) { return h ? h->C : RIP_EINVAL; }
+int rip_max_batch(const rip_handle* h) { return h ? h->max_batch : RIP_EINVAL; }
+
+int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel) {
+  REQUIRE(h != nullptr && packed_host != nullptr, "NULL argument");
+  REQUIRE(k >= 0 && k < h->K, "model index %d outside [0,%d)", k, h->K);
+  std::vector<float> enc, flow;
+  const char* err = "";
+  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(h->enc_w + (size_t)k * h->plan.blob_floats, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
+  h->loaded[k] = true;
+  return RIP_OK;
+}
+
+int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channels_last, int out_hw, float* out_dev,
+                  rip_stream_t stream) {
+  REQUIRE(lidar_dev != nullptr && out_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && out_hw >= 1, "bad shape B=%d C=%d H=%d W=%d out=%d", B, C, H, W, out_hw);
+  HIP_TRY(launch_transform(lidar_dev, B, C, H, W, channels_last, out_hw, out_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
+               int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream) {
+  int rc = check_models(h, k_begin, k_count);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(visual_dev != nullptr && vec_dev != nullptr && z_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
+  REQUIRE(enc_dtype == RIP_ENC_FP32, "encoder dtype %d not supported yet (fp32 only)", enc_dtype);
+  HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
+                         (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, int B, int k_begin,
+                   int k_count, int enc_dtype, float* z_dev, rip_stream_t stream) {
+  int rc = check_models(h, k_begin, k_count);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(lidar_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
+  HIP_TRY(launch_transform(lidar_dev, B, h->C, 200, 200, channels_last, 100, h->visual, (hipStream_t)stream));
+  return rip_encode(h, h->visual, vec_dev, B, k_begin, k_count, enc_dtype, z_dev, nullptr, stream);
+}
+
+int rip_flow_forward(rip_handle* h, int k, const float* x_dev, const float* z_dev, int N, int z_rows, float* y_dev,
+                     float* logabsdet_dev, rip_stream_t stream) {
+  int rc = check_models(h, k, 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(x_dev != nullptr && z_dev != nullptr && y_dev != nullptr, "NULL argument");
+  REQUIRE(N >= 0 && (z_rows == N || z_rows == 1), "z_rows=%d must be N=%d or 1", z_rows, N);
+  if (N == 0) return RIP_OK;
+  HIP_TRY(launch_flow_forward(h->flow_w + (size_t)k * FW_SIZE, x_dev, z_dev, N, z_rows, y_dev, logabsdet_dev,
+                              (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_flow_inverse(rip_handle* h, int k, const float* y_dev, const float* z_dev, int N, int z_rows, float* x_dev,
+                     float* log_prob_dev, float* logabsdet_dev, rip_stream_t stream) {
+  int rc = check_models(h, k, 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(y_dev != nullptr && z_dev != nullptr, "NULL argument");
+  REQUIRE(N >= 0 && (z_rows == N || z_rows == 1), "z_rows=%d must be N=%d or 1", z_rows, N);
+  if (N == 0) return RIP_OK;
+  HIP_TRY(launch_flow_inverse(h->flow_w + (size_t)k * FW_SIZE, y_dev, z_dev, N, z_rows, x_dev, log_prob_dev,
+                              logabsdet_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_goal_likelihood(const float* y_dev, const float* goal_dev, int N, int goal_rows, int G, float epsilon,
+                        float* rows_dev, rip_stream_t stream) {
+  REQUIRE(y_dev != nullptr && goal_dev != nullptr && rows_dev != nullptr, "NULL argument");
+  REQUIRE(N >= 0 && G >= 1 && (goal_rows == N || goal_rows == 1), "bad shape N=%d goal_rows=%d G=%d", N, goal_rows, G);
+  REQUIRE(epsilon > 0.f, "epsilon must be positive");
+  if (N == 0) return RIP_OK;
+  HIP_TRY(launch_goal_rows(y_dev, goal_dev, N, goal_rows, G, epsilon, rows_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_score(rip_handle* h, int k_begin, int k_count, const float* z_dev, const float* y_dev, const float* goal_dev,
+              int B, int N, int G, float epsilon, float* S_dev, rip_stream_t stream) {
+  int rc = check_models(h, k_begin, k_count);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(z_dev != nullptr && y_dev != nullptr && S_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && N >= 1, "bad shape B=%d N=%d", B, N);
+  REQUIRE(goal_dev == nullptr || (G >= 1 && epsilon > 0.f), "bad goal arguments G=%d eps=%g", G, epsilon);
+  HIP_TRY(launch_score(h->flow_w, k_begin, k_count, z_dev, y_dev, goal_dev, B, N, G, epsilon, S_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+static int ensure_plans(rip_handle* h, size_t rows) {
+  if (rows <= h->plans_cap) return RIP_OK;
+  if (h->plans) (void)hipFree(h->plans);
+  if (h->loss_best) (void)hipFree(h->loss_best);
+  h->plans = h->loss_best = nullptr;
+  h->plans_cap = 0;
+  HIP_TRY(hipMalloc((void**)&h->plans, rows * 8 * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&h->loss_best, rows * sizeof(float)));
+  h->plans_cap = rows;
+  return RIP_OK;
+}
+
+int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
+               int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
+               float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
+               rip_stream_t stream) {
+  int rc = check_models(h, 0, h ? h->K : 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(z_dev != nullptr && x0_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && N >= 1, "bad shape B=%d N=%d", B, N);
+  REQUIRE(goal_dev == nullptr || G >= 1, "G=%d must be >= 1 with a goal", G);
+  REQUIRE(algorithm == RIP_ALGO_WCM || algorithm == RIP_ALGO_MA || algorithm == RIP_ALGO_BCM, "unknown algorithm %d", algorithm);
+  REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
+  REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
+  HIP_TRY(hipSetDevice(h->device));
+  const bool need_select = plan_dev != nullptr || best_index_dev != nullptr;
+  float* plans = plans_dev;
+  float* lbest = loss_best_dev;
+  if (need_select && (plans == nullptr || lbest == nullptr)) {
+    rc = ensure_plans(h, (size_t)B * N);
+    if (rc != RIP_OK) return rc;
+    if (plans == nullptr) plans = h->plans;
+    if (lbest == nullptr) lbest = h->loss_best;
+  }
+  SearchArgs a;
+  a.flow_w = h->flow_w;
+  a.k0 = 0;
+  a.K = h->K;
+  a.z = z_dev;
+  a.goal = goal_dev;
+  a.x0 = x0_dev;
+  a.B = B;
+  a.N = N;
+  a.G = G;
+  a.algorithm = algorithm;
+  a.num_steps = num_steps;
+  a.lr = lr;
+  a.epsilon = epsilon;
+  a.grad_scale = 1.0f;
+  a.plans = plans;
+  a.loss_best = lbest;
+  a.trace_post = trace_post_dev;
+  a.trace_x = trace_x_dev;
+  a.trace_loss = nullptr;
+  HIP_TRY(launch_search(a, (hipStream_t)stream));
+  if (need_select) HIP_TRY(launch_select_best(plans, lbest, B, N, plan_dev, best_index_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int G,
+                    int num_steps, float lr, float epsilon, float* y_dev, float* trace_loss_dev, rip_stream_t stream) {
+  int rc = check_models(h, k, 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(z_dev != nullptr && x0_dev != nullptr && y_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1, "B=%d must be >= 1", B);
+  REQUIRE(goal_dev == nullptr || G >= 1, "G=%d must be >= 1 with a goal", G);
+  REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
+  REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t need = (size_t)(num_steps > 0 ? num_steps : 1) * B;
+  if (need > h->trace_cap) {
+    if (h->trace_loss) (void)hipFree(h->trace_loss);
+    if (h->trace_x) (void)hipFree(h->trace_x);
+    h->trace_loss = h->trace_x = nullptr;
+    h->trace_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->trace_loss, need * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&h->trace_x, need * 8 * sizeof(float)));
+    h->trace_cap = need;
+  }
+  SearchArgs a;
+  a.flow_w = h->flow_w;
+  a.k0 = k;
+  a.K = 1;
+  a.z = z_dev;
+  a.goal = goal_dev;
+  a.x0 = x0_dev;
+  a.B = B;
+  a.N = 1;
+  a.G = G;
+  a.algorithm = RIP_ALGO_MA;
+  a.num_steps = num_steps;
+  a.lr = lr;
+  a.epsilon = epsilon;
+  a.grad_scale = 1.0f / (float)B;  // the loss is a mean over the batch (dim/model.py:124,171)
+  a.plans = nullptr;
+  a.loss_best = nullptr;
+  a.trace_post = nullptr;
+  a.trace_x = h->trace_x;
+  a.trace_loss = h->trace_loss;
+  HIP_TRY(launch_search(a, (hipStream_t)stream));
+  HIP_TRY(launch_dim_select(h->flow_w + (size_t)k * FW_SIZE, z_dev, x0_dev, h->trace_loss, h->trace_x, B, num_steps,
+                            y_dev, trace_loss_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, const float* goal_dev,
+            const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr, float epsilon,
+            int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream) {
+  REQUIRE(h != nullptr, "handle is NULL");
+  REQUIRE(plan_dev != nullptr, "plan_dev is NULL");
+  int rc = rip_encode_raw(h, lidar_dev, channels_last, vec_dev, B, 0, h->K, enc_dtype, h->z, stream);
+  if (rc != RIP_OK) return rc;
+  // h->z is [K][B][64] because rip_encode packs by the B it was given
+  return rip_search(h, h->z, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, nullptr,
+                    loss_best_dev, nullptr, nullptr, nullptr, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""CPU tests of the host logic: state_dict compatibility, packing, C-ABI symbol table, interpolation,
+frame transforms, loud failure without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oatomobile_amd import arch
+from oatomobile_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_keys_match_oracle_tree():
+  """The product's parameter container and the oracle's torchvision-shaped tree expose identical keys/shapes
+  (328 tensors, 2 419 716 parameters — SURVEY.md §8b)."""
+  from oatomobile_amd import ImitativeModel
+  from oracle import reference_cpu as O
+  a = ImitativeModel().state_dict()
+  b = O.OracleImitativeModel().state_dict()
+  assert list(a.keys()) == list(b.keys()) and len(a) == 328
+  for k in a:
+    assert tuple(a[k].shape) == tuple(b[k].shape), k
+  assert sum(p.numel() for p in ImitativeModel().parameters()) == 2419716
+
+
+def test_checkpoint_roundtrip_through_product_container(tmp_path):
+  """A reference-style checkpoint (bare state_dict, torch/savers.py:45) loads strict and re-packs identically."""
+  from oatomobile_amd import ImitativeModel
+  from oracle import reference_cpu as O
+  sd = W.synthetic_state_dict(9)
+  ref = O.OracleImitativeModel.from_numpy_state_dict(sd)
+  path = os.path.join(tmp_path, "model-1.pt")
+  torch.save(ref.state_dict(), path)
+  m = ImitativeModel()
+  m.load_state_dict(torch.load(path), strict=True)
+  np.testing.assert_array_equal(m.packed_weights(), W.pack_state_dict(sd))
+  assert m.packed_weights().size == arch.packed_numel(2)
+  with pytest.raises(RuntimeError):
+    bad = dict(ref.state_dict())
+    bad.pop("_merger._model.0.weight")
+    ImitativeModel().load_state_dict(bad, strict=True)
+
+
+def test_pack_rejects_bad_shapes():
+  sd = W.synthetic_state_dict(1)
+  sd["_decoder._decoder.weight_hh"] = np.zeros((192, 63), np.float32)
+  with pytest.raises(ValueError, match="size mismatch"):
+    W.pack_state_dict(sd)
+
+
+def test_synthetic_weights_are_deterministic():
+  a, b = W.synthetic_state_dict(5), W.synthetic_state_dict(5)
+  for k in a:
+    np.testing.assert_array_equal(a[k], b[k])
+  assert float(np.abs(W.pack_state_dict(a)).sum()) > 0
+
+
+def test_library_exports_every_declared_symbol():
+  """include/rip_hip.h <-> librip_hip.so <-> _lib.SIGNATURES agree (no compute calls: no GPU here)."""
+  from oatomobile_amd import _lib
+  header = open(os.path.join(ROOT, "include", "rip_hip.h")).read()
+  declared = set(re.findall(r"\b(rip_[a-z_]+)\s*\(", header))
+  lib = _lib.load()
+  bound = {name for name, _, _ in _lib.SIGNATURES}
+  assert declared == bound, declared ^ bound
+  for name in declared:
+    assert hasattr(lib, name)
+  assert lib.rip_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+  from oatomobile_amd import ImitativeModel
+  m = ImitativeModel()
+  with pytest.raises(RuntimeError, match="no CPU path"):
+    m._forward(torch.zeros(1, 4, 2), torch.zeros(1, 64))
+  with pytest.raises(RuntimeError, match="no CPU path"):
+    m.transform({"lidar": torch.zeros(1, 2, 200, 200)})
+
+
+def test_product_does_not_import_oracle():
+  for dirpath, _, files in os.walk(os.path.join(ROOT, "oatomobile_amd")):
+    for f in files:
+      if f.endswith((".py", ".hip", ".h", ".cpp")):
+        src = open(os.path.join(dirpath, f)).read()
+        assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_interpolate_plan_matches_scipy():
+  import scipy.interpolate
+  from oatomobile_amd.agents import interpolate_plan
+  plan = np.random.default_rng(3).normal(size=(4, 2)).astype(np.float32)
+  t = list(range(0, 40, 10))
+  ref = scipy.interpolate.interp1d(x=t, y=plan, axis=0)(np.arange(0, t[-1]))
+  out = interpolate_plan(plan)
+  assert out.shape == (30, 3) and out.dtype == np.float64
+  np.testing.assert_allclose(out[:, :2], ref, atol=1e-12)
+
+
+def test_frame_transforms_roundtrip():
+  from oatomobile_amd.agents import local2world, rot2mat, world2local
+  rng = np.random.default_rng(0)
+  loc, rot = rng.normal(size=3) * 50, np.array([3.0, 47.0, -2.0])
+  pts = rng.normal(size=(30, 3)) * 10
+  back = world2local(current_location=loc, current_rotation=rot,
+                     world_locations=local2world(current_location=loc, current_rotation=rot, local_locations=pts))
+  np.testing.assert_allclose(back, pts, atol=1e-9)
+  R = rot2mat(np.array([0.0, 90.0, 0.0]))  # yaw 90deg: world x-axis maps to local -y
+  np.testing.assert_allclose(R @ np.array([1.0, 0, 0]), [0, -1, 0], atol=1e-12)
+  np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+
+
+def test_setpoint_agent_replan_logic():
+  from oatomobile_amd.agents import SetPointAgent
+
+  class Fixed(SetPointAgent):
+    calls = 0
+
+    def __call__(self, observation):
+      Fixed.calls += 1
+      return np.c_[np.arange(30.0), np.zeros(30), np.zeros(30)]
+
+  a = Fixed(None, replan_every_steps=3)
+  ob = dict(location=np.zeros(3), rotation=np.zeros(3))
+  outs = [a.act(ob) for _ in range(4)]
+  assert Fixed.calls == 2  # steps 0 and 3
+  assert outs[0]["target_speed"] == pytest.approx(20 / 3.6)  # forced for the first 100 steps (base.py:166-167)
+  np.testing.assert_allclose(outs[0]["setpoint"], [5, 0, 0])
+  np.testing.assert_allclose(outs[1]["setpoint"], [6, 0, 0])  # buffer popped
+  a._steps_counter = 200
+  assert a.act(ob)["target_speed"] == pytest.approx(1.0 / 0.05)
+
+
+def test_encoder_plan_matches_arch_tables():
+  blocks = arch.blocks()
+  assert len(blocks) == 17 and blocks[-1].h_out == 4 and blocks[-1].oup == 320
+  assert [b.index for b in blocks if b.residual] == [3, 5, 6, 8, 9, 10, 12, 13, 15, 16]
+  assert arch.packed_numel(2) + 52 == sum(int(np.prod(s)) if s else 1 for _, s in arch.state_dict_spec(2))
