@@ -1,0 +1,248 @@
+"""bench.py — RIPAgent.act() throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): K=4 ensemble, algorithm "WCM" (as coded), N=128 candidate plans,
+10 Adam steps, 200x200xC BEV, synthetic observations (SURVEY.md §8d distribution), random-init weights
+(`oatomobile_amd.weights.synthetic_state_dict`), fp32 everywhere.
+
+A *step* = one pass of the whole hot path (R1..R11: transform, K encoders + merger, plan search,
+candidate selection, plan copy-back) over one batch of `--obs-batch` observations already resident in HBM;
+every observation is one `RIPAgent.act()` call, so value = obs_batch * steps * n_gpus / time.  Ranks are
+independent replicas over different observations (no data-path collective): scaling = "weak".
+
+The JSON line also carries
+  roofline     — the dominant kernel (plan search) against the fp32 peak, from HIP events on the launch stream
+  cpu_baseline — the CPU oracle (oracle/reference_cpu.py, "port") timed on this box's host cores on a
+                 bounded sample of the same workload
+  online       — B=1 sequential calls with a host sync + copy-back per call (the reference's usage pattern)
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+# SURVEY.md §8(d) / BASELINE.md §5 work-per-unit figures
+FLOW_MAC_PER_STEP = 14848  # GRU + head, one time step
+ENC_MAC_C2 = 73448704  # + 720000 * C
+ENC_ACT_ELEMS = 1466229 + 1465488  # layer-wise activation elements read + written per image (C = 2)
+ENC_WEIGHT_ELEMS = 2370336 + 17056
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(rng, B, C, G=10):
+  lidar = (rng.integers(0, 6, size=(B, 200, 200, C)) / 5.0) * (rng.random((B, 200, 200, C)) < 0.12)
+  vec = np.c_[rng.normal(0, 3.0, size=(B, 3)), (rng.random((B, 1)) < 0.2), rng.integers(0, 4, size=(B, 1))]
+  goal = np.cumsum(np.abs(rng.normal(size=(B, G, 2))) * 2.0, axis=1)
+  return lidar.astype(np.float32), vec.astype(np.float32), goal.astype(np.float32)
+
+
+def cpu_baseline(args, seeds, x0_rows):
+  """The oracle's whole act() on the host cores, bounded sample."""
+  from oatomobile_amd import weights
+  from oracle import reference_cpu as O
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  models = [O.OracleImitativeModel.from_numpy_state_dict(weights.synthetic_state_dict(s, args.channels), args.channels)
+            for s in seeds]
+  rng = np.random.default_rng(2)
+  lidar, vec, goal = synth_batch(rng, 1, args.channels)
+  goal3 = np.c_[goal[0], np.zeros((goal.shape[1], 1), np.float32)]
+
+  def one():
+    O.rip_call(models, lidar[0], vec[0, :3], vec[0, 3], vec[0, 4], goal3, x0=x0_rows, algorithm=args.algorithm,
+               num_steps=args.search_steps)
+
+  one()
+  t0 = time.perf_counter()
+  n = 0
+  while True:
+    one()
+    n += 1
+    dt = time.perf_counter() - t0
+    if dt > args.cpu_seconds or n >= 200:
+      break
+  return {
+      "value": n / dt,
+      "unit": "calls/s",
+      "cores": cores,
+      "kind": "port",
+      "sample": "%d sequential act() calls (K=%d, N=%d, %d Adam steps, encoders under no_grad = the 'fair' variant), "
+                "PyTorch-CPU oracle, %d threads, %.1f s" % (n, len(seeds), x0_rows.shape[0], args.search_steps, cores, dt),
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--obs-batch", type=int, default=64, help="observations (= act() calls) per step per GPU")
+  ap.add_argument("--models", type=int, default=4)
+  ap.add_argument("--candidates", type=int, default=128)
+  ap.add_argument("--channels", type=int, default=2, help="BEV channels (reference sensor: 2; BASELINE.json text: 4)")
+  ap.add_argument("--algorithm", default="WCM")
+  ap.add_argument("--search-steps", type=int, default=10)
+  ap.add_argument("--cpu-seconds", type=float, default=12.0)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--online-calls", type=int, default=200)
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus and world > 1:
+    raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+  assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the product has no CPU path)"
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+  import __graft_entry__ as entry
+  if rank == 0:
+    entry.build()
+  if dist is not None:
+    dist.barrier()
+  from oatomobile_amd import ImitativeModel, RIPAgent, _lib
+
+  K, N, B, C = args.models, args.candidates, args.obs_batch, args.channels
+  seeds = [100 + k for k in range(K)]
+  models = [ImitativeModel.synthetic(s, in_channels=C, max_batch=1) for s in seeds]
+  agent = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, num_steps=args.search_steps,
+                   max_batch=B, seed=0, device=dev)
+  lib = _lib.load()
+  h = agent._handle.raw
+
+  # distinct observation batches per rank and per step parity (resident in HBM before timing)
+  rng = np.random.default_rng(1000 + rank)
+  batches = []
+  for _ in range(2):
+    lidar, vec, goal = synth_batch(rng, B, C)
+    batches.append(tuple(torch.from_numpy(a).to(dev) for a in (lidar, vec, goal)))
+  x0 = agent._x0(B)
+  z = torch.empty(K, B, 64, device=dev)
+  plan = torch.empty(B, 4, 2, device=dev)
+  loss = torch.empty(B, N, device=dev)
+  plan_host = torch.empty(B, 4, 2).pin_memory()
+  G = batches[0][2].shape[1]
+  algo = _lib.ALGORITHMS[args.algorithm]
+  stream = torch.cuda.current_stream()
+
+  def step(i, ev=None):
+    lidar, vec, goal = batches[i & 1]
+    s = _lib.current_stream()
+    if ev is not None:
+      ev[0].record(stream)
+    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, _lib.ptr(vec), B, 0, K, 0, _lib.ptr(z), s))
+    if ev is not None:
+      ev[1].record(stream)
+    _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x0), B, N, G, algo, args.search_steps, 0.1, 1.0,
+                              _lib.ptr(plan), None, _lib.ptr(loss), None, None, None, s))
+    if ev is not None:
+      ev[2].record(stream)
+    plan_host.copy_(plan, non_blocking=True)  # the reference's D2H (rip/agent.py:139)
+
+  def sync_all():
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for i in range(args.warmup):
+    step(i)
+  events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+  sync_all()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(i, events[i])
+  sync_all()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  assert torch.isfinite(plan).all()
+
+  enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+  search_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+
+  # ---- online pattern: B = 1, host sync and copy-back every call (rank 0 only) ----
+  online = None
+  if rank == 0 and args.online_calls > 0:
+    a1 = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, num_steps=args.search_steps,
+                  max_batch=1, seed=0, device=dev)
+    l1, v1, g1 = (t[:1].contiguous() for t in batches[0])
+    for _ in range(10):
+      a1.plan_batch(l1, v1, g1).cpu()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.online_calls):
+      a1.plan_batch(l1, v1, g1).cpu()
+    dt1 = time.perf_counter() - t1
+    online = {"calls_per_s": args.online_calls / dt1, "latency_us": 1e6 * dt1 / args.online_calls,
+              "pattern": "B=1 sequential, device-resident observation, plan copied back and host-synced per call"}
+
+  if rank == 0:
+    calls = B * args.steps * world
+    flow_flops = 2.0 * 3.0 * (1 + K) * 4 * FLOW_MAC_PER_STEP * N * args.search_steps * B  # SURVEY §8(d) flops_flow(grad)
+    enc_bytes = B * (200 * 200 * C * 4 + 100 * 100 * C * 4) + K * (B * (ENC_ACT_ELEMS + 10000 * (C - 2)) * 4 + ENC_WEIGHT_ELEMS * 4)
+    roof = {
+        "kernel": "search_kernel<%d> (fused forward + K inverses + adjoint + Adam, %d steps)" % (min(K, 4), args.search_steps),
+        "bound": "mfma",
+        "achieved": flow_flops / (search_ms * 1e-3) / 1e12,
+        "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+        "traffic": None,
+        "ms_per_launch": search_ms,
+        "note": "fp32 VALU-bound kernel: the fp32 vector peak equals the fp32-input MFMA peak (157.3 TFLOP/s); "
+                "flops = SURVEY.md §8(d) flops_flow(grad) x obs_batch",
+        "encoder": {"ms_per_step": enc_ms, "algorithmic_GBps": enc_bytes / (enc_ms * 1e-3) / 1e9,
+                    "frac_hbm": enc_bytes / (enc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "note": "transform + %d conv launches + tail, layer-wise compulsory bytes (SURVEY §8d bytes_pre+bytes_enc)" % 52},
+    }
+    out = {
+        "metric": "RIPAgent.act() calls/sec (K=%d, %d plans, 200x200 BEV)" % (K, N),
+        "value": calls / elapsed,
+        "unit": "calls/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV, "
+                               "fp32 encoder + fp32 flow" % (K, args.algorithm, N, args.search_steps, C),
+                   "obs_per_step_per_gpu": B, "models": K, "candidates": N, "bev_channels": C,
+                   "parallelism": "observation-parallel replicas x%d (no data-path collective)" % world},
+        "roofline": roof,
+        "online": online,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(args, seeds, agent._x0_rows.cpu())
+    print(json.dumps(out))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()
