@@ -226,56 +226,70 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5+K6: global average pool -> classifier Linear(1280,128) -> cat(vec5) -> merger 3x(Linear+ReLU).
-// One block per (model, observation).
+// K5: global average pool -> classifier Linear(1280,128).  One block per (observation, model, group of
+// 16 outputs): the pooled vector is rebuilt per block (the 16x1280 activation tile is L2-resident),
+// each wave owns 4 outputs and strides the 1280 inputs with coalesced row reads.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act, const float* __restrict__ wbase,
-                                                    size_t model_stride, int k0, size_t cls_w, size_t cls_b,
-                                                    size_t m0w, size_t m0b, size_t m1w, size_t m1b, size_t m2w,
-                                                    size_t m2b, const float* __restrict__ vec, int B, int HW,
-                                                    float* __restrict__ z, float* __restrict__ feat_out) {
+constexpr int CLS_GROUP = 16;
+
+__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ act, const float* __restrict__ wbase,
+                                                   size_t model_stride, int k0, size_t cls_w, size_t cls_b, int B,
+                                                   int HW, float* __restrict__ feat) {
   __shared__ float pooled[LAST_C];
-  __shared__ float v133[FEAT + VEC + 3];
-  __shared__ float hbuf[2][HID];
-  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, k = blockIdx.y, og = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* W = wbase + (size_t)(k0 + k) * model_stride;
   const float* a = act + ((size_t)k * B + b) * HW * LAST_C;
+  const float inv = 1.0f / (float)HW;
   for (int c = tid; c < LAST_C; c += 256) {
     float s = 0.f;
     for (int p = 0; p < HW; ++p) s += a[(size_t)p * LAST_C + c];
-    pooled[c] = s / (float)HW;
+    pooled[c] = s * inv;
   }
   __syncthreads();
-  // classifier: 128 outputs, each wave takes 32 of them; lanes stride the 1280 inputs (coalesced rows)
-  for (int o = wave; o < FEAT; o += 4) {
+#pragma unroll
+  for (int q = 0; q < CLS_GROUP / 4; ++q) {
+    const int o = og * CLS_GROUP + wave * (CLS_GROUP / 4) + q;
     const float* wr = W + cls_w + (size_t)o * LAST_C;
     float s = 0.f;
-    for (int i = lane; i < LAST_C; i += 64) s = fmaf(wr[i], pooled[i], s);
+#pragma unroll
+    for (int i = 0; i < LAST_C / 64; ++i) s = fmaf(wr[i * 64 + lane], pooled[i * 64 + lane], s);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane == 0) {
-      const float f = s + W[cls_b + o];
-      v133[o] = f;
-      if (feat_out != nullptr) feat_out[((size_t)k * B + b) * FEAT + o] = f;
-    }
+    if (lane == 0) feat[((size_t)k * B + b) * FEAT + o] = s + W[cls_b + o];
   }
-  if (tid < VEC) v133[FEAT + tid] = vec[(size_t)b * VEC + tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: cat(feat128, vec5) -> merger 3x(Linear+ReLU) (dim/model.py:206-217).  One wave per (obs, model):
+// lane j owns output unit j, inputs broadcast from LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merger_kernel(const float* __restrict__ feat, const float* __restrict__ wbase,
+                                                     size_t model_stride, int k0, size_t m0w, size_t m0b, size_t m1w,
+                                                     size_t m1b, size_t m2w, size_t m2b,
+                                                     const float* __restrict__ vec, int B, float* __restrict__ z) {
+  __shared__ float v[FEAT + VEC + 3];
+  __shared__ float hbuf[2][HID];
+  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+  const float* W = wbase + (size_t)(k0 + k) * model_stride;
+  for (int i = tid; i < FEAT; i += 64) v[i] = feat[((size_t)k * B + b) * FEAT + i];
+  if (tid < VEC) v[FEAT + tid] = vec[(size_t)b * VEC + tid];
   __syncthreads();
-  if (tid < HID) {
+  {
     const float* wr = W + m0w + (size_t)tid * (FEAT + VEC);
     float s = W[m0b + tid];
-    for (int i = 0; i < FEAT + VEC; ++i) s = fmaf(wr[i], v133[i], s);
+    for (int i = 0; i < FEAT + VEC; ++i) s = fmaf(wr[i], v[i], s);
     hbuf[0][tid] = fmaxf(s, 0.f);
   }
   __syncthreads();
-  if (tid < HID) {
+  {
     const float* wr = W + m1w + (size_t)tid * HID;
     float s = W[m1b + tid];
     for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[0][i], s);
     hbuf[1][tid] = fmaxf(s, 0.f);
   }
   __syncthreads();
-  if (tid < HID) {
+  {
     const float* wr = W + m2w + (size_t)tid * HID;
     float s = W[m2b + tid];
     for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[1][i], s);
@@ -477,10 +491,13 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
                          l.relu6, sin, sout);
     }
   }
-  hipLaunchKernelGGL(tail_kernel, dim3(B, kc), dim3(256), 0, s, (const float*)bufs[plan.final_buf], enc_w, ms, k0,
-                     plan.cls_w_off, plan.cls_b_off, plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1],
-                     plan.mrg_b_off[1], plan.mrg_w_off[2], plan.mrg_b_off[2], vec, B,
-                     plan.final_hw * plan.final_hw, z, feat);
+  // classifier logits go to `feat` if the caller wants them, else to scratch at the end of a free buffer
+  float* feat_buf = feat != nullptr ? feat : bufs[(plan.final_buf + 1) & 3];
+  hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, (const float*)bufs[plan.final_buf],
+                     enc_w, ms, k0, plan.cls_w_off, plan.cls_b_off, B, plan.final_hw * plan.final_hw, feat_buf);
+  hipLaunchKernelGGL(merger_kernel, dim3(B, kc), dim3(64), 0, s, (const float*)feat_buf, enc_w, ms, k0,
+                     plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1], plan.mrg_b_off[1], plan.mrg_w_off[2],
+                     plan.mrg_b_off[2], vec, B, z);
   return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ constexpr int FW_B2 = 13248;    // [4]
 constexpr int FW_W1 = 13252;    // [32][64] row-major (staged to LDS)
 constexpr int FW_SIZE = 15300;
 constexpr int MAX_MODELS = 8;
+constexpr int MAX_GOALS = 64;
 enum { ALGO_WCM = 0, ALGO_MA = 1, ALGO_BCM = 2 };
 
 struct SearchArgs {

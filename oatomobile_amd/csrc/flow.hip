@@ -72,23 +72,36 @@ __device__ __forceinline__ float rs16(float lo, float hi) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 template <int D>
+__device__ __forceinline__ float xor_lane(float v) {  // v[lane ^ D] for D in {1,2,4,8}, all DPP (no LDS)
+  if (D == 1) return dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  if (D == 2) return dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  if (D == 8) return dpp<0x128>(v);  // row_ror:8
+  // D == 4: lanes with bit2 clear read lane+4 (row_shl:4, banks 0/2), the others lane-4 (row_shr:4, banks 1/3)
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);
+  r = __builtin_amdgcn_update_dpp(r, __float_as_int(v), 0x114, 0xf, 0xA, false);
+  return __int_as_float(r);
+}
+template <int D>
 __device__ __forceinline__ float rs_small(float lo, float hi, int lane) {
   const bool up = (lane & D) != 0;
   const float send = up ? lo : hi;
   const float keep = up ? hi : lo;
-  return keep + __shfl_xor(send, D, 64);
+  return keep + xor_lane<D>(send);
 }
 
 // ------------------------------------------------------------------------------------------
 // scalar math (fp32; tolerances of the parity tests are 1e-4 absolute)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 / v_exp_f32 / v_log_f32 are ~1 ulp; the parity budget is 1e-4 absolute.
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly for large |x|
-  return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+  return 1.0f - 2.0f * rcpf_(__expf(2.0f * x) + 1.0f);
 }
-// F.softplus(beta=1, threshold=20) (sequence.py:133,193)
-__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// F.softplus(beta=1, threshold=20) (sequence.py:133,193); the caller adds the 1e-3 floor, so the
+// absolute error of log(1+e^x) for very negative x (<= 6e-8) is invisible
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
 __device__ __forceinline__ float softplus_gradf_(float x) { return x > 20.0f ? 1.0f : sigmoidf_(x); }
 
 // ------------------------------------------------------------------------------------------
@@ -271,15 +284,15 @@ __device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, c
     } else {
       y0 = in8[2 * t];
       y1 = in8[2 * t + 1];
-      x0 = (y0 - (yp0 + o0)) / s0;  // sequence.py:196
-      x1 = (y1 - (yp1 + o1)) / s1;
+      x0 = (y0 - (yp0 + o0)) * rcpf_(s0);  // sequence.py:196
+      x1 = (y1 - (yp1 + o1)) * rcpf_(s1);
       o.sq = fmaf(x0, x0, fmaf(x1, x1, o.sq));
       if (out8 != nullptr && lane == 0) {
         out8[2 * t] = x0;
         out8[2 * t + 1] = x1;
       }
     }
-    o.lad += logf(s0 * s1);  // sequence.py:211-214 (the :148-149 variant agrees to rounding)
+    o.lad += __logf(s0 * s1);  // sequence.py:211-214 (the :148-149 variant agrees to rounding)
     if (SAVE && lane == 0) {
       float* tu = tape + TAPE_LANE + t * 8;
       tu[0] = x0;
@@ -309,7 +322,7 @@ __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, cons
     const float x0 = tu[0], x1 = tu[1], s0 = tu[2], s1 = tu[3], sg0 = tu[4], sg1 = tu[5];
     float dd0, dd1, dos0, dos1, c0, c1;
     if (mode == MODE_INV) {
-      const float i0 = 1.0f / s0, i1 = 1.0f / s1;
+      const float i0 = rcpf_(s0), i1 = rcpf_(s1);
       const float xs0 = x0 * i0, xs1 = x1 * i1;  // x/s
       if (lane == 0) {
         out8[2 * t] = carry0 - xs0;  // dq/dy_t: own -x/s plus what step t+1 sent back
@@ -468,6 +481,7 @@ struct SearchShared {
   float gsum[8];     // dLoss/dy handed to the F_0 adjoint
   float dxbuf[8];    // dLoss/dx
   float gl[4];       // [0] goal log-likelihood, [1..2] its gradient wrt y_T
+  float goal[2 * MAX_GOALS];
   float q[MAX_MODELS];       // log_prob - logabsdet per model
   float gk[MAX_MODELS][8];   // dq_k/dy
 };
@@ -491,6 +505,9 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
   FlowRegs W;
   int loaded = wave < K ? wave : 0;
   load_flow_regs(W, a.flow_w + (size_t)(a.k0 + loaded) * FW_SIZE, lane);
+  float h0 = a.z[((size_t)loaded * a.B + b) * 64 + lane];  // context of the resident model
+  if (a.goal != nullptr)
+    for (int i = tid; i < 2 * a.G; i += NW * 64) sh.goal[i] = a.goal[(size_t)b * a.G * 2 + i];
 
   // Adam state of the 8 latent coordinates lives in lanes 0..7 of wave 0
   float x = 0.f, am = 0.f, av = 0.f, xbest = 0.f;
@@ -498,7 +515,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
   xbest = x;
   float loss_best = 1000.0f;  // rip/agent.py:100
   double b1p = 1.0, b2p = 1.0;
-  const float* goal = a.goal != nullptr ? a.goal + (size_t)b * a.G * 2 : nullptr;
+  const float* goal = a.goal != nullptr ? sh.goal : nullptr;
   __syncthreads();
 
 #pragma unroll 1
@@ -520,10 +537,10 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
       if (k >= 0) {
         if (k != loaded) {
           load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
+          h0 = a.z[((size_t)k * a.B + b) * 64 + lane];
           loaded = k;
         }
         const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;
-        const float h0 = a.z[((size_t)k * a.B + b) * 64 + lane];
         const int mode = ph == 0 ? MODE_FWD : MODE_INV;
         float* tape = tapes + (ph == 0 ? 0 : 1 + k) * TAPE;
         const ChainOut o = chain_forward<true>(mode, W, w1row, h0, ph == 0 ? sh.xbuf : sh.ybuf,
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
       if (k >= 0 && needed) {
         if (k != loaded) {
           load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
+          h0 = a.z[((size_t)k * a.B + b) * 64 + lane];
           loaded = k;
         }
         const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;

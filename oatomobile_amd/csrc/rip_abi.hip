@@ -228,7 +228,7 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   if (rc != RIP_OK) return rc;
   REQUIRE(z_dev != nullptr && x0_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1 && N >= 1, "bad shape B=%d N=%d", B, N);
-  REQUIRE(goal_dev == nullptr || G >= 1, "G=%d must be >= 1 with a goal", G);
+  REQUIRE(goal_dev == nullptr || (G >= 1 && G <= rip::MAX_GOALS), "G=%d must be in [1,%d] with a goal", G, rip::MAX_GOALS);
   REQUIRE(algorithm == RIP_ALGO_WCM || algorithm == RIP_ALGO_MA || algorithm == RIP_ALGO_BCM, "unknown algorithm %d", algorithm);
   REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
   REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
@@ -273,7 +273,7 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
   if (rc != RIP_OK) return rc;
   REQUIRE(z_dev != nullptr && x0_dev != nullptr && y_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1, "B=%d must be >= 1", B);
-  REQUIRE(goal_dev == nullptr || G >= 1, "G=%d must be >= 1 with a goal", G);
+  REQUIRE(goal_dev == nullptr || (G >= 1 && G <= rip::MAX_GOALS), "G=%d must be in [1,%d] with a goal", G, rip::MAX_GOALS);
   REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
   REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
   HIP_TRY(hipSetDevice(h->device));
