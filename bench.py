@@ -49,21 +49,22 @@ def synth_batch(rng, B, C, G=10):
   return lidar.astype(np.float32), vec.astype(np.float32), goal.astype(np.float32)
 
 
-def cpu_baseline(args, seeds, x0_rows):
-  """The oracle's whole act() on the host cores, bounded sample."""
+def _cpu_baseline_worker(argv):
+  """Runs in a fresh process (no GPU context): the oracle's whole act() on the host cores."""
+  K, N, C, algo, nsteps, seconds, threads = int(argv[0]), int(argv[1]), int(argv[2]), argv[3], int(argv[4]), float(argv[5]), int(argv[6])
+  torch.set_num_threads(threads)
   from oatomobile_amd import weights
   from oracle import reference_cpu as O
-  cores = os.cpu_count() or 1
-  torch.set_num_threads(cores)
-  models = [O.OracleImitativeModel.from_numpy_state_dict(weights.synthetic_state_dict(s, args.channels), args.channels)
-            for s in seeds]
-  rng = np.random.default_rng(2)
-  lidar, vec, goal = synth_batch(rng, 1, args.channels)
+  seeds = [100 + k for k in range(K)]
+  models = [O.OracleImitativeModel.from_numpy_state_dict(weights.synthetic_state_dict(s, C), C) for s in seeds]
+  x0 = np.random.default_rng(0).standard_normal((N, 4, 2)).astype(np.float32)
+  x0[0] = 0.0
+  x0 = torch.from_numpy(x0)
+  lidar, vec, goal = synth_batch(np.random.default_rng(2), 1, C)
   goal3 = np.c_[goal[0], np.zeros((goal.shape[1], 1), np.float32)]
 
   def one():
-    O.rip_call(models, lidar[0], vec[0, :3], vec[0, 3], vec[0, 4], goal3, x0=x0_rows, algorithm=args.algorithm,
-               num_steps=args.search_steps)
+    O.rip_call(models, lidar[0], vec[0, :3], vec[0, 3], vec[0, 4], goal3, x0=x0, algorithm=algo, num_steps=nsteps)
 
   one()
   t0 = time.perf_counter()
@@ -72,16 +73,37 @@ def cpu_baseline(args, seeds, x0_rows):
     one()
     n += 1
     dt = time.perf_counter() - t0
-    if dt > args.cpu_seconds or n >= 200:
+    if dt > seconds or n >= 200:
       break
-  return {
-      "value": n / dt,
-      "unit": "calls/s",
-      "cores": cores,
-      "kind": "port",
-      "sample": "%d sequential act() calls (K=%d, N=%d, %d Adam steps, encoders under no_grad = the 'fair' variant), "
-                "PyTorch-CPU oracle, %d threads, %.1f s" % (n, len(seeds), x0_rows.shape[0], args.search_steps, cores, dt),
-  }
+  print(json.dumps({"n": n, "dt": dt}))
+
+
+def cpu_baseline(args):
+  """Bounded sample of the same workload on the CPU oracle ("port"), in a subprocess with a hard timeout
+  so a pathological host (cgroup-limited cores, oversubscribed OpenMP) can never hang the bench."""
+  import subprocess
+  try:
+    avail = len(os.sched_getaffinity(0))
+  except AttributeError:
+    avail = os.cpu_count() or 1
+  threads = max(1, min(avail, 16))  # the oracle's ops are tiny; more threads only add barrier cost
+  cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(args.models), str(args.candidates),
+         str(args.channels), args.algorithm, str(args.search_steps), str(args.cpu_seconds), str(threads)]
+  env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+  base = {"unit": "calls/s", "cores": threads, "kind": "port"}
+  try:
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=max(120.0, 10 * args.cpu_seconds), env=env, cwd=ROOT)
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+  except Exception as e:  # timeout / crash: report, never hang
+    base.update({"value": None, "sample": "cpu baseline failed: %r" % (e,)})
+    return base
+  base.update({
+      "value": r["n"] / r["dt"],
+      "sample": "%d sequential act() calls (K=%d, N=%d, %d Adam steps; encoders under no_grad = the 'fair' variant) of "
+                "oracle/reference_cpu.py (PyTorch CPU), %d threads of %d available host cores, %.1f s" %
+                (r["n"], args.models, args.candidates, args.search_steps, threads, avail, r["dt"]),
+  })
+  return base
 
 
 def main():
@@ -98,6 +120,8 @@ def main():
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--online-calls", type=int, default=200)
+  if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
+    return _cpu_baseline_worker(sys.argv[2:])
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -237,7 +261,7 @@ def main():
         "online": online,
     }
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(args, seeds, agent._x0_rows.cpu())
+      out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))
   if dist is not None:
     dist.barrier()

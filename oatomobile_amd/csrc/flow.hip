@@ -220,23 +220,93 @@ struct ChainOut {
   float sq;   // sum x^2 (INV)
 };
 
-// One pass over the T steps of a chain.
-//   MODE_FWD: reads x from `xin` (LDS/any float[8]), writes y to `yout`.
-//   MODE_INV: reads y from `yin`, writes x to `xout` (may be null).
+// Candidate-independent prefix of a chain: with y_0 = 0 and h_0 = z the first GRU step, its head and
+// W_hh h_1 depend only on (model, observation) — computed once per launch, not per candidate / Adam step.
+struct Prefix {
+  float h1;            // hidden state after step 0 (lane j)
+  float gh[3];         // b_hh + W_hh h_1 (lane j)
+  float dloc0, dloc1;  // head(h_1)
+  float s0, s1;
+  float lad;           // log(s0 * s1)
+};
+
+__device__ __forceinline__ void head_finish(const FlowRegs& W, float a1, float& o0, float& o1, float& o2, float& o3) {
+  // head layer 2: lanes <32 own outputs 0,1 (dloc); lanes >=32 own outputs 2,3 (scale)
+  const float a = fmaxf(a1, 0.f);
+  const float p0 = row_sum16(W.w2a * a);
+  const float p1 = row_sum16(W.w2b * a);
+  o0 = (rl(p0, 0) + rl(p0, 16)) + W.b2[0];
+  o1 = (rl(p1, 0) + rl(p1, 16)) + W.b2[1];
+  o2 = (rl(p0, 32) + rl(p0, 48)) + W.b2[2];
+  o3 = (rl(p1, 32) + rl(p1, 48)) + W.b2[3];
+}
+
+__device__ __forceinline__ Prefix chain_prefix(const FlowRegs& W, const float* w1row, float h0) {
+  Prefix p;
+  float gh[3], a1 = 0.f;
+  matvec<true, false>(W, w1row, h0, gh, a1);
+  // GRUCell with input 0 (sequence.py:119-128)
+  const float r = sigmoidf_(W.bih[0] + gh[0]);
+  const float zg = sigmoidf_(W.bih[1] + gh[1]);
+  const float n = tanhf_(fmaf(r, gh[2], W.bih[2]));
+  p.h1 = fmaf(zg, h0 - n, n);
+  matvec<true, true>(W, w1row, p.h1, p.gh, a1);
+  float o0, o1, o2, o3;
+  head_finish(W, a1, o0, o1, o2, o3);
+  p.dloc0 = o0;
+  p.dloc1 = o1;
+  p.s0 = softplusf_(o2) + 1e-3f;
+  p.s1 = softplusf_(o3) + 1e-3f;
+  p.lad = __logf(p.s0 * p.s1);
+  return p;
+}
+
+// One pass over the T steps of a chain, starting from the shared prefix.
+//   MODE_FWD: reads x from `in8` (LDS/any float[8]), writes y to `out8`.
+//   MODE_INV: reads y from `in8`, writes x to `out8` (may be null).
 // `tape` (LDS, TAPE floats) receives what the adjoint needs when SAVE.
 template <bool SAVE>
-__device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, const float* w1row, float h0,
+__device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, const float* w1row, const Prefix& pre,
                                                   const float* in8, float* out8, float* tape, int lane) {
-  float h = h0;
-  float gh[3];
-  float a1 = 0.f;
-  matvec<true, false>(W, w1row, h, gh, a1);
-  float yp0 = 0.f, yp1 = 0.f;
   ChainOut o;
-  o.lad = 0.f;
+  o.lad = pre.lad;
   o.sq = 0.f;
+  float yp0, yp1;
+  {  // ---- t = 0: only the affine coupling is candidate-specific ----
+    float x0, x1;
+    if (mode == MODE_FWD) {
+      x0 = in8[0];
+      x1 = in8[1];
+      yp0 = pre.dloc0 + pre.s0 * x0;  // (0 + dloc) + scale * x, sequence.py:136
+      yp1 = pre.dloc1 + pre.s1 * x1;
+      if (lane == 0) {
+        out8[0] = yp0;
+        out8[1] = yp1;
+      }
+    } else {
+      yp0 = in8[0];
+      yp1 = in8[1];
+      x0 = (yp0 - pre.dloc0) * rcpf_(pre.s0);
+      x1 = (yp1 - pre.dloc1) * rcpf_(pre.s1);
+      o.sq = fmaf(x0, x0, x1 * x1);
+      if (out8 != nullptr && lane == 0) {
+        out8[0] = x0;
+        out8[1] = x1;
+      }
+    }
+    if (SAVE && lane == 0) {
+      float* tu = tape + TAPE_LANE;
+      tu[0] = x0;
+      tu[1] = x1;
+      tu[2] = pre.s0;
+      tu[3] = pre.s1;
+    }
+  }
+  float h = pre.h1;
+  float gh[3] = {pre.gh[0], pre.gh[1], pre.gh[2]};
+  float a1 = 0.f;
 #pragma unroll 1
-  for (int t = 0; t < T; ++t) {
+  for (int t = 1; t < T; ++t) {
     // ---- GRUCell (sequence.py:128 / :188), gate order r, z, n ----
     const float gir = fmaf(W.wih[0][1], yp1, fmaf(W.wih[0][0], yp0, W.bih[0]));
     const float giz = fmaf(W.wih[1][1], yp1, fmaf(W.wih[1][0], yp0, W.bih[1]));
@@ -261,14 +331,8 @@ __device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, c
       matvec<false, true>(W, w1row, h, gh, a1);
     }
     if (SAVE) tape[t * TAPE_Q * 64 + 5 * 64 + lane] = a1;
-    // ---- head layer 2: lanes <32 own outputs 0,1 (dloc); lanes >=32 own outputs 2,3 (scale) ----
-    const float a = fmaxf(a1, 0.f);
-    const float p0 = row_sum16(W.w2a * a);
-    const float p1 = row_sum16(W.w2b * a);
-    const float o0 = (rl(p0, 0) + rl(p0, 16)) + W.b2[0];
-    const float o1 = (rl(p1, 0) + rl(p1, 16)) + W.b2[1];
-    const float o2 = (rl(p0, 32) + rl(p0, 48)) + W.b2[2];
-    const float o3 = (rl(p1, 32) + rl(p1, 48)) + W.b2[3];
+    float o0, o1, o2, o3;
+    head_finish(W, a1, o0, o1, o2, o3);
     const float s0 = softplusf_(o2) + 1e-3f;  // sequence.py:133
     const float s1 = softplusf_(o3) + 1e-3f;
     float x0, x1, y0, y1;
@@ -311,13 +375,15 @@ __device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, c
 // Adjoint of one chain pass.
 //   MODE_INV: q = -0.5|x|^2 - logabsdet  ->  writes dq/dy to out8.
 //   MODE_FWD: given dL/dy in in8          ->  writes dL/dx to out8.
+// Step 0 has no hidden-state dependence on the candidate (see Prefix), so only steps T-1..1 run the
+// head / GRU adjoint; nothing flows into h_0 = z or y_0 = 0.
 __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, const float* w1row, const float* tape,
                                                const float* in8, float* out8, int lane) {
   const bool upper = lane >= 32;
   float dhdir = 0.f, dpr = 0.f, dpz = 0.f, dghn = 0.f;
   float carry0 = 0.f, carry1 = 0.f;
 #pragma unroll 1
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = T - 1; t >= 1; --t) {
     const float* tu = tape + TAPE_LANE + t * 8;
     const float x0 = tu[0], x1 = tu[1], s0 = tu[2], s1 = tu[3], sg0 = tu[4], sg1 = tu[5];
     float dd0, dd1, dos0, dos1, c0, c1;
@@ -366,11 +432,20 @@ __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, cons
     dghn = dpn * r;
     dpr = dr * r * (1.0f - r);
     dpz = dzg * zg * (1.0f - zg);
-    if (t > 0) {
-      const float du0 = wave_sum(fmaf(W.wih[0][0], dpr, fmaf(W.wih[1][0], dpz, W.wih[2][0] * dpn)));
-      const float du1 = wave_sum(fmaf(W.wih[0][1], dpr, fmaf(W.wih[1][1], dpz, W.wih[2][1] * dpn)));
-      carry0 = c0 + du0;
-      carry1 = c1 + du1;
+    const float du0 = wave_sum(fmaf(W.wih[0][0], dpr, fmaf(W.wih[1][0], dpz, W.wih[2][0] * dpn)));
+    const float du1 = wave_sum(fmaf(W.wih[0][1], dpr, fmaf(W.wih[1][1], dpz, W.wih[2][1] * dpn)));
+    carry0 = c0 + du0;
+    carry1 = c1 + du1;
+  }
+  // ---- t = 0: coupling only ----
+  if (lane == 0) {
+    const float* tu = tape + TAPE_LANE;
+    if (mode == MODE_INV) {
+      out8[0] = carry0 - tu[0] * rcpf_(tu[2]);
+      out8[1] = carry1 - tu[1] * rcpf_(tu[3]);
+    } else {
+      out8[0] = (in8[0] + carry0) * tu[2];
+      out8[1] = (in8[1] + carry1) * tu[3];
     }
   }
 }
@@ -418,11 +493,14 @@ __global__ __launch_bounds__(256) void flow_rows_kernel(int mode, const float* _
   const float* w1row = w1 + (lane & 31) * W1_STRIDE;
   float* my_in = io + wave * 16;
   float* my_out = my_in + 8;
+  Prefix pre;
+  bool first = true;
   for (int row = blockIdx.x * nw + wave; row < N; row += gridDim.x * nw) {
     if (lane < 8) my_in[lane] = in[(size_t)row * 8 + lane];
-    const float h0 = z[(size_t)(z_rows == 1 ? 0 : row) * 64 + lane];
+    if (first || z_rows != 1) pre = chain_prefix(W, w1row, z[(size_t)(z_rows == 1 ? 0 : row) * 64 + lane]);
+    first = false;
     __builtin_amdgcn_wave_barrier();
-    const ChainOut o = chain_forward<false>(mode, W, w1row, h0, my_in, my_out, nullptr, lane);
+    const ChainOut o = chain_forward<false>(mode, W, w1row, pre, my_in, my_out, nullptr, lane);
     __builtin_amdgcn_wave_barrier();
     if (out != nullptr && lane < 8) out[(size_t)row * 8 + lane] = my_out[lane];
     if (lane == 0) {
@@ -459,12 +537,17 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ fl
   const float* w1row = w1 + (lane & 31) * W1_STRIDE;
   float* my_in = io + wave * 8;
   const int rows = B * N;
+  Prefix pre;
+  int pre_b = -1;
   for (int row = blockIdx.x * nw + wave; row < rows; row += gridDim.x * nw) {
     const int b = row / N;
     if (lane < 8) my_in[lane] = y[(size_t)row * 8 + lane];
-    const float h0 = z[((size_t)k * B + b) * 64 + lane];
+    if (b != pre_b) {
+      pre = chain_prefix(W, w1row, z[((size_t)k * B + b) * 64 + lane]);
+      pre_b = b;
+    }
     __builtin_amdgcn_wave_barrier();
-    const ChainOut o = chain_forward<false>(MODE_INV, W, w1row, h0, my_in, nullptr, nullptr, lane);
+    const ChainOut o = chain_forward<false>(MODE_INV, W, w1row, pre, my_in, nullptr, nullptr, lane);
     float s = (-0.5f * o.sq - 4.0f * LOG_2PI) - o.lad;
     if (goal != nullptr) s += goal_ll(goal + (size_t)b * G * 2, G, eps, my_in[6], my_in[7], nullptr, nullptr);
     if (lane == 0) S[((size_t)k * B + b) * N + (row - b * N)] = s;
@@ -505,7 +588,9 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
   FlowRegs W;
   int loaded = wave < K ? wave : 0;
   load_flow_regs(W, a.flow_w + (size_t)(a.k0 + loaded) * FW_SIZE, lane);
-  float h0 = a.z[((size_t)loaded * a.B + b) * 64 + lane];  // context of the resident model
+  __syncthreads();  // W1 rows staged
+  Prefix pre = chain_prefix(W, w1_all + loaded * W1_LDS + (lane & 31) * W1_STRIDE,
+                            a.z[((size_t)loaded * a.B + b) * 64 + lane]);  // prefix of the resident model
   if (a.goal != nullptr)
     for (int i = tid; i < 2 * a.G; i += NW * 64) sh.goal[i] = a.goal[(size_t)b * a.G * 2 + i];
 
@@ -537,13 +622,13 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
       if (k >= 0) {
         if (k != loaded) {
           load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
-          h0 = a.z[((size_t)k * a.B + b) * 64 + lane];
+          pre = chain_prefix(W, w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE, a.z[((size_t)k * a.B + b) * 64 + lane]);
           loaded = k;
         }
         const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;
         const int mode = ph == 0 ? MODE_FWD : MODE_INV;
         float* tape = tapes + (ph == 0 ? 0 : 1 + k) * TAPE;
-        const ChainOut o = chain_forward<true>(mode, W, w1row, h0, ph == 0 ? sh.xbuf : sh.ybuf,
+        const ChainOut o = chain_forward<true>(mode, W, w1row, pre, ph == 0 ? sh.xbuf : sh.ybuf,
                                                ph == 0 ? sh.ybuf : nullptr, tape, lane);
         if (ph == 0) {
           if (goal != nullptr && !final_pass) {
@@ -605,7 +690,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
       if (k >= 0 && needed) {
         if (k != loaded) {
           load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
-          h0 = a.z[((size_t)k * a.B + b) * 64 + lane];
+          pre = chain_prefix(W, w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE, a.z[((size_t)k * a.B + b) * 64 + lane]);
           loaded = k;
         }
         const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;
@@ -715,9 +800,9 @@ __global__ __launch_bounds__(64) void dim_select_kernel(const float* __restrict_
   for (int row = blockIdx.x; row < B; row += gridDim.x) {
     if (lane < 8)
       io[lane] = best_step < 0 ? x0[(size_t)row * 8 + lane] : trace_x[((size_t)best_step * B + row) * 8 + lane];
-    const float h0 = z[(size_t)row * 64 + lane];
+    const Prefix pre = chain_prefix(W, w1row, z[(size_t)row * 64 + lane]);
     __builtin_amdgcn_wave_barrier();
-    chain_forward<false>(MODE_FWD, W, w1row, h0, io, io + 8, nullptr, lane);
+    chain_forward<false>(MODE_FWD, W, w1row, pre, io, io + 8, nullptr, lane);
     __builtin_amdgcn_wave_barrier();
     if (lane < 8) y[(size_t)row * 8 + lane] = io[8 + lane];
     __builtin_amdgcn_wave_barrier();
