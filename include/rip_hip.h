@@ -152,6 +152,11 @@ int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const floa
             const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr, float epsilon,
             int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
 
+/* Selects the plan-search kernel: 0 = auto (MFMA-batched when B*N >= 1024 and N % 16 == 0, K <= 4, no traces),
+ * 1 = wave-per-chain kernel (lowest latency, any K/N, supports traces), 2 = MFMA-batched (16 candidates per wave).
+ * Both implement rip/agent.py:78-137 identically; parity tests run each. */
+int rip_set_search_kernel(rip_handle* h, int mode);
+
 /* Introspection used by bench.py / tests. */
 int rip_num_models(const rip_handle* h);
 int rip_in_channels(const rip_handle* h);

@@ -39,6 +39,7 @@ SIGNATURES = [
         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
         c_int, c_void_p, c_void_p, c_void_p
     ]),
+    ("rip_set_search_kernel", c_int, [c_void_p, c_int]),
     ("rip_num_models", c_int, [c_void_p]),
     ("rip_in_channels", c_int, [c_void_p]),
     ("rip_max_batch", c_int, [c_void_p]),

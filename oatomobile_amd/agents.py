@@ -135,11 +135,14 @@ class RIPAgent(SetPointAgent):
       candidate with the lowest best-loss wins.  N = 1 is the reference algorithm.
     num_steps / lr / epsilon: hard-coded 10 / 0.1 / 1.0 in the reference.
     max_batch: observations per `plan_batch` call.
+    search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 1024 (N % 16 == 0, K <= 4), else the
+      wave-per-chain kernel; both are the same algorithm.
   """
 
   def __init__(self, environment: Any = None, *, algorithm: str, models: Sequence[ImitativeModel],
                num_candidates: int = 1, num_steps: int = 10, lr: float = 1e-1, epsilon: float = 1.0, seed: int = 0,
-               max_batch: int = 1, device: Optional[torch.device] = None, **kwargs) -> None:
+               max_batch: int = 1, device: Optional[torch.device] = None, search_kernel: str = "auto",
+               **kwargs) -> None:
     assert algorithm in ("WCM", "MA", "BCM")  # rip/agent.py:43
     self._algorithm = algorithm
     super().__init__(environment=environment, **kwargs)
@@ -154,6 +157,8 @@ class RIPAgent(SetPointAgent):
                                self._device.index if self._device.index is not None else torch.cuda.current_device())
     for k, m in enumerate(self._models):
       self._handle.load_model(k, m.packed_weights())
+    # "auto" | "chain" (one wave per candidate x model chain) | "mfma" (16 candidates per wave on MFMA)
+    _lib.check(_lib.load().rip_set_search_kernel(self._handle.raw, {"auto": 0, "chain": 1, "mfma": 2}[search_kernel]))
     rng = np.random.default_rng(seed)
     x0 = rng.standard_normal((self._num_candidates, arch_T(), 2)).astype(np.float32)
     x0[0] = 0.0  # base distribution mean (rip/agent.py:85)

@@ -374,7 +374,7 @@ EncoderPlan build_encoder_plan(int in_channels) {
 }
 
 bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc,
-                   std::vector<float>& flow, const char** err) {
+                   std::vector<float>& flow, std::vector<float>& mw, const char** err) {
   enc.assign(plan.blob_floats, 0.f);
   flow.assign(FW_SIZE, 0.f);
   size_t pos = 0;
@@ -456,6 +456,54 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
   }
   for (int c = 0; c < 4; ++c) flow[FW_B2 + c] = b2[c];
   std::memcpy(flow.data() + FW_W1, w1, 32 * 64 * sizeof(float));
+
+  // ---- operands of the MFMA search kernel (flow_mfma.hip): lane (m = lane & 15, q = lane >> 4) ----
+  mw.assign(MW_SIZE, 0.f);
+  auto F = [&](int idx, int lane) -> float& { return mw[(size_t)(idx / 4) * 256 + lane * 4 + (idx & 3)]; };
+  auto Bk = [&](int f4, int lane, int comp) -> float& { return mw[MWF_FLOATS + ((size_t)f4 * 64 + lane) * 4 + comp]; };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, q = lane >> 4;
+    for (int g = 0; g < 3; ++g)
+      for (int up = 0; up < 4; ++up)
+        for (int u = 0; u < 4; ++u)
+          for (int r = 0; r < 4; ++r)
+            F((g * 4 + up) * 16 + u * 4 + r, lane) = whh[(size_t)(g * 64 + 16 * up + m) * 64 + 16 * u + 4 * q + r];
+    for (int up = 0; up < 4; ++up) {
+      const int j = 16 * up + m;
+      for (int a = 0; a < 4; ++a) {
+        const int g = a < 2 ? a : 2;
+        float v = 0.f;
+        if (a < 3) {
+          if (q < 2) v = wih[(g * 64 + j) * 2 + q];
+          if (q == 2) v = a < 2 ? bih[g * 64 + j] + bhh[g * 64 + j] : bih[g * 64 + j];
+        } else if (q == 2) {
+          v = bhh[128 + j];
+        }
+        F(192 + a * 4 + up, lane) = v;
+      }
+    }
+    for (int mt = 0; mt < 2; ++mt) {
+      for (int u = 0; u < 4; ++u)
+        for (int r = 0; r < 4; ++r) F(208 + mt * 16 + u * 4 + r, lane) = w1[(16 * mt + m) * 64 + 16 * u + 4 * q + r];
+      F(240 + mt, lane) = q == 2 ? b1[16 * mt + m] : 0.f;
+      for (int r = 0; r < 4; ++r) F(242 + mt * 4 + r, lane) = w2[(m & 3) * 32 + 16 * mt + 4 * q + r];
+    }
+    F(250, lane) = q == 2 ? b2[m & 3] : 0.f;
+    // adjoint operands
+    Bk(0, lane, 0) = w2[q * 32 + m];
+    Bk(0, lane, 1) = w2[q * 32 + 16 + m];
+    for (int mt = 0; mt < 2; ++mt)
+      for (int r = 0; r < 4; ++r)
+        for (int ut = 0; ut < 4; ++ut) Bk(1 + mt * 4 + r, lane, ut) = w1[(16 * mt + 4 * q + r) * 64 + 16 * ut + m];
+    for (int g = 0; g < 3; ++g)
+      for (int up = 0; up < 4; ++up)
+        for (int r = 0; r < 4; ++r) {
+          const int s = (g * 4 + up) * 4 + r;
+          const int j = g * 64 + 16 * up + 4 * q + r;
+          for (int ut = 0; ut < 4; ++ut) Bk(9 + s, lane, ut) = whh[(size_t)j * 64 + 16 * ut + m];
+          mw[MWF_FLOATS + 57 * 256 + (size_t)s * 64 + lane] = wih[j * 2 + (m & 1)];  // [48][64 lanes]
+        }
+  }
   return true;
 }
 

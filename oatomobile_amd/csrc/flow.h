@@ -17,6 +17,11 @@ constexpr int FW_W2 = 13120;    // [q][64]: W2[2*(j>>5)+q][j & 31]
 constexpr int FW_B2 = 13248;    // [4]
 constexpr int FW_W1 = 13252;    // [32][64] row-major (staged to LDS)
 constexpr int FW_SIZE = 15300;
+// MFMA search kernel operands (flow_mfma.hip): 252 forward values/lane as 63 lane-major float4, then 69
+// lane-major float4 of transposed (adjoint) operands.
+constexpr int MWF_FLOATS = 63 * 64 * 4;
+constexpr int MWB_F4 = 69;
+constexpr int MW_SIZE = MWF_FLOATS + MWB_F4 * 64 * 4;
 constexpr int MAX_MODELS = 8;
 constexpr int MAX_GOALS = 64;
 enum { ALGO_WCM = 0, ALGO_MA = 1, ALGO_BCM = 2 };
@@ -54,5 +59,9 @@ hipError_t launch_select_best(const float* plans, const float* loss_best, int B,
 hipError_t launch_dim_select(const float* flow_w_k, const float* z, const float* x0, const float* trace_loss,
                              const float* trace_x, int B, int num_steps, float* y, float* trace_mean, hipStream_t s);
 size_t search_lds_bytes(int K);
+// MFMA-batched variant (16 candidates per wave); needs N % 16 == 0, K <= 4, no traces
+bool search_mfma_supported(const SearchArgs& a);
+size_t search_mfma_tape_bytes(int B, int N, int K);
+hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s);
 
 }  // namespace rip

@@ -18,6 +18,7 @@
 //                       ImitativeModel.forward loop   baselines/torch/dim/model.py:98-141
 //   adam                torch.optim.Adam defaults     rip/agent.py:96,131
 #include "flow.h"
+#include "flow_math.h"
 
 namespace rip {
 
@@ -30,7 +31,6 @@ constexpr int TAPE_Q = 6;                     // hprev, r, zg, n, ghn, a1
 constexpr int TAPE_LANE = T * TAPE_Q * 64;
 constexpr int TAPE_UNI = T * 8;               // x0,x1,s0,s1,sg0,sg1,pad,pad
 constexpr int TAPE = TAPE_LANE + TAPE_UNI;    // floats per slot
-constexpr float LOG_2PI = 1.8378770664093453f;
 
 enum { MODE_FWD = 0, MODE_INV = 1 };
 
@@ -88,21 +88,6 @@ __device__ __forceinline__ float rs_small(float lo, float hi, int lane) {
   const float keep = up ? hi : lo;
   return keep + xor_lane<D>(send);
 }
-
-// ------------------------------------------------------------------------------------------
-// scalar math (fp32; tolerances of the parity tests are 1e-4 absolute)
-// ------------------------------------------------------------------------------------------
-// v_rcp_f32 / v_exp_f32 / v_log_f32 are ~1 ulp; the parity budget is 1e-4 absolute.
-__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) {
-  // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly for large |x|
-  return 1.0f - 2.0f * rcpf_(__expf(2.0f * x) + 1.0f);
-}
-// F.softplus(beta=1, threshold=20) (sequence.py:133,193); the caller adds the 1e-3 floor, so the
-// absolute error of log(1+e^x) for very negative x (<= 6e-8) is invisible
-__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
-__device__ __forceinline__ float softplus_gradf_(float x) { return x > 20.0f ? 1.0f : sigmoidf_(x); }
 
 // ------------------------------------------------------------------------------------------
 // register-resident weights of one model, as seen by lane j
@@ -448,31 +433,6 @@ __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, cons
       out8[1] = (in8[1] + carry1) * tu[3];
     }
   }
-}
-
-// goal log-likelihood of the last waypoint and (optionally) its gradient  (dim/model.py:163-171)
-__device__ __forceinline__ float goal_ll(const float* __restrict__ goal, int G, float eps, float y0, float y1,
-                                         float* g0, float* g1) {
-  const float inv2 = 1.0f / (2.0f * eps * eps);
-  float m = -INFINITY;
-  for (int j = 0; j < G; ++j) {
-    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
-    m = fmaxf(m, -(d0 * d0 + d1 * d1) * inv2);
-  }
-  float se = 0.f, a0 = 0.f, a1 = 0.f;
-  for (int j = 0; j < G; ++j) {
-    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
-    const float e = expf(-(d0 * d0 + d1 * d1) * inv2 - m);
-    se += e;
-    a0 = fmaf(e, -d0, a0);
-    a1 = fmaf(e, -d1, a1);
-  }
-  if (g0 != nullptr) {
-    const float sc = 2.0f * inv2 / se;  // d/dy logsumexp = sum_j softmax_j * (g_j - y)/eps^2
-    *g0 = a0 * sc;
-    *g1 = a1 * sc;
-  }
-  return m + logf(se) - 2.0f * logf(eps) - LOG_2PI - logf((float)G);
 }
 
 // ------------------------------------------------------------------------------------------

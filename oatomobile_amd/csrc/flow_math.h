@@ -1,0 +1,51 @@
+// Scalar device helpers shared by the flow kernels (flow.hip, flow_mfma.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rip {
+
+constexpr float LOG_2PI = 1.8378770664093453f;
+
+// ------------------------------------------------------------------------------------------
+// scalar math (fp32; tolerances of the parity tests are 1e-4 absolute)
+// ------------------------------------------------------------------------------------------
+// v_rcp_f32 / v_exp_f32 / v_log_f32 are ~1 ulp; the parity budget is 1e-4 absolute.
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly for large |x|
+  return 1.0f - 2.0f * rcpf_(__expf(2.0f * x) + 1.0f);
+}
+// F.softplus(beta=1, threshold=20) (sequence.py:133,193); the caller adds the 1e-3 floor, so the
+// absolute error of log(1+e^x) for very negative x (<= 6e-8) is invisible
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
+__device__ __forceinline__ float softplus_gradf_(float x) { return x > 20.0f ? 1.0f : sigmoidf_(x); }
+
+
+// goal log-likelihood of the last waypoint and (optionally) its gradient  (dim/model.py:163-171)
+__device__ __forceinline__ float goal_ll(const float* __restrict__ goal, int G, float eps, float y0, float y1,
+                                         float* g0, float* g1) {
+  const float inv2 = 1.0f / (2.0f * eps * eps);
+  float m = -INFINITY;
+  for (int j = 0; j < G; ++j) {
+    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
+    m = fmaxf(m, -(d0 * d0 + d1 * d1) * inv2);
+  }
+  float se = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int j = 0; j < G; ++j) {
+    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
+    const float e = expf(-(d0 * d0 + d1 * d1) * inv2 - m);
+    se += e;
+    a0 = fmaf(e, -d0, a0);
+    a1 = fmaf(e, -d1, a1);
+  }
+  if (g0 != nullptr) {
+    const float sc = 2.0f * inv2 / se;  // d/dy logsumexp = sum_j softmax_j * (g_j - y)/eps^2
+    *g0 = a0 * sc;
+    *g1 = a1 * sc;
+  }
+  return m + logf(se) - 2.0f * logf(eps) - LOG_2PI - logf((float)G);
+}
+
+
+}  // namespace rip

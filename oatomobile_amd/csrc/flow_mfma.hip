@@ -1,0 +1,563 @@
+// MFMA-batched RIP plan search for gfx950: 16 candidate plans per wavefront on
+// v_mfma_f32_16x16x4_f32 (fp32 in / fp32 accumulate, bitwise an fmaf chain).
+//
+// Same algorithm and phase structure as search_kernel (flow.hip; rip/agent.py:78-137), different
+// mapping — the throughput kernel for large candidate counts:
+//   * workgroup = 16 candidates of one observation x K models, wave k = model k.
+//   * lane (c = lane & 15, q = lane >> 4) holds, for candidate c, hidden units i = 16u + 4q + r in 16
+//     registers H[u][r].  Every product is computed transposed, OUT^T[j][cand] = sum_i W[j][i] H[cand][i]:
+//     A = a 16-row weight tile, B = H.  The k-step (u, r) contracts units {16u+4q+r : q}, and the result tile
+//     u' comes back as lane (c, q) reg r' <-> unit 16u'+4q+r' — exactly the H layout.  The output of a step is
+//     therefore the B operand of the next one with no data movement; the unit permutation is absorbed into
+//     the host-side weight layout (fold_and_pack_mfma).
+//   * biases and the GRU's 2-wide input are one extra k-step with B = (y0, y1, 1, 0) over q.
+//   * forward operands (251 values/lane) are register resident (MFMA reads AGPRs directly); the transposed
+//     operands of the adjoint (274 values/lane) are streamed from L2 as lane-major float4.
+//   * the per-step tape (88 values/lane/step) goes to a global scratch (L2 resident), per-candidate scalars to LDS.
+#include "flow.h"
+#include "flow_math.h"
+
+namespace rip {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int T = 4;
+constexpr int CB = 16;                        // candidates per workgroup
+constexpr int TAPE_F4 = 22;                   // float4 per lane per heavy step: 4 x (hprev,r,z,n,ghn) + 2 x a1
+constexpr int TAPE_STEP_F4 = TAPE_F4 * 64;    // float4 per heavy step
+constexpr int TAPE_SLOT_F4 = 3 * TAPE_STEP_F4;
+
+enum { MODE_FWD = 0, MODE_INV = 1 };
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+
+// register-resident forward operands of one model (see MWF_* in flow.h)
+struct MW {
+  float wf[192];  // [(g*4+u')*16 + (u*4+r)]  W_hh[g*64+16u'+m][16u+4q+r]
+  float wx[16];   // [a*4+u'], a in {r, z, gi_n, gh_n}: (W_ih[.][0], W_ih[.][1], bias, 0) over q
+  float w1f[32];  // [mt*16 + (u*4+r)]        W1[16mt+m][16u+4q+r]
+  float w1x[2];   // q==2 ? b1[16mt+m] : 0
+  float w2f[8];   // [mt*4+r']                W2[m&3][16mt+4q+r']
+  float w2x;      // q==2 ? b2[m&3] : 0
+};
+
+__device__ __forceinline__ void load_mw(MW& W, const float* __restrict__ blob, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(blob) + lane;
+  float tmp[252];
+#pragma unroll
+  for (int i = 0; i < 63; ++i) {
+    const float4 v = p[i * 64];
+    tmp[4 * i + 0] = v.x;
+    tmp[4 * i + 1] = v.y;
+    tmp[4 * i + 2] = v.z;
+    tmp[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 192; ++i) W.wf[i] = tmp[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) W.wx[i] = tmp[192 + i];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) W.w1f[i] = tmp[208 + i];
+  W.w1x[0] = tmp[240];
+  W.w1x[1] = tmp[241];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) W.w2f[i] = tmp[242 + i];
+  W.w2x = tmp[250];
+}
+
+// One GRU + head step for 16 candidates.  H (in/out): hidden state; (yp0, yp1): GRU input of this lane's
+// candidate; o: head output (dloc0, dloc1, pre-softplus scale0, scale1), replicated over q.
+template <bool SAVE>
+__device__ __forceinline__ void fwd_step(const MW& W, float (&H)[16], float yp0, float yp1, int q,
+                                         float4* __restrict__ tape, float (&o)[4]) {
+  const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
+  float Hn[16];
+#pragma unroll
+  for (int up = 0; up < 4; ++up) {
+    f32x4 ar = zero4(), az = zero4(), agn = zero4(), ahn = zero4();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float b = H[s];
+      ar = mfma(W.wf[(0 * 4 + up) * 16 + s], b, ar);
+      az = mfma(W.wf[(1 * 4 + up) * 16 + s], b, az);
+      ahn = mfma(W.wf[(2 * 4 + up) * 16 + s], b, ahn);
+    }
+    ar = mfma(W.wx[0 * 4 + up], bin, ar);
+    az = mfma(W.wx[1 * 4 + up], bin, az);
+    agn = mfma(W.wx[2 * 4 + up], bin, agn);
+    ahn = mfma(W.wx[3 * 4 + up], bin, ahn);
+    float rr[4], zz[4], nn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rr[r] = sigmoidf_(ar[r]);
+      zz[r] = sigmoidf_(az[r]);
+      nn[r] = tanhf_(fmaf(rr[r], ahn[r], agn[r]));
+      Hn[up * 4 + r] = fmaf(zz[r], H[up * 4 + r] - nn[r], nn[r]);  // (1-z)*n + z*h
+    }
+    if (SAVE) {
+      tape[(up * 5 + 0) * 64] = make_float4(H[up * 4], H[up * 4 + 1], H[up * 4 + 2], H[up * 4 + 3]);
+      tape[(up * 5 + 1) * 64] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+      tape[(up * 5 + 2) * 64] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+      tape[(up * 5 + 3) * 64] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+      tape[(up * 5 + 4) * 64] = make_float4(ahn[0], ahn[1], ahn[2], ahn[3]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) H[i] = Hn[i];
+  // ---- head: a1 = W1 h + b1 (32 x cand), o = W2 relu(a1) + b2 (4 x cand) ----
+  const float bone = q == 2 ? 1.f : 0.f;
+  f32x4 a0 = zero4(), a1 = zero4();
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    a0 = mfma(W.w1f[s], H[s], a0);
+    a1 = mfma(W.w1f[16 + s], H[s], a1);
+  }
+  a0 = mfma(W.w1x[0], bone, a0);
+  a1 = mfma(W.w1x[1], bone, a1);
+  if (SAVE) {
+    tape[20 * 64] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    tape[21 * 64] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+  }
+  f32x4 oa = zero4(), ob = zero4();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    oa = mfma(W.w2f[r], fmaxf(a0[r], 0.f), oa);
+    ob = mfma(W.w2f[4 + r], fmaxf(a1[r], 0.f), ob);
+  }
+  oa = mfma(W.w2x, bone, oa);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = oa[r] + ob[r];
+}
+
+struct MPrefix {
+  float H1[16];
+  float dloc0, dloc1, s0, s1, lad;
+};
+
+struct MShared {
+  float xbuf[CB][8];
+  float ybuf[CB][8];
+  float gsum[CB][8];
+  float gl[3][CB];
+  float q[MAX_MODELS][CB];
+  float gk[MAX_MODELS][CB][8];
+  float goal[2 * MAX_GOALS];
+  float stape[MAX_MODELS + 1][T][6][CB];  // per-candidate scalars of every pass: x0,x1,s0,s1,sg0,sg1
+  float dg[4][64 * 64];                   // per wave: gate gradients of the adjoint (pass_backward)
+};
+
+struct PassOut {
+  float lad, sq;
+};
+
+// forward / inverse pass for this wave's 16 candidates (steps 1..3 are "heavy"; step 0 is the shared prefix)
+__device__ __forceinline__ PassOut pass_forward(int mode, const MW& W, const MPrefix& pre, const float (*in)[8],
+                                                float (*out)[8], float (*st)[6][CB], float4* __restrict__ tape,
+                                                int c, int q) {
+  PassOut po;
+  po.lad = pre.lad;
+  po.sq = 0.f;
+  float yp0, yp1;
+  {
+    float x0, x1;
+    if (mode == MODE_FWD) {
+      x0 = in[c][0];
+      x1 = in[c][1];
+      yp0 = pre.dloc0 + pre.s0 * x0;
+      yp1 = pre.dloc1 + pre.s1 * x1;
+      if (q == 0) {
+        out[c][0] = yp0;
+        out[c][1] = yp1;
+      }
+    } else {
+      yp0 = in[c][0];
+      yp1 = in[c][1];
+      x0 = (yp0 - pre.dloc0) * rcpf_(pre.s0);
+      x1 = (yp1 - pre.dloc1) * rcpf_(pre.s1);
+      po.sq = fmaf(x0, x0, x1 * x1);
+    }
+    if (q == 0) {
+      st[0][0][c] = x0;
+      st[0][1][c] = x1;
+      st[0][2][c] = pre.s0;
+      st[0][3][c] = pre.s1;
+    }
+  }
+  float H[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) H[i] = pre.H1[i];
+#pragma unroll 1
+  for (int t = 1; t < T; ++t) {
+    float o[4];
+    fwd_step<true>(W, H, yp0, yp1, q, tape + (t - 1) * TAPE_STEP_F4, o);
+    const float s0 = softplusf_(o[2]) + 1e-3f;  // sequence.py:133
+    const float s1 = softplusf_(o[3]) + 1e-3f;
+    float x0, x1, y0, y1;
+    if (mode == MODE_FWD) {
+      x0 = in[c][2 * t];
+      x1 = in[c][2 * t + 1];
+      y0 = (yp0 + o[0]) + s0 * x0;  // sequence.py:136
+      y1 = (yp1 + o[1]) + s1 * x1;
+      if (q == 0) {
+        out[c][2 * t] = y0;
+        out[c][2 * t + 1] = y1;
+      }
+    } else {
+      y0 = in[c][2 * t];
+      y1 = in[c][2 * t + 1];
+      x0 = (y0 - (yp0 + o[0])) * rcpf_(s0);  // sequence.py:196
+      x1 = (y1 - (yp1 + o[1])) * rcpf_(s1);
+      po.sq = fmaf(x0, x0, fmaf(x1, x1, po.sq));
+    }
+    po.lad += __logf(s0 * s1);
+    if (q == 0) {
+      st[t][0][c] = x0;
+      st[t][1][c] = x1;
+      st[t][2][c] = s0;
+      st[t][3][c] = s1;
+      st[t][4][c] = softplus_gradf_(o[2]);
+      st[t][5][c] = softplus_gradf_(o[3]);
+    }
+    yp0 = y0;
+    yp1 = y1;
+  }
+  return po;
+}
+
+// adjoint pass.  MODE_INV: writes dq/dy (q = -0.5|x|^2 - logabsdet) to res[8]; MODE_FWD: takes dL/dy from
+// gin[c][*] and writes dL/dx to res[8].  bw: this model's streamed transposed operands (lane base, stride 64);
+// dgl: this wave's LDS scratch [64 slots][64 lanes]: slots 0-15 d pre_r, 16-31 d pre_z, 32-47 d gh_n, 48-63 d pre_n
+// (kept in LDS so the 48-step contractions can be rolled loops with dynamic slot indices).
+__device__ __forceinline__ void pass_backward(int mode, const float4* __restrict__ bw,
+                                              const float* __restrict__ wiht, const float (*gin)[8],
+                                              const float (*st)[6][CB], const float4* __restrict__ tape,
+                                              float* __restrict__ dgl, int c, int q, float (&res)[8]) {
+  float dHdir[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dHdir[i] = 0.f;
+  float carry0 = 0.f, carry1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) res[i] = 0.f;
+#pragma unroll 1
+  for (int t = T - 1; t >= 1; --t) {
+    const float x0 = st[t][0][c], x1 = st[t][1][c], s0 = st[t][2][c], s1 = st[t][3][c];
+    const float sg0 = st[t][4][c], sg1 = st[t][5][c];
+    float dd0, dd1, dos0, dos1, c0, c1, r0, r1;
+    if (mode == MODE_INV) {
+      const float i0 = rcpf_(s0), i1 = rcpf_(s1);
+      const float xs0 = x0 * i0, xs1 = x1 * i1;
+      r0 = carry0 - xs0;
+      r1 = carry1 - xs1;
+      c0 = xs0;
+      c1 = xs1;
+      dd0 = xs0;
+      dd1 = xs1;
+      dos0 = (x0 * x0 - 1.0f) * i0 * sg0;
+      dos1 = (x1 * x1 - 1.0f) * i1 * sg1;
+    } else {
+      const float D0 = gin[c][2 * t] + carry0;
+      const float D1 = gin[c][2 * t + 1] + carry1;
+      r0 = D0 * s0;
+      r1 = D1 * s1;
+      c0 = D0;
+      c1 = D1;
+      dd0 = D0;
+      dd1 = D1;
+      dos0 = D0 * x0 * sg0;
+      dos1 = D1 * x1 * sg1;
+    }
+    // static-index scatter of (r0, r1) into res[2t], res[2t+1]
+#pragma unroll
+    for (int tt = 1; tt < T; ++tt) {
+      res[2 * tt] = tt == t ? r0 : res[2 * tt];
+      res[2 * tt + 1] = tt == t ? r1 : res[2 * tt + 1];
+    }
+    const float4* tp = tape + (t - 1) * TAPE_STEP_F4;
+    // ---- head adjoint: da1 = relu'(a1) * W2^T do ----
+    const float bdo = q == 0 ? dd0 : (q == 1 ? dd1 : (q == 2 ? dos0 : dos1));
+    const float4 w2t = bw[0];
+    const f32x4 da0 = mfma(w2t.x, bdo, zero4());
+    const f32x4 da1 = mfma(w2t.y, bdo, zero4());
+    const float4 a1s0 = tp[20 * 64], a1s1 = tp[21 * 64];
+    float da[8];
+    da[0] = a1s0.x > 0.f ? da0[0] : 0.f;
+    da[1] = a1s0.y > 0.f ? da0[1] : 0.f;
+    da[2] = a1s0.z > 0.f ? da0[2] : 0.f;
+    da[3] = a1s0.w > 0.f ? da0[3] : 0.f;
+    da[4] = a1s1.x > 0.f ? da1[0] : 0.f;
+    da[5] = a1s1.y > 0.f ? da1[1] : 0.f;
+    da[6] = a1s1.z > 0.f ? da1[2] : 0.f;
+    da[7] = a1s1.w > 0.f ? da1[3] : 0.f;
+    // ---- dh_t = W1^T da1_t + W_hh^T dgh_{t+1} + dh'_{t+1} z_{t+1} ----
+    f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4(), acc3 = zero4();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float4 w = bw[(1 + s) * 64];
+      acc0 = mfma(w.x, da[s], acc0);
+      acc1 = mfma(w.y, da[s], acc1);
+      acc2 = mfma(w.z, da[s], acc2);
+      acc3 = mfma(w.w, da[s], acc3);
+    }
+    if (t != T - 1) {
+#pragma unroll 4
+      for (int s = 0; s < 48; ++s) {
+        const float4 w = bw[(9 + s) * 64];
+        const float bv = dgl[s * 64];
+        acc0 = mfma(w.x, bv, acc0);
+        acc1 = mfma(w.y, bv, acc1);
+        acc2 = mfma(w.z, bv, acc2);
+        acc3 = mfma(w.w, bv, acc3);
+      }
+    }
+    // ---- GRUCell adjoint, lane-local in the H layout ----
+    const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int up = 0; up < 4; ++up) {
+      const float4 hp = tp[(up * 5 + 0) * 64], rr = tp[(up * 5 + 1) * 64], zz = tp[(up * 5 + 2) * 64];
+      const float4 nn = tp[(up * 5 + 3) * 64], gh = tp[(up * 5 + 4) * 64];
+      const float hpa[4] = {hp.x, hp.y, hp.z, hp.w}, rra[4] = {rr.x, rr.y, rr.z, rr.w};
+      const float zza[4] = {zz.x, zz.y, zz.z, zz.w}, nna[4] = {nn.x, nn.y, nn.z, nn.w};
+      const float gha[4] = {gh.x, gh.y, gh.z, gh.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = up * 4 + r;
+        const float dh = accs[up][r] + dHdir[i];
+        const float dn = dh * (1.0f - zza[r]);
+        const float dzg = dh * (hpa[r] - nna[r]);
+        dHdir[i] = dh * zza[r];
+        const float dp = dn * (1.0f - nna[r] * nna[r]);
+        const float dr = dp * gha[r];
+        dgl[(48 + i) * 64] = dp;                                 // d pre_n
+        dgl[(32 + i) * 64] = dp * rra[r];                        // d gh_n
+        dgl[i * 64] = dr * rra[r] * (1.0f - rra[r]);             // d pre_r
+        dgl[(16 + i) * 64] = dzg * zza[r] * (1.0f - zza[r]);     // d pre_z
+      }
+    }
+    // ---- du = W_ih^T (dpr, dpz, dpn): rows m <-> input dim m & 1 ----
+    f32x4 dua = zero4(), dub = zero4();
+#pragma unroll 4
+    for (int s = 0; s < 48; s += 2) {
+      const int sl0 = s < 32 ? s : s + 16, sl1 = sl0 + 1;
+      dua = mfma(wiht[s * 64], dgl[sl0 * 64], dua);
+      dub = mfma(wiht[(s + 1) * 64], dgl[sl1 * 64], dub);
+    }
+    carry0 = c0 + (dua[0] + dub[0]);
+    carry1 = c1 + (dua[1] + dub[1]);
+  }
+  // ---- t = 0: coupling only ----
+  {
+    const float x0 = st[0][0][c], x1 = st[0][1][c], s0 = st[0][2][c], s1 = st[0][3][c];
+    if (mode == MODE_INV) {
+      res[0] = carry0 - x0 * rcpf_(s0);
+      res[1] = carry1 - x1 * rcpf_(s1);
+    } else {
+      res[0] = (gin[c][0] + carry0) * s0;
+      res[1] = (gin[c][1] + carry1) * s1;
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void search_mfma_kernel(SearchArgs a, const float* __restrict__ mw_all,
+                                                              float4* __restrict__ tape_all) {
+  __shared__ MShared sh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K;  // == NW
+  const int blocks_per_obs = a.N / CB;
+  const int b = blockIdx.x / blocks_per_obs;
+  const int n0 = (blockIdx.x - b * blocks_per_obs) * CB;
+  const int k = wave;
+  const float* mwk = mw_all + (size_t)(a.k0 + k) * MW_SIZE;
+  MW W;
+  load_mw(W, mwk, lane);
+  const float4* bw = reinterpret_cast<const float4*>(mwk + MWF_FLOATS) + lane;
+  const float* wiht = mwk + MWF_FLOATS + 57 * 256 + lane;  // W_ih^T operands, [48][64 lanes]
+  float* dgl = sh.dg[wave] + lane;
+  float4* tape_fwd = tape_all + ((size_t)blockIdx.x * (K + 1) + 0) * TAPE_SLOT_F4 + lane;
+  float4* tape_inv = tape_all + ((size_t)blockIdx.x * (K + 1) + 1 + k) * TAPE_SLOT_F4 + lane;
+
+  if (a.goal != nullptr)
+    for (int i = tid; i < 2 * a.G; i += NW * 64) sh.goal[i] = a.goal[(size_t)b * a.G * 2 + i];
+  const float* goal = a.goal != nullptr ? sh.goal : nullptr;
+
+  // ---- shared prefix: step 0 from h_0 = z_k (same for all 16 candidates), y_0 = 0 ----
+  MPrefix pre;
+  {
+    float H[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H[u * 4 + r] = a.z[((size_t)k * a.B + b) * 64 + 16 * u + 4 * q + r];
+    float o[4];
+    fwd_step<false>(W, H, 0.f, 0.f, q, nullptr, o);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pre.H1[i] = H[i];
+    pre.dloc0 = o[0];
+    pre.dloc1 = o[1];
+    pre.s0 = softplusf_(o[2]) + 1e-3f;
+    pre.s1 = softplusf_(o[3]) + 1e-3f;
+    pre.lad = __logf(pre.s0 * pre.s1);
+  }
+
+  // Adam state: lane (c, q) owns latent coordinates 2q, 2q+1 of candidate c (wave 0 only)
+  const size_t row = (size_t)b * a.N + n0 + c;
+  float x0v = a.x0[row * 8 + 2 * q], x1v = a.x0[row * 8 + 2 * q + 1];
+  float m0 = 0.f, m1 = 0.f, v0 = 0.f, v1 = 0.f;
+  float xb0 = x0v, xb1 = x1v;
+  float loss_best = 1000.0f;
+  double b1p = 1.0, b2p = 1.0;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int step = 0; step <= a.num_steps; ++step) {
+    const bool final_pass = step == a.num_steps;
+    if (wave == 0) {
+      sh.xbuf[c][2 * q] = final_pass ? xb0 : x0v;
+      sh.xbuf[c][2 * q + 1] = final_pass ? xb1 : x1v;
+    }
+    __syncthreads();
+    // ---------------- forward phases: 0 = F_0 (wave 0), 1 = inverses (all waves) ----------------
+    const int nph = final_pass ? 0 : 1;
+#pragma unroll 1
+    for (int ph = 0; ph <= nph; ++ph) {
+      if (ph == 1 || wave == 0) {
+        const int mode = ph == 0 ? MODE_FWD : MODE_INV;
+        const PassOut po = pass_forward(mode, W, pre, ph == 0 ? sh.xbuf : sh.ybuf, sh.ybuf,
+                                        sh.stape[ph == 0 ? 0 : 1 + k], ph == 0 ? tape_fwd : tape_inv, c, q);
+        if (ph == 0) {
+          float gl = 0.f, g0 = 0.f, g1 = 0.f;
+          if (goal != nullptr && !final_pass) {
+            __builtin_amdgcn_wave_barrier();
+            gl = goal_ll(goal, a.G, a.epsilon, sh.ybuf[c][6], sh.ybuf[c][7], &g0, &g1);
+          }
+          if (q == 0) {
+            sh.gl[0][c] = gl;
+            sh.gl[1][c] = g0;
+            sh.gl[2][c] = g1;
+          }
+        } else if (q == 0) {
+          sh.q[k][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
+        }
+      }
+      __syncthreads();
+    }
+    if (final_pass) break;
+
+    // ---------------- aggregate over the K models, per candidate (rip/agent.py:121-127) ----------------
+    const float gl = sh.gl[0][c];
+    int ksel = 0;
+    float qsel = sh.q[0][c], qmean = sh.q[0][c];
+    for (int kk = 1; kk < K; ++kk) {
+      const float qk = sh.q[kk][c];
+      qmean += qk;
+      const bool take = a.algorithm == ALGO_WCM ? (qk > qsel) : (qk < qsel);
+      if (take) {
+        qsel = qk;
+        ksel = kk;
+      }
+    }
+    qmean /= (float)K;
+    const bool mean_mode = a.algorithm == ALGO_MA;
+    const float loss = -((mean_mode ? qmean : qsel) + gl);
+
+    // ---------------- adjoint phases: 1 = inverses, 0 = F_0 ----------------
+#pragma unroll 1
+    for (int ph = 1; ph >= 0; --ph) {
+      if (ph == 1) {
+        const float wk = mean_mode ? 1.0f / (float)K : (ksel == k ? 1.0f : 0.0f);
+        if (__any(wk != 0.f)) {
+          float res[8];
+          pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[1 + k], tape_inv, dgl, c, q, res);
+          sh.gk[k][c][2 * q] = wk * (q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6]);
+          sh.gk[k][c][2 * q + 1] = wk * (q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7]);
+        } else {
+          sh.gk[k][c][2 * q] = 0.f;
+          sh.gk[k][c][2 * q + 1] = 0.f;
+        }
+      } else if (wave == 0) {
+        // dLoss/dy = -(sum_k w_k dq_k/dy + d gl/dy_T)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = 2 * q + j;
+          float g = 0.f;
+          for (int kk = 0; kk < K; ++kk) g += sh.gk[kk][c][e];
+          if (e >= 6) g += sh.gl[e - 5][c];
+          sh.gsum[c][e] = -g * a.grad_scale;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float res[8];
+        pass_backward(MODE_FWD, bw, wiht, sh.gsum, sh.stape[0], tape_fwd, dgl, c, q, res);
+        const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
+        const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
+        // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
+        b1p *= 0.9;
+        b2p *= 0.999;
+        const float step_size = (float)((double)a.lr / (1.0 - b1p));
+        const float bc2s = (float)sqrt(1.0 - b2p);
+        m0 = m0 + (g0 - m0) * 0.1f;
+        m1 = m1 + (g1 - m1) * 0.1f;
+        v0 = v0 * 0.999f + 0.001f * g0 * g0;
+        v1 = v1 * 0.999f + 0.001f * g1 * g1;
+        x0v = x0v - step_size * (m0 / (sqrtf(v0) / bc2s + 1e-8f));
+        x1v = x1v - step_size * (m1 / (sqrtf(v1) / bc2s + 1e-8f));
+        if (loss < loss_best) {  // post-step x vs pre-step loss (rip/agent.py:131-135)
+          xb0 = x0v;
+          xb1 = x1v;
+          loss_best = loss;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // plan = F_0(x_best) is in ybuf (rip/agent.py:137)
+  if (wave == 0) {
+    if (a.plans != nullptr) {
+      a.plans[row * 8 + 2 * q] = sh.ybuf[c][2 * q];
+      a.plans[row * 8 + 2 * q + 1] = sh.ybuf[c][2 * q + 1];
+    }
+    if (a.loss_best != nullptr && q == 0) a.loss_best[row] = loss_best;
+  }
+}
+
+}  // namespace
+
+size_t search_mfma_tape_bytes(int B, int N, int K) {
+  return (size_t)B * (N / CB) * (K + 1) * TAPE_SLOT_F4 * sizeof(float4);
+}
+
+bool search_mfma_supported(const SearchArgs& a) {
+  return a.K >= 1 && a.K <= 4 && a.N % CB == 0 && a.trace_post == nullptr && a.trace_x == nullptr &&
+         a.trace_loss == nullptr;
+}
+
+hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s) {
+  const dim3 grid(a.B * (a.N / CB));
+  float4* tp = reinterpret_cast<float4*>(tape);
+  switch (a.K) {
+    case 1:
+      hipLaunchKernelGGL(search_mfma_kernel<1>, grid, dim3(64), 0, s, a, mw_all, tp);
+      break;
+    case 2:
+      hipLaunchKernelGGL(search_mfma_kernel<2>, grid, dim3(128), 0, s, a, mw_all, tp);
+      break;
+    case 3:
+      hipLaunchKernelGGL(search_mfma_kernel<3>, grid, dim3(192), 0, s, a, mw_all, tp);
+      break;
+    default:
+      hipLaunchKernelGGL(search_mfma_kernel<4>, grid, dim3(256), 0, s, a, mw_all, tp);
+      break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rip

@@ -23,6 +23,10 @@ struct rip_handle {
   EncoderPlan plan;
   float* enc_w = nullptr;   // [K][plan.blob_floats]
   float* flow_w = nullptr;  // [K][FW_SIZE]
+  float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the MFMA search kernel
+  void* tape = nullptr;     // scratch of the MFMA search kernel
+  size_t tape_bytes = 0;
+  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA-batched
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
   size_t buf_floats = 0;
@@ -97,6 +101,7 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int devi
   } while (0)
   ALLOC(h->enc_w, (size_t)K * h->plan.blob_floats);
   ALLOC(h->flow_w, (size_t)K * FW_SIZE);
+  ALLOC(h->mfma_w, (size_t)K * MW_SIZE);
   for (int i = 0; i < 4; ++i) ALLOC(h->bufs[i], h->buf_floats);
   ALLOC(h->visual, (size_t)max_batch * in_channels * 100 * 100);
   ALLOC(h->z, (size_t)K * max_batch * 64);
@@ -108,11 +113,19 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int devi
 int rip_destroy(rip_handle* h) {
   if (h == nullptr) return RIP_OK;
   (void)hipSetDevice(h->device);
-  float* ptrs[] = {h->enc_w, h->flow_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  if (h->tape != nullptr) (void)hipFree(h->tape);
+  float* ptrs[] = {h->enc_w, h->flow_w, h->mfma_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
   delete h;
+  return RIP_OK;
+}
+
+int rip_set_search_kernel(rip_handle* h, int mode) {
+  REQUIRE(h != nullptr, "handle is NULL");
+  REQUIRE(mode >= 0 && mode <= 2, "mode %d not in {0 auto, 1 wave-per-chain, 2 mfma}", mode);
+  h->search_mode = mode;
   return RIP_OK;
 }
 
@@ -123,12 +136,13 @@ int rip_max_batch(const rip_handle* h) { return h ? h->max_batch : RIP_EINVAL; }
 int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel) {
   REQUIRE(h != nullptr && packed_host != nullptr, "NULL argument");
   REQUIRE(k >= 0 && k < h->K, "model index %d outside [0,%d)", k, h->K);
-  std::vector<float> enc, flow;
+  std::vector<float> enc, flow, mw;
   const char* err = "";
-  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
+  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpy(h->enc_w + (size_t)k * h->plan.blob_floats, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
   h->loaded[k] = true;
   return RIP_OK;
 }
@@ -262,7 +276,24 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   a.trace_post = trace_post_dev;
   a.trace_x = trace_x_dev;
   a.trace_loss = nullptr;
-  HIP_TRY(launch_search(a, (hipStream_t)stream));
+  // kernel choice: the MFMA-batched kernel wins once there are enough 16-candidate blocks to fill the chip;
+  // the wave-per-chain kernel has the lower latency for a single observation.
+  bool use_mfma = search_mfma_supported(a) && h->search_mode != 1 && (h->search_mode == 2 || (size_t)B * N >= 1024);
+  if (h->search_mode == 2 && !search_mfma_supported(a))
+    return fail(RIP_EINVAL, "MFMA search kernel needs K<=4, N%%16==0 and no trace outputs (K=%d N=%d)", h->K, N);
+  if (use_mfma) {
+    const size_t need = search_mfma_tape_bytes(B, N, h->K);
+    if (need > h->tape_bytes) {
+      if (h->tape != nullptr) (void)hipFree(h->tape);
+      h->tape = nullptr;
+      h->tape_bytes = 0;
+      HIP_TRY(hipMalloc(&h->tape, need));
+      h->tape_bytes = need;
+    }
+    HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));
+  } else {
+    HIP_TRY(launch_search(a, (hipStream_t)stream));
+  }
   if (need_select) HIP_TRY(launch_select_best(plans, lbest, B, N, plan_dev, best_index_dev, (hipStream_t)stream));
   return RIP_OK;
 }

@@ -223,14 +223,17 @@ def test_g8_scores(golden, dev):
   np.testing.assert_allclose(S.cpu().numpy()[:, 0], g["SG"], rtol=2e-5, atol=2e-3)
 
 
-@pytest.mark.parametrize("algo,K,N", [("WCM", 4, 128), ("MA", 3, 16), ("BCM", 2, 5), ("WCM", 1, 7), ("WCM", 8, 8)])
-def test_search_candidates_vs_oracle(dev, algo, K, N):
+@pytest.mark.parametrize("kernel,algo,K,N", [("chain", "WCM", 4, 128), ("chain", "MA", 3, 16), ("chain", "BCM", 2, 5),
+                                             ("chain", "WCM", 1, 7), ("chain", "WCM", 8, 8),
+                                             ("mfma", "WCM", 4, 128), ("mfma", "MA", 3, 16), ("mfma", "BCM", 2, 32),
+                                             ("mfma", "WCM", 1, 16)])
+def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
   """N candidates (BASELINE config 3 = K4/N128): every candidate's best loss and plan vs the oracle."""
   from oatomobile_amd import RIPAgent
   from oracle import reference_cpu as O
   models = [hip_model(200 + k, dev) for k in range(K)]
   refs = [oracle_model(200 + k) for k in range(K)]
-  agent = RIPAgent(None, algorithm=algo, models=models, num_candidates=N, seed=5)
+  agent = RIPAgent(None, algorithm=algo, models=models, num_candidates=N, seed=5, search_kernel=kernel)
   ob = synth_observation(np.random.default_rng(77))
   lidar = torch.from_numpy(ob["lidar"]).to(dev)[None]
   vec = torch.tensor([[*ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"]]], device=dev)
@@ -245,6 +248,27 @@ def test_search_candidates_vs_oracle(dev, algo, K, N):
   assert close.mean() >= 0.97, (lh, lo)
   if abs(np.sort(lo)[0] - np.sort(lo)[min(1, N - 1)]) > 1e-3 or N == 1:
     np.testing.assert_allclose(plan.cpu().numpy()[0], res["plan"].numpy(), atol=5e-4)
+
+
+def test_mfma_kernel_matches_chain_kernel(dev):
+  """The two search kernels are the same algorithm: per-candidate best losses and plans agree (B=3, N=32)."""
+  from oatomobile_amd import RIPAgent
+  models = [hip_model(300 + k, dev) for k in range(4)]
+  obs = [synth_observation(np.random.default_rng(700 + i)) for i in range(3)]
+  lidar = torch.stack([torch.from_numpy(o["lidar"]) for o in obs]).to(dev)
+  vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
+  goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
+  out = {}
+  for kern in ("chain", "mfma"):
+    agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=32, max_batch=3, seed=9, search_kernel=kern)
+    plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
+    out[kern] = (plan.cpu().numpy(), loss.cpu().numpy())
+  close = np.abs(out["chain"][1] - out["mfma"][1]) <= 1e-3 + 1e-4 * np.abs(out["chain"][1])
+  assert close.mean() >= 0.97
+  np.testing.assert_allclose(out["chain"][0], out["mfma"][0], atol=5e-4)
+  with pytest.raises(Exception):
+    RIPAgent(None, algorithm="WCM", models=models, num_candidates=5, search_kernel="mfma").plan_batch(
+        lidar[:1].contiguous(), vec[:1].contiguous(), goal[:1].contiguous())
 
 
 def test_batched_act_matches_single(dev):
