@@ -501,7 +501,7 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
           const int s = (g * 4 + up) * 4 + r;
           const int j = g * 64 + 16 * up + 4 * q + r;
           for (int ut = 0; ut < 4; ++ut) Bk(9 + s, lane, ut) = whh[(size_t)j * 64 + 16 * ut + m];
-          mw[MWF_FLOATS + 57 * 256 + (size_t)s * 64 + lane] = wih[j * 2 + (m & 1)];  // [48][64 lanes]
+          Bk(57 + s / 4, lane, s & 3) = wih[j * 2 + (m & 1)];
         }
   }
   return true;

@@ -147,11 +147,12 @@ struct MShared {
   float ybuf[CB][8];
   float gsum[CB][8];
   float gl[3][CB];
-  float q[MAX_MODELS][CB];
-  float gk[MAX_MODELS][CB][8];
+  float q[4][CB];
+  float gk[4][CB][8];
   float goal[2 * MAX_GOALS];
-  float stape[MAX_MODELS + 1][T][6][CB];  // per-candidate scalars of every pass: x0,x1,s0,s1,sg0,sg1
-  float dg[4][64 * 64];                   // per wave: gate gradients of the adjoint (pass_backward)
+  float stape[4 + 1][T][6][CB];  // per-candidate scalars of every pass: x0,x1,s0,s1,sg0,sg1
+  float dg[4][88 * 64];                   // per wave: gate gradients + carried dh of the adjoint (pass_backward)
+  float4 wiht[4][12 * 64];                // per wave: W_ih^T operands of its model (48 contraction steps)
 };
 
 struct PassOut {
@@ -235,14 +236,14 @@ __device__ __forceinline__ PassOut pass_forward(int mode, const MW& W, const MPr
 // adjoint pass.  MODE_INV: writes dq/dy (q = -0.5|x|^2 - logabsdet) to res[8]; MODE_FWD: takes dL/dy from
 // gin[c][*] and writes dL/dx to res[8].  bw: this model's streamed transposed operands (lane base, stride 64);
 // dgl: this wave's LDS scratch [64 slots][64 lanes]: slots 0-15 d pre_r, 16-31 d pre_z, 32-47 d gh_n, 48-63 d pre_n
-// (kept in LDS so the 48-step contractions can be rolled loops with dynamic slot indices).
+// (kept in LDS so the 48-step contractions can be rolled loops with dynamic slot indices); slots 64-79 carry
+// dh'_{t+1} z_{t+1}, slots 80-87 hold da1_t.  wiht4: LDS copy of the W_ih^T operands (lane base, stride 64).
 __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict__ bw,
-                                              const float* __restrict__ wiht, const float (*gin)[8],
+                                              const float4* __restrict__ wiht4, const float (*gin)[8],
                                               const float (*st)[6][CB], const float4* __restrict__ tape,
                                               float* __restrict__ dgl, int c, int q, float (&res)[8]) {
-  float dHdir[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) dHdir[i] = 0.f;
+  for (int i = 0; i < 16; ++i) dgl[(64 + i) * 64] = 0.f;
   float carry0 = 0.f, carry1 = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) res[i] = 0.f;
@@ -282,35 +283,37 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     }
     const float4* tp = tape + (t - 1) * TAPE_STEP_F4;
     // ---- head adjoint: da1 = relu'(a1) * W2^T do ----
-    const float bdo = q == 0 ? dd0 : (q == 1 ? dd1 : (q == 2 ? dos0 : dos1));
     const float4 w2t = bw[0];
+    const float4 a1s0 = tp[20 * 64], a1s1 = tp[21 * 64];
+    // Streamed operands are issued well ahead of their MFMAs (explicit register ring): the L2 round trip
+    // (~700 cycles) is longer than the 16 MFMAs (512 cycles) one float4 feeds.  The contraction is one
+    // sequence of 8 (W1^T, B = da1) + 48 (W_hh^T, B = dgh_{t+1}) steps; at t = T-1 only the first 8 exist.
+    constexpr int RING = 8;
+    const int nsteps = t == T - 1 ? 8 : 56;
+    float4 wb[RING];
+#pragma unroll
+    for (int j = 0; j < RING; ++j) wb[j] = bw[(1 + j) * 64];
+    const float bdo = q == 0 ? dd0 : (q == 1 ? dd1 : (q == 2 ? dos0 : dos1));
     const f32x4 da0 = mfma(w2t.x, bdo, zero4());
     const f32x4 da1 = mfma(w2t.y, bdo, zero4());
-    const float4 a1s0 = tp[20 * 64], a1s1 = tp[21 * 64];
-    float da[8];
-    da[0] = a1s0.x > 0.f ? da0[0] : 0.f;
-    da[1] = a1s0.y > 0.f ? da0[1] : 0.f;
-    da[2] = a1s0.z > 0.f ? da0[2] : 0.f;
-    da[3] = a1s0.w > 0.f ? da0[3] : 0.f;
-    da[4] = a1s1.x > 0.f ? da1[0] : 0.f;
-    da[5] = a1s1.y > 0.f ? da1[1] : 0.f;
-    da[6] = a1s1.z > 0.f ? da1[2] : 0.f;
-    da[7] = a1s1.w > 0.f ? da1[3] : 0.f;
+    dgl[80 * 64] = a1s0.x > 0.f ? da0[0] : 0.f;
+    dgl[81 * 64] = a1s0.y > 0.f ? da0[1] : 0.f;
+    dgl[82 * 64] = a1s0.z > 0.f ? da0[2] : 0.f;
+    dgl[83 * 64] = a1s0.w > 0.f ? da0[3] : 0.f;
+    dgl[84 * 64] = a1s1.x > 0.f ? da1[0] : 0.f;
+    dgl[85 * 64] = a1s1.y > 0.f ? da1[1] : 0.f;
+    dgl[86 * 64] = a1s1.z > 0.f ? da1[2] : 0.f;
+    dgl[87 * 64] = a1s1.w > 0.f ? da1[3] : 0.f;
     // ---- dh_t = W1^T da1_t + W_hh^T dgh_{t+1} + dh'_{t+1} z_{t+1} ----
     f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4(), acc3 = zero4();
+#pragma unroll 1
+    for (int s0 = 0; s0 < nsteps; s0 += RING) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float4 w = bw[(1 + s) * 64];
-      acc0 = mfma(w.x, da[s], acc0);
-      acc1 = mfma(w.y, da[s], acc1);
-      acc2 = mfma(w.z, da[s], acc2);
-      acc3 = mfma(w.w, da[s], acc3);
-    }
-    if (t != T - 1) {
-#pragma unroll 4
-      for (int s = 0; s < 48; ++s) {
-        const float4 w = bw[(9 + s) * 64];
-        const float bv = dgl[s * 64];
+      for (int j = 0; j < RING; ++j) {
+        const float4 w = wb[j];
+        if (s0 + RING < nsteps) wb[j] = bw[(1 + s0 + RING + j) * 64];
+        const int sl = s0 == 0 ? 80 + j : s0 - 8 + j;  // B operand slot: da1 for the first 8 steps, then dgh
+        const float bv = dgl[sl * 64];
         acc0 = mfma(w.x, bv, acc0);
         acc1 = mfma(w.y, bv, acc1);
         acc2 = mfma(w.z, bv, acc2);
@@ -329,10 +332,10 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = up * 4 + r;
-        const float dh = accs[up][r] + dHdir[i];
+        const float dh = accs[up][r] + dgl[(64 + i) * 64];
         const float dn = dh * (1.0f - zza[r]);
         const float dzg = dh * (hpa[r] - nna[r]);
-        dHdir[i] = dh * zza[r];
+        dgl[(64 + i) * 64] = dh * zza[r];
         const float dp = dn * (1.0f - nna[r] * nna[r]);
         const float dr = dp * gha[r];
         dgl[(48 + i) * 64] = dp;                                 // d pre_n
@@ -343,11 +346,14 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     }
     // ---- du = W_ih^T (dpr, dpz, dpn): rows m <-> input dim m & 1 ----
     f32x4 dua = zero4(), dub = zero4();
-#pragma unroll 4
-    for (int s = 0; s < 48; s += 2) {
-      const int sl0 = s < 32 ? s : s + 16, sl1 = sl0 + 1;
-      dua = mfma(wiht[s * 64], dgl[sl0 * 64], dua);
-      dub = mfma(wiht[(s + 1) * 64], dgl[sl1 * 64], dub);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      const int sl = 4 * g < 32 ? 4 * g : 4 * g + 16;
+      const float4 wq = wiht4[g * 64];
+      dua = mfma(wq.x, dgl[(sl + 0) * 64], dua);
+      dub = mfma(wq.y, dgl[(sl + 1) * 64], dub);
+      dua = mfma(wq.z, dgl[(sl + 2) * 64], dua);
+      dub = mfma(wq.w, dgl[(sl + 3) * 64], dub);
     }
     carry0 = c0 + (dua[0] + dub[0]);
     carry1 = c1 + (dua[1] + dub[1]);
@@ -381,7 +387,9 @@ __global__ __launch_bounds__(NW * 64) void search_mfma_kernel(SearchArgs a, cons
   MW W;
   load_mw(W, mwk, lane);
   const float4* bw = reinterpret_cast<const float4*>(mwk + MWF_FLOATS) + lane;
-  const float* wiht = mwk + MWF_FLOATS + 57 * 256 + lane;  // W_ih^T operands, [48][64 lanes]
+#pragma unroll
+  for (int g = 0; g < 12; ++g) sh.wiht[wave][g * 64 + lane] = bw[(57 + g) * 64];  // own model, read only by this wave
+  const float4* wiht = sh.wiht[wave] + lane;
   float* dgl = sh.dg[wave] + lane;
   float4* tape_fwd = tape_all + ((size_t)blockIdx.x * (K + 1) + 0) * TAPE_SLOT_F4 + lane;
   float4* tape_inv = tape_all + ((size_t)blockIdx.x * (K + 1) + 1 + k) * TAPE_SLOT_F4 + lane;
