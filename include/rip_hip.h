@@ -152,10 +152,15 @@ int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const floa
             const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr, float epsilon,
             int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
 
-/* Selects the plan-search kernel: 0 = auto (MFMA-batched when B*N >= 1024 and N % 16 == 0, K <= 4, no traces),
- * 1 = wave-per-chain kernel (lowest latency, any K/N, supports traces), 2 = MFMA-batched (16 candidates per wave).
- * Both implement rip/agent.py:78-137 identically; parity tests run each. */
-int rip_set_search_kernel(rip_handle* h, int mode);
+/* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (MFMA-batched when B*N >= 1024, N % 16 == 0, K <= 4, no traces),
+ *     1 = wave-per-chain kernel (lowest latency, any K/N, supports traces),
+ *     2 = MFMA-batched kernel (16 candidates per wave).  Both implement rip/agent.py:78-137.
+ *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
+ *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
+ *     as one batched kernel per conv layer.  -1 (default) = auto: 3 when B >= 8, else 0. */
+enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1 };
+int rip_set_option(rip_handle* h, int option, int value);
 
 /* Introspection used by bench.py / tests. */
 int rip_num_models(const rip_handle* h);

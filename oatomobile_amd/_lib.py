@@ -39,7 +39,7 @@ SIGNATURES = [
         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
         c_int, c_void_p, c_void_p, c_void_p
     ]),
-    ("rip_set_search_kernel", c_int, [c_void_p, c_int]),
+    ("rip_set_option", c_int, [c_void_p, c_int, c_int]),
     ("rip_num_models", c_int, [c_void_p]),
     ("rip_in_channels", c_int, [c_void_p]),
     ("rip_max_batch", c_int, [c_void_p]),
@@ -47,6 +47,8 @@ SIGNATURES = [
 
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
+OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED = 0, 1
+SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2}
 
 _lib = None
 
@@ -109,6 +111,9 @@ class Handle:
     import numpy as np
     packed = np.ascontiguousarray(packed, dtype=np.float32)
     check(self._lib.rip_load_model(self._h, k, packed.ctypes.data_as(c_void_p), packed.size))
+
+  def set_option(self, option: int, value: int) -> None:
+    check(self._lib.rip_set_option(self._h, option, value))
 
   def close(self) -> None:
     if self._h:

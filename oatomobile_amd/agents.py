@@ -9,6 +9,7 @@ setpoint/target-speed pair the PID would consume.
 """
 
 import copy
+import os
 from typing import Any, Mapping, Optional, Sequence
 
 import numpy as np
@@ -142,7 +143,7 @@ class RIPAgent(SetPointAgent):
   def __init__(self, environment: Any = None, *, algorithm: str, models: Sequence[ImitativeModel],
                num_candidates: int = 1, num_steps: int = 10, lr: float = 1e-1, epsilon: float = 1.0, seed: int = 0,
                max_batch: int = 1, device: Optional[torch.device] = None, search_kernel: str = "auto",
-               **kwargs) -> None:
+               fused_encoder: Optional[int] = None, **kwargs) -> None:
     assert algorithm in ("WCM", "MA", "BCM")  # rip/agent.py:43
     self._algorithm = algorithm
     super().__init__(environment=environment, **kwargs)
@@ -158,7 +159,11 @@ class RIPAgent(SetPointAgent):
     for k, m in enumerate(self._models):
       self._handle.load_model(k, m.packed_weights())
     # "auto" | "chain" (one wave per candidate x model chain) | "mfma" (16 candidates per wave on MFMA)
-    _lib.check(_lib.load().rip_set_search_kernel(self._handle.raw, {"auto": 0, "chain": 1, "mfma": 2}[search_kernel]))
+    self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS[search_kernel])
+    if fused_encoder is None and "RIP_ENCODER_FUSED" in os.environ:
+      fused_encoder = int(os.environ["RIP_ENCODER_FUSED"])
+    if fused_encoder is not None:
+      self._handle.set_option(_lib.OPT_ENCODER_FUSED, int(fused_encoder))
     rng = np.random.default_rng(seed)
     x0 = rng.standard_normal((self._num_candidates, arch_T(), 2)).astype(np.float32)
     x0[0] = 0.0  # base distribution mean (rip/agent.py:85)

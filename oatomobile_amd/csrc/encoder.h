@@ -22,9 +22,16 @@ struct Layer {
   int src, dst, res;  // workspace buffer ids (0..3); src == -1 -> the [B,C,100,100] network input
 };
 
+// one torchvision InvertedResidual block = [expand] + depthwise + project (indices into EncoderPlan::layers)
+struct FusedBlock {
+  int expand, dw, project;  // expand == -1 for the t == 1 block
+  int src, dst;             // workspace buffers (block input / output)
+};
+
 struct EncoderPlan {
   int in_channels;
   std::vector<Layer> layers;
+  std::vector<FusedBlock> blocks;
   size_t cls_w_off, cls_b_off;     // classifier.1  [128][1280], [128]
   size_t mrg_w_off[3], mrg_b_off[3];  // merger Linear 133->64, 64->64, 64->64
   size_t blob_floats;              // per-model folded blob size
@@ -45,7 +52,13 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
 
 // Runs the encoder + merger for models [k0, k0+kc) on B observations.
 //   enc_w: [K_total][plan.blob_floats]; visual [B,C,100,100]; vec [B,5]; bufs[4]: each >= kc*B*max_act floats.
+//   fused_blocks: the first `fused_blocks` inverted-residual blocks run as one kernel each (encoder_fused.hip),
+//   the rest layer by layer.
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
-                          const float* vec, int B, float* const bufs[4], float* z, float* feat, hipStream_t s);
+                          const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
+                          hipStream_t s);
+
+hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
+                              size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);
 
 }  // namespace rip

@@ -340,13 +340,21 @@ EncoderPlan build_encoder_plan(int in_channels) {
       const int hidden = inp * t;
       const int e = (cur + 1) & 3, d = (cur + 2) & 3, o = (cur + 3) & 3;
       int src = cur;
+      FusedBlock fb;
+      fb.expand = -1;
+      fb.src = cur;
+      fb.dst = o;
       if (t != 1) {
+        fb.expand = (int)p.layers.size();
         add(L_PW, inp, hidden, h, 1, 1, 0, cur, e, -1);
         src = e;
       }
+      fb.dw = (int)p.layers.size();
       const int h2 = add(L_DW, hidden, hidden, h, stride, 1, 0, src, d, -1);
       const int residual = (stride == 1 && inp == c) ? 1 : 0;
+      fb.project = (int)p.layers.size();
       add(L_PW, hidden, c, h2, 1, 0, residual, d, o, residual ? cur : -1);
+      p.blocks.push_back(fb);
       cur = o;
       inp = c;
       h = h2;
@@ -517,9 +525,29 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
 }
 
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
-                          const float* vec, int B, float* const bufs[4], float* z, float* feat, hipStream_t s) {
+                          const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
+                          hipStream_t s) {
   const size_t ms = plan.blob_floats;
-  for (const Layer& l : plan.layers) {
+  std::vector<char> in_block(plan.layers.size(), 0);
+  {
+    for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
+      const FusedBlock& fb = plan.blocks[bi];
+      if (fb.expand >= 0) in_block[fb.expand] = 1;
+      in_block[fb.dw] = 1;
+      in_block[fb.project] = 2;  // the block is launched where its last layer sits
+    }
+  }
+  size_t next_block = 0;
+  for (size_t li = 0; li < plan.layers.size(); ++li) {
+    const Layer& l = plan.layers[li];
+    if (in_block[li] == 1) continue;
+    if (in_block[li] == 2) {
+      const FusedBlock& fb = plan.blocks[next_block++];
+      hipError_t e = launch_fused_block(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw],
+                                        plan.layers[fb.project], enc_w, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     float* dst = bufs[l.dst];
     if (l.kind == L_STEM) {
       const int total = B * l.h_out * l.h_out * 8;

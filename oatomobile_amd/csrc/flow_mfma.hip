@@ -174,6 +174,7 @@ __device__ __forceinline__ PassOut pass_forward(int mode, const MW& W, const MPr
       x1 = in[c][1];
       yp0 = pre.dloc0 + pre.s0 * x0;
       yp1 = pre.dloc1 + pre.s1 * x1;
+      po.sq = fmaf(x0, x0, x1 * x1);
       if (q == 0) {
         out[c][0] = yp0;
         out[c][1] = yp1;
@@ -207,6 +208,7 @@ __device__ __forceinline__ PassOut pass_forward(int mode, const MW& W, const MPr
       x1 = in[c][2 * t + 1];
       y0 = (yp0 + o[0]) + s0 * x0;  // sequence.py:136
       y1 = (yp1 + o[1]) + s1 * x1;
+      po.sq = fmaf(x0, x0, fmaf(x1, x1, po.sq));
       if (q == 0) {
         out[c][2 * t] = y0;
         out[c][2 * t + 1] = y1;
@@ -241,7 +243,8 @@ __device__ __forceinline__ PassOut pass_forward(int mode, const MW& W, const MPr
 __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict__ bw,
                                               const float4* __restrict__ wiht4, const float (*gin)[8],
                                               const float (*st)[6][CB], const float4* __restrict__ tape,
-                                              float* __restrict__ dgl, int c, int q, float (&res)[8]) {
+                                              float* __restrict__ dgl, int c, int q, float (&res)[8],
+                                              float w0 = 0.f) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) dgl[(64 + i) * 64] = 0.f;
   float carry0 = 0.f, carry1 = 0.f;
@@ -264,16 +267,18 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
       dos0 = (x0 * x0 - 1.0f) * i0 * sg0;
       dos1 = (x1 * x1 - 1.0f) * i1 * sg1;
     } else {
+      // w0 != 0: this candidate's loss also holds -w0 * q_0 with q_0 = -0.5|x|^2 - logabsdet_F(x) evaluated on the
+      // forward pass itself (inverse_0(F_0(x)) == x): d/dx_t = w0 x_t, d/ds_t = w0 / s_t.
       const float D0 = gin[c][2 * t] + carry0;
       const float D1 = gin[c][2 * t + 1] + carry1;
-      r0 = D0 * s0;
-      r1 = D1 * s1;
+      r0 = fmaf(D0, s0, w0 * x0);
+      r1 = fmaf(D1, s1, w0 * x1);
       c0 = D0;
       c1 = D1;
       dd0 = D0;
       dd1 = D1;
-      dos0 = D0 * x0 * sg0;
-      dos1 = D1 * x1 * sg1;
+      dos0 = (D0 * x0 + w0 * rcpf_(s0)) * sg0;
+      dos1 = (D1 * x1 + w0 * rcpf_(s1)) * sg1;
     }
     // static-index scatter of (r0, r1) into res[2t], res[2t+1]
 #pragma unroll
@@ -365,8 +370,8 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
       res[0] = carry0 - x0 * rcpf_(s0);
       res[1] = carry1 - x1 * rcpf_(s1);
     } else {
-      res[0] = (gin[c][0] + carry0) * s0;
-      res[1] = (gin[c][1] + carry1) * s1;
+      res[0] = fmaf(gin[c][0] + carry0, s0, w0 * x0);
+      res[1] = fmaf(gin[c][1] + carry1, s1, w0 * x1);
     }
   }
 }
@@ -537,6 +542,236 @@ __global__ __launch_bounds__(NW * 64) void search_mfma_kernel(SearchArgs a, cons
   }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Software-pipelined variant: 32 candidates (blocks A, B of 16) per workgroup.  Wave 0 is the forward wave of
+// model 0: F_0 and its adjoint only — its own posterior q_0 = -0.5|x|^2 - logabsdet_F needs no inverse pass
+// because inverse_0(F_0(x)) == x (same weights, same teacher-forced inputs), and its gradient is folded into the
+// F_0 adjoint (pass_backward's w0 terms).  Waves 1..K-1 run the inverses of models 1..K-1 and their adjoints.
+// The two blocks are staggered by half an Adam step so both wave groups always have work:
+//     tick      wave 0                 waves k >= 1
+//     4i        F(A, i)                adjoint-inverse(B, i-1)
+//     4i+1      adjoint-F(B, i-1)+Adam inverse(A, i)
+//     4i+2      F(B, i)                adjoint-inverse(A, i)
+//     4i+3      adjoint-F(A, i)+Adam   inverse(B, i)
+// --------------------------------------------------------------------------------------------------------
+struct MShared2 {
+  float xbuf[2][CB][8];
+  float ybuf[2][CB][8];
+  float gsum[2][CB][8];
+  float gl[2][3][CB];
+  float q[2][4][CB];
+  float gk[2][4][CB][8];
+  float goal[2 * MAX_GOALS];
+  float stape[2][4][T][6][CB];   // [block][0 = forward pass, k = inverse of model k]
+  float dg[4][88 * 64];
+  float4 wiht[4][12 * 64];
+};
+
+struct Agg {
+  int ksel;
+  float loss, w0;
+  bool mean_mode;
+};
+
+__device__ __forceinline__ Agg aggregate(const float (*qb)[CB], const float (*glb)[CB], int K, int algorithm, int c,
+                                         float grad_scale) {
+  Agg g;
+  const float gl = glb[0][c];
+  int ksel = 0;
+  float qsel = qb[0][c], qmean = qb[0][c];
+  for (int kk = 1; kk < K; ++kk) {
+    const float qk = qb[kk][c];
+    qmean += qk;
+    const bool take = algorithm == ALGO_WCM ? (qk > qsel) : (qk < qsel);
+    if (take) {
+      qsel = qk;
+      ksel = kk;
+    }
+  }
+  qmean /= (float)K;
+  g.mean_mode = algorithm == ALGO_MA;
+  g.ksel = ksel;
+  g.loss = -((g.mean_mode ? qmean : qsel) + gl);
+  g.w0 = (g.mean_mode ? 1.0f / (float)K : (ksel == 0 ? 1.0f : 0.0f)) * grad_scale;
+  return g;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, const float* __restrict__ mw_all,
+                                                               float4* __restrict__ tape_all) {
+  __shared__ MShared2 sh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K;  // == NW
+  const int wgs_per_obs = a.N / (2 * CB);
+  const int b = blockIdx.x / wgs_per_obs;
+  const int n0 = (blockIdx.x - b * wgs_per_obs) * 2 * CB;
+  const int k = wave;
+  const float* mwk = mw_all + (size_t)(a.k0 + k) * MW_SIZE;
+  MW W;
+  load_mw(W, mwk, lane);
+  const float4* bw = reinterpret_cast<const float4*>(mwk + MWF_FLOATS) + lane;
+#pragma unroll
+  for (int g = 0; g < 12; ++g) sh.wiht[wave][g * 64 + lane] = bw[(57 + g) * 64];
+  const float4* wiht = sh.wiht[wave] + lane;
+  float* dgl = sh.dg[wave] + lane;
+  // tape slots of this workgroup: [block][wave]  (wave 0: forward pass, wave k: inverse of model k)
+  float4* tape_blk[2];
+  tape_blk[0] = tape_all + ((size_t)blockIdx.x * 2 * K + 0 * K + wave) * TAPE_SLOT_F4 + lane;
+  tape_blk[1] = tape_all + ((size_t)blockIdx.x * 2 * K + 1 * K + wave) * TAPE_SLOT_F4 + lane;
+
+  if (a.goal != nullptr)
+    for (int i = tid; i < 2 * a.G; i += NW * 64) sh.goal[i] = a.goal[(size_t)b * a.G * 2 + i];
+  const float* goal = a.goal != nullptr ? sh.goal : nullptr;
+
+  MPrefix pre;
+  {
+    float H[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H[u * 4 + r] = a.z[((size_t)k * a.B + b) * 64 + 16 * u + 4 * q + r];
+    float o[4];
+    fwd_step<false>(W, H, 0.f, 0.f, q, nullptr, o);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pre.H1[i] = H[i];
+    pre.dloc0 = o[0];
+    pre.dloc1 = o[1];
+    pre.s0 = softplusf_(o[2]) + 1e-3f;
+    pre.s1 = softplusf_(o[3]) + 1e-3f;
+    pre.lad = __logf(pre.s0 * pre.s1);
+  }
+
+  // Adam state of both blocks: lane (c, q) owns coordinates 2q, 2q+1 of candidate c (wave 0 only)
+  float xv[2][2], am[2][2], av[2][2], xb[2][2], lbest[2];
+  double b1p[2] = {1.0, 1.0}, b2p[2] = {1.0, 1.0};
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const size_t row = (size_t)b * a.N + n0 + blk * CB + c;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xv[blk][j] = a.x0[row * 8 + 2 * q + j];
+      xb[blk][j] = xv[blk][j];
+      am[blk][j] = 0.f;
+      av[blk][j] = 0.f;
+    }
+    lbest[blk] = 1000.0f;
+  }
+  __syncthreads();
+
+  const int S = a.num_steps;
+  const int nticks = 4 * S + 3;  // round S: final F(A), adjoint-inverse/adjoint-F(B, S-1), final F(B)
+#pragma unroll 1
+  for (int tick = 0; tick < nticks; ++tick) {
+    const int i = tick >> 2, p = tick & 3;
+    if (wave == 0) {
+      if (p == 0 || p == 2) {
+        // ---------------- F(blk, i)  (or the final pass with x_best when i == S) ----------------
+        const int blk = p >> 1;
+        const bool final_pass = i == S;
+        sh.xbuf[blk][c][2 * q] = final_pass ? xb[blk][0] : xv[blk][0];
+        sh.xbuf[blk][c][2 * q + 1] = final_pass ? xb[blk][1] : xv[blk][1];
+        __builtin_amdgcn_wave_barrier();
+        const PassOut po = pass_forward(MODE_FWD, W, pre, sh.xbuf[blk], sh.ybuf[blk], sh.stape[blk][0],
+                                        tape_blk[blk], c, q);
+        float gl = 0.f, g0 = 0.f, g1 = 0.f;
+        if (goal != nullptr && !final_pass) {
+          __builtin_amdgcn_wave_barrier();
+          gl = goal_ll(goal, a.G, a.epsilon, sh.ybuf[blk][c][6], sh.ybuf[blk][c][7], &g0, &g1);
+        }
+        if (q == 0) {
+          sh.gl[blk][0][c] = gl;
+          sh.gl[blk][1][c] = g0;
+          sh.gl[blk][2][c] = g1;
+          sh.q[blk][0][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // model 0's posterior via the shortcut
+        }
+      } else {
+        // ---------------- adjoint-F(blk, j) + Adam: p == 1 -> (B, i-1), p == 3 -> (A, i) ----------------
+        const int blk = p == 1 ? 1 : 0;
+        const int j = p == 1 ? i - 1 : i;
+        if (j >= 0 && j < S) {
+          const Agg ag = aggregate(sh.q[blk], sh.gl[blk], K, a.algorithm, c, a.grad_scale);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int e = 2 * q + jj;
+            float g = 0.f;
+            for (int kk = 1; kk < K; ++kk) g += sh.gk[blk][kk][c][e];
+            if (e >= 6) g += sh.gl[blk][e - 5][c];
+            sh.gsum[blk][c][e] = -g * a.grad_scale;
+          }
+          __builtin_amdgcn_wave_barrier();
+          float res[8];
+          pass_backward(MODE_FWD, bw, wiht, sh.gsum[blk], sh.stape[blk][0], tape_blk[blk], dgl, c, q, res, ag.w0);
+          const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
+          const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
+          // select this block's Adam state with static indices
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            if (bb == blk) {
+              b1p[bb] *= 0.9;
+              b2p[bb] *= 0.999;
+              const float step_size = (float)((double)a.lr / (1.0 - b1p[bb]));
+              const float bc2s = (float)sqrt(1.0 - b2p[bb]);
+              am[bb][0] = am[bb][0] + (g0 - am[bb][0]) * 0.1f;
+              am[bb][1] = am[bb][1] + (g1 - am[bb][1]) * 0.1f;
+              av[bb][0] = av[bb][0] * 0.999f + 0.001f * g0 * g0;
+              av[bb][1] = av[bb][1] * 0.999f + 0.001f * g1 * g1;
+              xv[bb][0] = xv[bb][0] - step_size * (am[bb][0] / (sqrtf(av[bb][0]) / bc2s + 1e-8f));
+              xv[bb][1] = xv[bb][1] - step_size * (am[bb][1] / (sqrtf(av[bb][1]) / bc2s + 1e-8f));
+              if (ag.loss < lbest[bb]) {  // post-step x vs pre-step loss (rip/agent.py:131-135)
+                xb[bb][0] = xv[bb][0];
+                xb[bb][1] = xv[bb][1];
+                lbest[bb] = ag.loss;
+              }
+            }
+          }
+        }
+      }
+    } else {
+      if (p == 1 || p == 3) {
+        // ---------------- inverse(blk, i) of model k ----------------
+        const int blk = p == 1 ? 0 : 1;
+        if (i < S) {
+          const PassOut po = pass_forward(MODE_INV, W, pre, sh.ybuf[blk], sh.ybuf[blk], sh.stape[blk][k],
+                                          tape_blk[blk], c, q);
+          if (q == 0) sh.q[blk][k][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;
+        }
+      } else {
+        // ---------------- adjoint-inverse(blk, j): p == 0 -> (B, i-1), p == 2 -> (A, i) ----------------
+        const int blk = p == 0 ? 1 : 0;
+        const int j = p == 0 ? i - 1 : i;
+        if (j >= 0 && j < S) {
+          const Agg ag = aggregate(sh.q[blk], sh.gl[blk], K, a.algorithm, c, a.grad_scale);
+          const float wk = ag.mean_mode ? 1.0f / (float)K : (ag.ksel == k ? 1.0f : 0.0f);
+          if (__any(wk != 0.f)) {
+            float res[8];
+            pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[blk][k], tape_blk[blk], dgl, c, q, res);
+            sh.gk[blk][k][c][2 * q] = wk * (q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6]);
+            sh.gk[blk][k][c][2 * q + 1] = wk * (q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7]);
+          } else {
+            sh.gk[blk][k][c][2 * q] = 0.f;
+            sh.gk[blk][k][c][2 * q + 1] = 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // plans = F_0(x_best) of both blocks are in ybuf (rip/agent.py:137)
+  if (wave == 0) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const size_t row = (size_t)b * a.N + n0 + blk * CB + c;
+      if (a.plans != nullptr) {
+        a.plans[row * 8 + 2 * q] = sh.ybuf[blk][c][2 * q];
+        a.plans[row * 8 + 2 * q + 1] = sh.ybuf[blk][c][2 * q + 1];
+      }
+      if (a.loss_best != nullptr && q == 0) a.loss_best[row] = lbest[blk];
+    }
+  }
+}
+
 }  // namespace
 
 size_t search_mfma_tape_bytes(int B, int N, int K) {
@@ -549,8 +784,26 @@ bool search_mfma_supported(const SearchArgs& a) {
 }
 
 hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s) {
-  const dim3 grid(a.B * (a.N / CB));
   float4* tp = reinterpret_cast<float4*>(tape);
+  if (a.N % (2 * CB) == 0) {  // pipelined dual-block kernel
+    const dim3 grid2(a.B * (a.N / (2 * CB)));
+    switch (a.K) {
+      case 1:
+        hipLaunchKernelGGL(search_mfma2_kernel<1>, grid2, dim3(64), 0, s, a, mw_all, tp);
+        break;
+      case 2:
+        hipLaunchKernelGGL(search_mfma2_kernel<2>, grid2, dim3(128), 0, s, a, mw_all, tp);
+        break;
+      case 3:
+        hipLaunchKernelGGL(search_mfma2_kernel<3>, grid2, dim3(192), 0, s, a, mw_all, tp);
+        break;
+      default:
+        hipLaunchKernelGGL(search_mfma2_kernel<4>, grid2, dim3(256), 0, s, a, mw_all, tp);
+        break;
+    }
+    return hipGetLastError();
+  }
+  const dim3 grid(a.B * (a.N / CB));
   switch (a.K) {
     case 1:
       hipLaunchKernelGGL(search_mfma_kernel<1>, grid, dim3(64), 0, s, a, mw_all, tp);

@@ -27,6 +27,7 @@ struct rip_handle {
   void* tape = nullptr;     // scratch of the MFMA search kernel
   size_t tape_bytes = 0;
   int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA-batched
+  int encoder_fused = -1;   // leading inverted-residual blocks run fused (0 = none, 17 = all); -1 = auto by batch
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
   size_t buf_floats = 0;
@@ -122,11 +123,20 @@ int rip_destroy(rip_handle* h) {
   return RIP_OK;
 }
 
-int rip_set_search_kernel(rip_handle* h, int mode) {
+int rip_set_option(rip_handle* h, int option, int value) {
   REQUIRE(h != nullptr, "handle is NULL");
-  REQUIRE(mode >= 0 && mode <= 2, "mode %d not in {0 auto, 1 wave-per-chain, 2 mfma}", mode);
-  h->search_mode = mode;
-  return RIP_OK;
+  switch (option) {
+    case RIP_OPT_SEARCH_KERNEL:
+      REQUIRE(value >= 0 && value <= 2, "search kernel %d not in {0 auto, 1 wave-per-chain, 2 mfma}", value);
+      h->search_mode = value;
+      return RIP_OK;
+    case RIP_OPT_ENCODER_FUSED:
+      REQUIRE(value >= -1 && value <= 17, "encoder_fused must be in [-1,17] (got %d)", value);
+      h->encoder_fused = value;
+      return RIP_OK;
+    default:
+      return fail(RIP_EINVAL, "unknown option %d", option);
+  }
 }
 
 int rip_num_models(const rip_handle* h) { return h ? h->K : RIP_EINVAL; }
@@ -163,7 +173,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
   REQUIRE(enc_dtype == RIP_ENC_FP32, "encoder dtype %d not supported yet (fp32 only)", enc_dtype);
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
-                         (hipStream_t)stream));
+                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream));
   return RIP_OK;
 }
 

@@ -182,6 +182,8 @@ class ImitativeModel(nn.Module):
     if self._dirty:
       self._hip[0].load_model(0, self.packed_weights())
       self._dirty = False
+    if getattr(self, "fused_encoder", None) is not None:
+      self._hip[0].set_option(_lib.OPT_ENCODER_FUSED, int(self.fused_encoder))
     return self._hip[0]
 
   # -- reference API -------------------------------------------------------------------------

@@ -120,6 +120,19 @@ def test_g5_params(golden, dev):
       np.testing.assert_allclose(z, g["z_w%d_o%d" % (ws, os_)], atol=TOL)
 
 
+def test_layerwise_encoder_matches_fused(golden, dev):
+  """RIP_OPT_ENCODER_FUSED sweeps: every split between fused blocks and per-layer kernels gives the golden z."""
+  g = golden("g5_params.npz")
+  m = hip_model(5, dev)
+  obs = [synth_observation(np.random.default_rng(50 + i)) for i in range(2)]
+  ctx = ctx_tensors(obs, dev)
+  for nfused in (0, 4, 17):  # all layer-wise, hybrid, every block fused
+    m.fused_encoder = nfused
+    z = m._params(**ctx).cpu().numpy()
+    for i, os_ in enumerate((50, 51)):
+      np.testing.assert_allclose(z[i], g["z_w5_o%d" % os_], atol=TOL, err_msg="fused_blocks=%d" % nfused)
+
+
 def test_params_missing_key_raises(dev):
   m = hip_model(5, dev)
   with pytest.raises(ValueError, match="Missing `velocity`"):
