@@ -24,7 +24,6 @@ constexpr double BN_EPS = 1e-5;
 
 inline int conv_out(int h, int stride) { return (h + 2 - 3) / stride + 1; }
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 
@@ -154,75 +153,128 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in, c
 
 // ------------------------------------------------------------------------------------------------
 // K4: pointwise conv as GEMM  out[M][Cout] = act(in[M][Cin] * W[Cout][Cin]^T + bias) (+ residual),
-// M = B*H*W rows of one model.  fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, bitwise an fmaf
-// chain).  Block = 4 waves, tile 64x64, each wave one 32x32 accumulator; K tiles of 32 through LDS.
+// M = B*H*W rows of one model.  Register-direct fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, bitwise
+// an fmaf chain): no LDS, no barriers.  The product is formed transposed, OUT^T[co][pixel]: A = 16 output
+// channels of W, B = 16 pixels, both K-contiguous float4 loads (k-step (S, r) contracts channels 16S+4q+r);
+// lane (n = lane & 15, q = lane >> 4) ends up with 4 consecutive output channels of pixel n -> float4 NHWC stores.
+// A wave owns PT pixel tiles x CT channel tiles; with CT covering all of Cout the activations are read once.
 // ------------------------------------------------------------------------------------------------
-constexpr int PW_BM = 64, PW_BN = 64, PW_BK = 32, PW_LD = PW_BK + 1;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+template <int CT, int PT, int UNROLL>
 __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
                                                   size_t model_stride, int k0, size_t w_off, size_t b_off,
                                                   const float* __restrict__ res, float* __restrict__ out, int M,
                                                   int Cin, int Cout, int relu6, size_t act_model_stride_in,
                                                   size_t act_model_stride_out) {
-  __shared__ float As[PW_BM * PW_LD];
-  __shared__ float Ws[PW_BN * PW_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
   const int k = blockIdx.z;
-  const float* A = in + (size_t)k * act_model_stride_in;
-  const float* Wg = wbase + (size_t)(k0 + k) * model_stride + w_off;
+  const int ptile0 = (blockIdx.x * 4 + wave) * PT;
+  const int ctile0 = blockIdx.y * CT;
+  if (ptile0 * 16 >= M) return;
+  const float* A = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const float* X = in + (size_t)k * act_model_stride_in;
   float* O = out + (size_t)k * act_model_stride_out;
   const float* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
-  const int m0 = blockIdx.x * PW_BM, n0 = blockIdx.y * PW_BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  for (int kt = 0; kt < Cin; kt += PW_BK) {
+  const float* arow[CT];
+  bool aval[CT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256;
-      const int row = e >> 3, c4 = (e & 7) * 4;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
-      if (m0 + row < M && kt + c4 < Cin) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * Cin + kt + c4);
-      if (n0 + row < Cout && kt + c4 < Cin)
-        vw = *reinterpret_cast<const float4*>(Wg + (size_t)(n0 + row) * Cin + kt + c4);
-      float* pa = As + row * PW_LD + c4;
-      pa[0] = va.x;
-      pa[1] = va.y;
-      pa[2] = va.z;
-      pa[3] = va.w;
-      float* pw = Ws + row * PW_LD + c4;
-      pw[0] = vw.x;
-      pw[1] = vw.y;
-      pw[2] = vw.z;
-      pw[3] = vw.w;
-    }
-    __syncthreads();
-    const float* ar = As + (wr * 32 + (lane & 31)) * PW_LD + (lane >> 5);
-    const float* br = Ws + (wc * 32 + (lane & 31)) * PW_LD + (lane >> 5);
-#pragma unroll
-    for (int kk = 0; kk < PW_BK / 2; ++kk) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * kk], br[2 * kk], acc, 0, 0, 0);
-    }
-    __syncthreads();
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + n;
+    aval[ct] = co < Cout;
+    arow[ct] = A + (size_t)min(co, Cout - 1) * Cin + 4 * q;
   }
-  // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int n = n0 + wc * 32 + (lane & 31);
-  if (n < Cout) {
-    const float bv = bias[n];
+  const float* brow[PT];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (m < M) {
-        float v = acc[reg] + bv;
-        if (R != nullptr) v += R[(size_t)m * Cout + n];
-        if (relu6) v = relu6f(v);
-        O[(size_t)m * Cout + n] = v;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int p = (ptile0 + pt) * 16 + n;
+    brow[pt] = X + (size_t)min(p, M - 1) * Cin + 4 * q;
+  }
+  f32x4 acc[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll UNROLL
+  for (int kc = 0; kc < Cin; kc += 16) {
+    const bool kval = kc + 4 * q < Cin;  // Cin is a multiple of 8: a lane's float4 is all-valid or all-pad
+    float4 av[CT], bv[PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      av[ct] = (kval && aval[ct]) ? *reinterpret_cast<const float4*>(arow[ct] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+      bv[pt] = kval ? *reinterpret_cast<const float4*>(brow[pt] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        f32x4 c = acc[ct][pt];
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].x, bv[pt].x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].y, bv[pt].y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].z, bv[pt].z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct].w, bv[pt].w, c, 0, 0, 0);
+        acc[ct][pt] = c;
       }
     }
   }
+  // C/D layout of the 16x16 MFMA: col = lane & 15 (pixel), row = 4*(lane >> 4) + reg (channel)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + 4 * q;
+    if (co < Cout) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = (ptile0 + pt) * 16 + n;
+        if (p < M) {
+          float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
+                                 acc[ct][pt][3] + bb.w);
+          if (R != nullptr) {
+            const float4 r = *reinterpret_cast<const float4*>(R + (size_t)p * Cout + co);
+            v.x += r.x;
+            v.y += r.y;
+            v.z += r.z;
+            v.w += r.w;
+          }
+          if (relu6) {
+            v.x = relu6f(v.x);
+            v.y = relu6f(v.y);
+            v.z = relu6f(v.z);
+            v.w = relu6f(v.w);
+          }
+          *reinterpret_cast<float4*>(O + (size_t)p * Cout + co) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int CT, int PT, int UNROLL>
+void launch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc, const Layer& l, const float* res,
+               float* dst, int M, hipStream_t s) {
+  const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
+  const dim3 grid(((n_pt + PT - 1) / PT + 3) / 4, (n_ct + CT - 1) / CT, kc);
+  hipLaunchKernelGGL((pw_kernel<CT, PT, UNROLL>), grid, dim3(256), 0, s, in, enc_w, ms, k0, l.w_off, l.b_off, res,
+                     dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+}
+
+// biggest wave tile that still leaves >= ~4 waves per CU; small problems get 16x16 tiles for parallelism.
+// Small tiles feed few MFMAs per K chunk, so their K loop is unrolled deeper to keep more loads in flight.
+void dispatch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc, const Layer& l, const float* res,
+                 float* dst, int M, hipStream_t s) {
+  const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
+  auto waves = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
+  const long want = 1024;
+  if (n_ct >= 5 && waves(6, 2) >= want) return launch_pw<6, 2, 2>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
+  if (n_ct >= 3 && waves(4, 2) >= want) return launch_pw<4, 2, 2>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
+  if (n_ct >= 2 && waves(2, 2) >= want) return launch_pw<2, 2, 4>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
+  if (waves(1, 2) >= want) return launch_pw<1, 2, 8>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
+  return launch_pw<1, 1, 8>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -560,11 +612,8 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
                          l.stride, dst);
     } else {
       const int M = B * l.h_out * l.h_out;
-      const size_t sin = (size_t)M * l.cin, sout = (size_t)M * l.cout;
       const float* res = l.residual ? bufs[l.res] : nullptr;
-      hipLaunchKernelGGL(pw_kernel, dim3((M + PW_BM - 1) / PW_BM, (l.cout + PW_BN - 1) / PW_BN, kc), dim3(256), 0, s,
-                         (const float*)bufs[l.src], enc_w, ms, k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout,
-                         l.relu6, sin, sout);
+      dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, s);
     }
   }
   // classifier logits go to `feat` if the caller wants them, else to scratch at the end of a free buffer
