@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in, c
 // ------------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int CT, int PT, int UNROLL>
+// KSPLIT = 1: the block's 4 waves take 4 different pixel-tile groups.  KSPLIT = 4: they take the 4 quarters of the
+// K range of ONE (CT x PT) tile and reduce through LDS — big register tiles (little operand re-reading from L2)
+// and still enough waves when M is small (7x7 / 4x4 stages, or a single observation).
+template <int CT, int PT, int UNROLL, int KSPLIT>
 __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
                                                   size_t model_stride, int k0, size_t w_off, size_t b_off,
                                                   const float* __restrict__ res, float* __restrict__ out, int M,
@@ -170,9 +173,9 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int k = blockIdx.z;
-  const int ptile0 = (blockIdx.x * 4 + wave) * PT;
+  const int ptile0 = (KSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * PT;
   const int ctile0 = blockIdx.y * CT;
-  if (ptile0 * 16 >= M) return;
+  if (KSPLIT == 1 && ptile0 * 16 >= M) return;
   const float* A = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
   const float* X = in + (size_t)k * act_model_stride_in;
@@ -199,9 +202,18 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll UNROLL
-  for (int kc = 0; kc < Cin; kc += 16) {
-    const bool kval = kc + 4 * q < Cin;  // Cin is a multiple of 8: a lane's float4 is all-valid or all-pad
+  // UNROLL chunks per trip, all their loads issued before the first MFMA (chunks past Cin are predicated off)
+  // K range of this wave (multiples of 16)
+  const int kchunks = (Cin + 15) / 16;
+  const int kper = (kchunks + KSPLIT - 1) / KSPLIT;
+  const int kbeg = KSPLIT == 1 ? 0 : 16 * kper * wave;
+  const int kend = KSPLIT == 1 ? Cin : min(Cin, 16 * kper * (wave + 1));
+#pragma unroll 1
+  for (int kc0 = kbeg; kc0 < kend; kc0 += 16 * UNROLL) {
+#pragma unroll
+   for (int u = 0; u < UNROLL; ++u) {
+    const int kc = kc0 + 16 * u;
+    const bool kval = kc + 4 * q < kend;  // Cin is a multiple of 8: a lane's float4 is all-valid or all-pad
     float4 av[CT], bv[PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -221,6 +233,35 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
         acc[ct][pt] = c;
       }
     }
+   }
+  }
+  if (KSPLIT > 1) {
+    // reduce the K slices: every wave parks its partial tiles in LDS, then wave w finishes tiles t = w (mod 4)
+    __shared__ float4 part[KSPLIT][CT * PT][64];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        part[wave][ct * PT + pt][lane] = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int t = ct * PT + pt;
+        if ((t & (KSPLIT - 1)) == wave) {
+          float4 sum = part[0][t][lane];
+#pragma unroll
+          for (int w2 = 1; w2 < KSPLIT; ++w2) {
+            const float4 o = part[w2][t][lane];
+            sum.x += o.x;
+            sum.y += o.y;
+            sum.z += o.z;
+            sum.w += o.w;
+          }
+          acc[ct][pt] = f32x4{sum.x, sum.y, sum.z, sum.w};
+        }
+      }
   }
   // C/D layout of the 16x16 MFMA: col = lane & 15 (pixel), row = 4*(lane >> 4) + reg (channel)
 #pragma unroll
@@ -231,7 +272,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
-        if (p < M) {
+        if (p < M && (KSPLIT == 1 || ((ct * PT + pt) & (KSPLIT - 1)) == wave)) {
           float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                  acc[ct][pt][3] + bb.w);
           if (R != nullptr) {
@@ -254,27 +295,37 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
   }
 }
 
-template <int CT, int PT, int UNROLL>
+template <int CT, int PT, int UNROLL, int KSPLIT>
 void launch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc, const Layer& l, const float* res,
                float* dst, int M, hipStream_t s) {
   const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
-  const dim3 grid(((n_pt + PT - 1) / PT + 3) / 4, (n_ct + CT - 1) / CT, kc);
-  hipLaunchKernelGGL((pw_kernel<CT, PT, UNROLL>), grid, dim3(256), 0, s, in, enc_w, ms, k0, l.w_off, l.b_off, res,
-                     dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+  const int groups = (n_pt + PT - 1) / PT;
+  const dim3 grid(KSPLIT == 1 ? (groups + 3) / 4 : groups, (n_ct + CT - 1) / CT, kc);
+  hipLaunchKernelGGL((pw_kernel<CT, PT, UNROLL, KSPLIT>), grid, dim3(256), 0, s, in, enc_w, ms, k0, l.w_off, l.b_off,
+                     res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
 }
 
-// biggest wave tile that still leaves >= ~4 waves per CU; small problems get 16x16 tiles for parallelism.
-// Small tiles feed few MFMAs per K chunk, so their K loop is unrolled deeper to keep more loads in flight.
+// Tile choice: the biggest wave tile that still yields >= ~1024 waves.  When even that is impossible with one
+// wave per tile (small M) and the reduction is long enough, the 4 waves of a block split K instead.
 void dispatch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc, const Layer& l, const float* res,
                  float* dst, int M, hipStream_t s) {
   const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
-  auto waves = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
+  auto jobs = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
   const long want = 1024;
-  if (n_ct >= 5 && waves(6, 2) >= want) return launch_pw<6, 2, 2>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
-  if (n_ct >= 3 && waves(4, 2) >= want) return launch_pw<4, 2, 2>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
-  if (n_ct >= 2 && waves(2, 2) >= want) return launch_pw<2, 2, 4>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
-  if (waves(1, 2) >= want) return launch_pw<1, 2, 8>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
-  return launch_pw<1, 1, 8>(in, enc_w, ms, k0, kc, l, res, dst, M, s);
+#define PW_GO(CT_, PT_, U_, KS_) return launch_pw<CT_, PT_, U_, KS_>(in, enc_w, ms, k0, kc, l, res, dst, M, s)
+  if (n_ct >= 5 && jobs(6, 2) >= want) PW_GO(6, 2, 2, 1);
+  if (n_ct >= 3 && jobs(4, 2) >= want) PW_GO(4, 2, 2, 1);
+  if (n_ct >= 2 && jobs(2, 2) >= want) PW_GO(2, 2, 4, 1);
+  if (l.cin >= 128) {  // >= 8 K chunks: split K over the block's waves
+    if (n_ct >= 5 && jobs(6, 2) * 4 >= want) PW_GO(6, 2, 2, 4);
+    if (n_ct >= 3 && jobs(4, 2) * 4 >= want) PW_GO(4, 2, 2, 4);
+    if (n_ct >= 2 && jobs(2, 2) * 4 >= want) PW_GO(2, 2, 4, 4);
+    if (jobs(1, 2) * 4 >= want) PW_GO(1, 2, 4, 4);
+    PW_GO(1, 1, 4, 4);
+  }
+  if (jobs(1, 2) >= want) PW_GO(1, 2, 8, 1);
+  PW_GO(1, 1, 8, 1);
+#undef PW_GO
 }
 
 // ------------------------------------------------------------------------------------------------
