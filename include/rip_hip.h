@@ -119,6 +119,13 @@ int rip_goal_likelihood(const float* y_dev, const float* goal_dev, int N, int go
 int rip_score(rip_handle* h, int k_begin, int k_count, const float* z_dev, const float* y_dev,
               const float* goal_dev, int B, int N, int G, float epsilon, float* S_dev, rip_stream_t stream);
 
+/* Ensemble aggregation of a (gathered) score matrix, rip/agent.py:121-127 as coded but per plan:
+ * S_dev [K,B,N] -> loss_dev [B,N] = WCM: min_k(-S), BCM: max_k(-S), MA: mean_k(-S) (NULL to skip) and
+ * best_index_dev [B] int32 = argmin_n loss (NULL to skip).  In the model-parallel layout every rank calls this
+ * on the all-gathered matrix, so no second collective is needed. */
+int rip_aggregate_scores(const float* S_dev, int K, int B, int N, int algorithm, float* loss_dev,
+                         int32_t* best_index_dev, rip_stream_t stream);
+
 /* R5 — the RIPAgent.__call__ plan search (rip/agent.py:78-137) for B
  * observations x N candidate latents, all K loaded models.
  *   z_dev [K,B,64]; goal_dev [B,G,2]; x0_dev [B,N,4,2] (row n=0 zeros = the

@@ -58,6 +58,8 @@ hipError_t launch_select_best(const float* plans, const float* loss_best, int B,
                               hipStream_t s);
 hipError_t launch_dim_select(const float* flow_w_k, const float* z, const float* x0, const float* trace_loss,
                              const float* trace_x, int B, int num_steps, float* y, float* trace_mean, hipStream_t s);
+hipError_t launch_aggregate_scores(const float* S, int K, int B, int N, int algorithm, float* loss, int32_t* best,
+                                   hipStream_t s);
 size_t search_lds_bytes(int K);
 // MFMA-batched variant (16 candidates per wave); needs N % 16 == 0, K <= 4, no traces
 bool search_mfma_supported(const SearchArgs& a);

@@ -729,6 +729,40 @@ __global__ void select_best_kernel(const float* __restrict__ plans, const float*
   if (best != nullptr && lane == 0) best[b] = idx;
 }
 
+// Ensemble aggregation of a gathered score matrix S[K][B][N] (rip/agent.py:121-127 as coded, per plan):
+// loss[b][n] = WCM: min_k(-S) | BCM: max_k(-S) | MA: mean_k(-S); best[b] = argmin_n loss (first on ties).
+// One wave per observation; the arg-min over candidates is a 6-step __shfl_xor butterfly.
+__global__ void aggregate_scores_kernel(const float* __restrict__ S, int K, int B, int N, int algorithm,
+                                        float* __restrict__ loss_out, int32_t* __restrict__ best) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float bv = INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = lane; n < N; n += 64) {
+    float lo = -S[((size_t)0 * B + b) * N + n], acc = lo;
+    for (int k = 1; k < K; ++k) {
+      const float v = -S[((size_t)k * B + b) * N + n];
+      acc += v;
+      lo = algorithm == ALGO_WCM ? fminf(lo, v) : fmaxf(lo, v);
+    }
+    const float l = algorithm == ALGO_MA ? acc / (float)K : lo;
+    if (loss_out != nullptr) loss_out[(size_t)b * N + n] = l;
+    if (l < bv || (l == bv && n < bi)) {
+      bv = l;
+      bi = n;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float ov = __shfl_xor(bv, d, 64);
+    const int oi = __shfl_xor(bi, d, 64);
+    if (ov < bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  if (best != nullptr && lane == 0) best[b] = bi == 0x7fffffff ? 0 : bi;
+}
+
 // ImitativeModel.forward bookkeeping (dim/model.py:124-141): the loss is the batch mean, x_best is the
 // whole post-step x of the first step that reaches the running minimum; then y = F(x_best).
 __global__ __launch_bounds__(64) void dim_select_kernel(const float* __restrict__ blob, const float* __restrict__ z,
@@ -850,6 +884,12 @@ hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
 hipError_t launch_select_best(const float* plans, const float* loss_best, int B, int N, float* plan, int32_t* best,
                               hipStream_t s) {
   hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(64), 0, s, plans, loss_best, N, plan, best);
+  return hipGetLastError();
+}
+
+hipError_t launch_aggregate_scores(const float* S, int K, int B, int N, int algorithm, float* loss, int32_t* best,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(aggregate_scores_kernel, dim3(B), dim3(64), 0, s, S, K, B, N, algorithm, loss, best);
   return hipGetLastError();
 }
 

@@ -232,6 +232,15 @@ int rip_score(rip_handle* h, int k_begin, int k_count, const float* z_dev, const
   return RIP_OK;
 }
 
+int rip_aggregate_scores(const float* S_dev, int K, int B, int N, int algorithm, float* loss_dev,
+                         int32_t* best_index_dev, rip_stream_t stream) {
+  REQUIRE(S_dev != nullptr, "S_dev is NULL");
+  REQUIRE(K >= 1 && B >= 1 && N >= 1, "bad shape K=%d B=%d N=%d", K, B, N);
+  REQUIRE(algorithm == RIP_ALGO_WCM || algorithm == RIP_ALGO_MA || algorithm == RIP_ALGO_BCM, "unknown algorithm %d", algorithm);
+  HIP_TRY(launch_aggregate_scores(S_dev, K, B, N, algorithm, loss_dev, best_index_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
 static int ensure_plans(rip_handle* h, size_t rows) {
   if (rows <= h->plans_cap) return RIP_OK;
   if (h->plans) (void)hipFree(h->plans);

@@ -284,6 +284,50 @@ def test_mfma_kernel_matches_chain_kernel(dev):
         lidar[:1].contiguous(), vec[:1].contiguous(), goal[:1].contiguous())
 
 
+@pytest.mark.parametrize("algo", ["WCM", "MA", "BCM"])
+def test_model_parallel_scoring_layout(dev, algo):
+  """BASELINE config 4 layout on one GPU: two K_local=2 scorers (as two ranks would hold) + concatenation in
+  shard order == one K=4 scorer; aggregation kernel vs numpy; arg-best plan vs the oracle's scores."""
+  from oatomobile_amd import distributed as D
+  from oracle import reference_cpu as O
+  K, N = 4, 96
+  models = [hip_model(400 + k, dev) for k in range(K)]
+  refs = [oracle_model(400 + k) for k in range(K)]
+  obs = [synth_observation(np.random.default_rng(900 + i)) for i in range(2)]
+  lidar = torch.stack([torch.from_numpy(o["lidar"]) for o in obs]).to(dev)
+  vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
+  goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
+  plans = torch.from_numpy(np.cumsum(np.abs(np.random.default_rng(5).normal(size=(2, N, 4, 2))) * 2, axis=2).astype(np.float32)).to(dev)
+  full = D.ModelParallelScorer(models, K, algorithm=algo, max_batch=2, device=dev)
+  S_full = full.local_scores(lidar, vec, goal, plans)
+  halves = []
+  for r in range(2):
+    b, e = D.shard_range(K, r, 2)
+    sc = D.ModelParallelScorer.__new__(D.ModelParallelScorer)  # a rank of a 2-rank job, without a process group
+    from oatomobile_amd import _lib
+    sc._lib, sc._group, sc._algorithm, sc._epsilon, sc._k_total, sc._device = _lib, None, algo, 1.0, K, dev
+    sc._models = models[b:e]
+    sc._handle = _lib.Handle(e - b, 2, 2, 0)
+    for k, m in enumerate(sc._models):
+      sc._handle.load_model(k, m.packed_weights())
+    halves.append(sc.local_scores(lidar, vec, goal, plans))
+  S_cat = torch.cat(halves, 0)
+  np.testing.assert_allclose(S_cat.cpu().numpy(), S_full.cpu().numpy(), rtol=1e-6, atol=1e-5)
+  loss, best = full.aggregate(S_full)
+  Sn = -S_full.cpu().numpy()
+  ref_loss = {"WCM": Sn.min(0), "BCM": Sn.max(0), "MA": Sn.mean(0)}[algo]
+  np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-6, atol=1e-5)
+  np.testing.assert_array_equal(best.cpu().numpy(), ref_loss.argmin(1))
+  plan, best2, _ = full(lidar, vec, goal, plans)
+  np.testing.assert_array_equal(plan.cpu().numpy(), plans.cpu().numpy()[np.arange(2), ref_loss.argmin(1)])
+  # scores against the oracle (observation 0)
+  ob = obs[0]
+  ctx = ctx_tensors([ob], dev)
+  zs = [O.params(m, **{k: v.cpu() for k, v in ctx.items()}) for m in refs]
+  So = O.rip_scores(refs, zs, plans[0].cpu(), torch.from_numpy(ob["goal"][None, :, :2].copy())).numpy()
+  np.testing.assert_allclose(S_full.cpu().numpy()[:, 0], So, rtol=2e-5, atol=2e-3)
+
+
 def test_batched_act_matches_single(dev):
   """plan_batch over B observations == B single calls (observation-parallel replay)."""
   from oatomobile_amd import RIPAgent
