@@ -136,6 +136,8 @@ class RIPAgent(SetPointAgent):
       candidate with the lowest best-loss wins.  N = 1 is the reference algorithm.
     num_steps / lr / epsilon: hard-coded 10 / 0.1 / 1.0 in the reference.
     max_batch: observations per `plan_batch` call.
+    encoder_dtype: "fp32" (parity mode, default) or "bf16" (BASELINE config 3: bf16 activations/weights in the
+      MobileNetV2 encoder with fp32 accumulation; the flow and the search stay fp32).
     search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 1024 (N % 16 == 0, K <= 4), else the
       wave-per-chain kernel; both are the same algorithm.
   """
@@ -143,7 +145,7 @@ class RIPAgent(SetPointAgent):
   def __init__(self, environment: Any = None, *, algorithm: str, models: Sequence[ImitativeModel],
                num_candidates: int = 1, num_steps: int = 10, lr: float = 1e-1, epsilon: float = 1.0, seed: int = 0,
                max_batch: int = 1, device: Optional[torch.device] = None, search_kernel: str = "auto",
-               fused_encoder: Optional[int] = None, **kwargs) -> None:
+               fused_encoder: Optional[int] = None, encoder_dtype: str = "fp32", **kwargs) -> None:
     assert algorithm in ("WCM", "MA", "BCM")  # rip/agent.py:43
     self._algorithm = algorithm
     super().__init__(environment=environment, **kwargs)
@@ -154,6 +156,7 @@ class RIPAgent(SetPointAgent):
     self._in_channels = self._models[0]._in_channels
     self._num_candidates, self._num_steps, self._lr, self._epsilon = int(num_candidates), int(num_steps), float(lr), float(epsilon)
     self._max_batch = int(max_batch)
+    self._enc_dtype = _lib.ENC_DTYPES[encoder_dtype]
     self._handle = _lib.Handle(len(self._models), self._in_channels, self._max_batch,
                                self._device.index if self._device.index is not None else torch.cuda.current_device())
     for k, m in enumerate(self._models):
@@ -185,7 +188,7 @@ class RIPAgent(SetPointAgent):
     lib = _lib.load()
     _lib.check(lib.rip_act(self._handle.raw, _lib.ptr(lidar), 1, _lib.ptr(vec), _lib.ptr(goal), _lib.ptr(self._x0(b)), b,
                            self._num_candidates, goal.shape[1], _lib.ALGORITHMS[self._algorithm], self._num_steps,
-                           self._lr, self._epsilon, 0, _lib.ptr(plan), _lib.ptr(loss), _lib.current_stream()))
+                           self._lr, self._epsilon, self._enc_dtype, _lib.ptr(plan), _lib.ptr(loss), _lib.current_stream()))
     return (plan, loss) if return_loss else plan
 
   def __call__(self, observation: Mapping[str, np.ndarray]) -> np.ndarray:

@@ -58,6 +58,15 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
                           hipStream_t s);
 
+hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last,
+                       const float* vec, int B, float* scratch, float* z, float* feat, hipStream_t s);
+
+// bf16 encoder (encoder_bf16.hip): bf16 NHWC activations, bf16 pointwise weights (enc_wh: same offsets as the fp32
+// blob, 2 bytes per element), fp32 accumulation / bias / ReLU6 / residual math; features.18 is written in fp32.
+hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
+                               const float* visual, const float* vec, int B, float* const bufs[4], float* z,
+                               float* feat, hipStream_t s);
+
 hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                               size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);
 

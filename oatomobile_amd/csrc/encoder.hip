@@ -667,9 +667,16 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, s);
     }
   }
-  // classifier logits go to `feat` if the caller wants them, else to scratch at the end of a free buffer
-  float* feat_buf = feat != nullptr ? feat : bufs[(plan.final_buf + 1) & 3];
-  hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, (const float*)bufs[plan.final_buf],
+  return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], vec, B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
+}
+
+// avg-pool + classifier + merger on the fp32 features.18 output `act_last` [kc][B][HW][1280]
+hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last,
+                       const float* vec, int B, float* scratch, float* z, float* feat, hipStream_t s) {
+  const size_t ms = plan.blob_floats;
+  // classifier logits go to `feat` if the caller wants them, else to scratch
+  float* feat_buf = feat != nullptr ? feat : scratch;
+  hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, act_last,
                      enc_w, ms, k0, plan.cls_w_off, plan.cls_b_off, B, plan.final_hw * plan.final_hw, feat_buf);
   hipLaunchKernelGGL(merger_kernel, dim3(B, kc), dim3(64), 0, s, (const float*)feat_buf, enc_w, ms, k0,
                      plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1], plan.mrg_b_off[1], plan.mrg_w_off[2],

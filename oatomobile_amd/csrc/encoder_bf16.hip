@@ -1,0 +1,553 @@
+// bf16 MobileNetV2 encoder for gfx950 (BASELINE configs[2]: "bf16 encoder + fp32 flow").
+//
+// Activations are bf16 NHWC in HBM (half the bytes of the fp32 path), pointwise weights bf16, everything else
+// (accumulation, bias, ReLU6, residual add, depthwise taps) fp32 in registers.  Pointwise convs run on
+// v_mfma_f32_16x16x32_bf16: one 16-byte load per lane = 8 K-values = one MFMA k-group, so a K chunk of 32 costs one
+// load per operand tile.  Same transposed orientation as the fp32 GEMM (encoder.hip): A = 16 output channels,
+// B = 16 pixels, lane (n, q) ends with 4 consecutive channels of pixel n.  Both operands use the same
+// "lane q <-> K values 8q..8q+7 of the chunk" assignment, so the contraction is independent of the instruction's
+// internal k ordering.  features.18 is written in fp32 for the (fp32) pooling/classifier/merger tail.
+#include "encoder.h"
+
+namespace rip {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ unsigned f2bf(float f) {  // round to nearest even
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+// ---- stem: fp32 NCHW input -> bf16 NHWC [K][B][Ho][Ho][32]; thread = (pixel, 4 output channels) ----
+__global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                         size_t model_stride, int k0, size_t w_off, size_t b_off,
+                                                         int B, int C, int Hin, int Ho, bf16_t* __restrict__ out) {
+  const int k = blockIdx.z;
+  const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const int total = B * Ho * Ho * 4;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int oc8 = idx & 3;
+  const int pix = idx >> 2;
+  const int ox = pix % Ho, oy = (pix / Ho) % Ho, b = pix / (Ho * Ho);
+  float acc[8];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + oc8 * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + oc8 * 8 + 4);
+    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
+    acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  }
+  for (int c = 0; c < C; ++c) {
+    const float* ip = in + ((size_t)b * C + c) * Hin * Hin;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= Hin) continue;
+        const float v = ip[(size_t)iy * Hin + ix];
+        const float* wp = w + ((ky * 3 + kx) * C + c) * 32 + oc8 * 8;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+        acc[0] = fmaf(v, w0.x, acc[0]);
+        acc[1] = fmaf(v, w0.y, acc[1]);
+        acc[2] = fmaf(v, w0.z, acc[2]);
+        acc[3] = fmaf(v, w0.w, acc[3]);
+        acc[4] = fmaf(v, w1.x, acc[4]);
+        acc[5] = fmaf(v, w1.y, acc[5]);
+        acc[6] = fmaf(v, w1.z, acc[6]);
+        acc[7] = fmaf(v, w1.w, acc[7]);
+      }
+    }
+  }
+  uint4 o;
+  o.x = pack2(relu6f(acc[0]), relu6f(acc[1]));
+  o.y = pack2(relu6f(acc[2]), relu6f(acc[3]));
+  o.z = pack2(relu6f(acc[4]), relu6f(acc[5]));
+  o.w = pack2(relu6f(acc[6]), relu6f(acc[7]));
+  *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * 32 + oc8 * 8) = o;
+}
+
+// ---- depthwise 3x3: thread = (output pixel, 8 channels): 16-byte bf16 loads/stores, fp32 taps ----
+__global__ __launch_bounds__(256) void dw_bf16_kernel(const bf16_t* __restrict__ in, const float* __restrict__ wbase,
+                                                       size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
+                                                       int C, int Hin, int Ho, int stride, bf16_t* __restrict__ out) {
+  const int k = blockIdx.z;
+  const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const int C8 = C >> 3;
+  const long total = (long)B * Ho * Ho * C8;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % C8);
+  const long pix = idx / C8;
+  const int ox = (int)(pix % Ho), oy = (int)((pix / Ho) % Ho), b = (int)(pix / ((long)Ho * Ho));
+  const bf16_t* ip = in + ((size_t)k * B + b) * Hin * Hin * C + c8 * 8;
+  float acc[8];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
+    acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  }
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * stride - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * stride - 1 + kx;
+      if (ix < 0 || ix >= Hin) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(ip + ((size_t)iy * Hin + ix) * C);
+      const float4 w0 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c8 * 8);
+      const float4 w1 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c8 * 8 + 4);
+      acc[0] = fmaf(bf2f(v.x & 0xffffu), w0.x, acc[0]);
+      acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
+      acc[2] = fmaf(bf2f(v.y & 0xffffu), w0.z, acc[2]);
+      acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
+      acc[4] = fmaf(bf2f(v.z & 0xffffu), w1.x, acc[4]);
+      acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
+      acc[6] = fmaf(bf2f(v.w & 0xffffu), w1.z, acc[6]);
+      acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+    }
+  }
+  uint4 o;
+  o.x = pack2(relu6f(acc[0]), relu6f(acc[1]));
+  o.y = pack2(relu6f(acc[2]), relu6f(acc[3]));
+  o.z = pack2(relu6f(acc[4]), relu6f(acc[5]));
+  o.w = pack2(relu6f(acc[6]), relu6f(acc[7]));
+  *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * C + c8 * 8) = o;
+}
+
+// ---- pointwise GEMM on v_mfma_f32_16x16x32_bf16 (see encoder.hip pw_kernel for the tiling / KSPLIT scheme) ----
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) {
+  union {
+    uint4 u;
+    bf16x8 v;
+  } c;
+  c.u = u;
+  return c.v;
+}
+
+template <int CT, int PT, int UNROLL, int KSPLIT, bool OUT_F32>
+__global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ whbase,
+                                                       const float* __restrict__ wbase, size_t model_stride, int k0,
+                                                       size_t w_off, size_t b_off, const bf16_t* __restrict__ res,
+                                                       void* __restrict__ out, int M, int Cin, int Cout, int relu6,
+                                                       size_t act_model_stride_in, size_t act_model_stride_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.z;
+  const int ptile0 = (KSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * PT;
+  const int ctile0 = blockIdx.y * CT;
+  if (KSPLIT == 1 && ptile0 * 16 >= M) return;
+  const bf16_t* A = whbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const bf16_t* X = in + (size_t)k * act_model_stride_in;
+  const bf16_t* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
+
+  const bf16_t* arow[CT];
+  bool aval[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + n;
+    aval[ct] = co < Cout;
+    arow[ct] = A + (size_t)min(co, Cout - 1) * Cin + 8 * q;
+  }
+  const bf16_t* brow[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int p = (ptile0 + pt) * 16 + n;
+    brow[pt] = X + (size_t)min(p, M - 1) * Cin + 8 * q;
+  }
+  f32x4 acc[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kchunks = (Cin + 31) / 32;
+  const int kper = (kchunks + KSPLIT - 1) / KSPLIT;
+  const int kbeg = KSPLIT == 1 ? 0 : 32 * kper * wave;
+  const int kend = KSPLIT == 1 ? Cin : min(Cin, 32 * kper * (wave + 1));
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+  for (int kc0 = kbeg; kc0 < kend; kc0 += 32 * UNROLL) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int kc = kc0 + 32 * u;
+      const bool kval = kc + 8 * q < kend;  // Cin is a multiple of 8: a lane's 8 values are all-valid or all-pad
+      uint4 av[CT], bv[PT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        av[ct] = (kval && aval[ct]) ? *reinterpret_cast<const uint4*>(arow[ct] + kc) : zero;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) bv[pt] = kval ? *reinterpret_cast<const uint4*>(brow[pt] + kc) : zero;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[ct]), as_bf16x8(bv[pt]), acc[ct][pt], 0, 0, 0);
+    }
+  }
+  if (KSPLIT > 1) {
+    __shared__ float4 part[KSPLIT][CT * PT][64];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        part[wave][ct * PT + pt][lane] = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int t = ct * PT + pt;
+        if ((t & (KSPLIT - 1)) == wave) {
+          float4 sum = part[0][t][lane];
+#pragma unroll
+          for (int w2 = 1; w2 < KSPLIT; ++w2) {
+            const float4 o = part[w2][t][lane];
+            sum.x += o.x;
+            sum.y += o.y;
+            sum.z += o.z;
+            sum.w += o.w;
+          }
+          acc[ct][pt] = f32x4{sum.x, sum.y, sum.z, sum.w};
+        }
+      }
+  }
+  if (KSPLIT == 1 && !OUT_F32) {
+    // bf16 epilogue through LDS: a lane's MFMA result is 4 channels (8 bytes) of one pixel; writing that straight
+    // out gives 32-byte pieces per pixel and tile.  Park the wave's [PT*16 pixels][CT*16 channels] tile in LDS and
+    // write it back as 16-byte chunks in NHWC order (full rows when CT covers Cout).
+    constexpr int ROWB = CT * 32 + 16;  // bytes per pixel row in LDS (+16: spread the 64 lanes' b64 writes over banks)
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][PT * 16 * ROWB];
+    unsigned char* st = stage[wave];
+    bf16_t* O = reinterpret_cast<bf16_t*>(out) + (size_t)k * act_model_stride_out;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = (ctile0 + ct) * 16 + 4 * q;
+      const bool cval = co < Cout;
+      const float4 bb = cval ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = (ptile0 + pt) * 16 + n;
+        float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
+                               acc[ct][pt][3] + bb.w);
+        if (R != nullptr && cval && p < M) {
+          const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+          v.x += bf2f(r.x & 0xffffu);
+          v.y += bf2f(r.x >> 16);
+          v.z += bf2f(r.y & 0xffffu);
+          v.w += bf2f(r.y >> 16);
+        }
+        if (relu6) {
+          v.x = relu6f(v.x);
+          v.y = relu6f(v.y);
+          v.z = relu6f(v.z);
+          v.w = relu6f(v.w);
+        }
+        uint2 o;
+        o.x = pack2(v.x, v.y);
+        o.y = pack2(v.z, v.w);
+        *reinterpret_cast<uint2*>(st + (pt * 16 + n) * ROWB + ct * 32 + q * 8) = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CHUNKS_PER_ROW = CT * 2;  // 16-byte chunks (8 channels) per pixel row
+    constexpr int CHUNKS = PT * 16 * CHUNKS_PER_ROW;
+#pragma unroll
+    for (int j = 0; j < (CHUNKS + 63) / 64; ++j) {
+      const int c = lane + 64 * j;
+      if (c < CHUNKS) {
+        const int row = c / CHUNKS_PER_ROW, col = c - row * CHUNKS_PER_ROW;
+        const int p = ptile0 * 16 + row, co = ctile0 * 16 + col * 8;
+        if (p < M && co < Cout)
+          *reinterpret_cast<uint4*>(O + (size_t)p * Cout + co) = *reinterpret_cast<const uint4*>(st + row * ROWB + col * 16);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + 4 * q;
+    if (co < Cout) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = (ptile0 + pt) * 16 + n;
+        if (p < M && (KSPLIT == 1 || ((ct * PT + pt) & (KSPLIT - 1)) == wave)) {
+          float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
+                                 acc[ct][pt][3] + bb.w);
+          if (R != nullptr) {
+            const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+            v.x += bf2f(r.x & 0xffffu);
+            v.y += bf2f(r.x >> 16);
+            v.z += bf2f(r.y & 0xffffu);
+            v.w += bf2f(r.y >> 16);
+          }
+          if (relu6) {
+            v.x = relu6f(v.x);
+            v.y = relu6f(v.y);
+            v.z = relu6f(v.z);
+            v.w = relu6f(v.w);
+          }
+          if (OUT_F32) {
+            float* O = reinterpret_cast<float*>(out) + (size_t)k * act_model_stride_out;
+            *reinterpret_cast<float4*>(O + (size_t)p * Cout + co) = v;
+          } else {
+            bf16_t* O = reinterpret_cast<bf16_t*>(out) + (size_t)k * act_model_stride_out;
+            uint2 o;
+            o.x = pack2(v.x, v.y);
+            o.y = pack2(v.z, v.w);
+            *reinterpret_cast<uint2*>(O + (size_t)p * Cout + co) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- LDS-tiled block GEMM for the compute-heavy layers (13x13 / 7x7 / 4x4 stages with many observations) ----
+// Block tile: 128 pixels x (32*WN) channels, K steps of 32, double-buffered LDS.  Each operand row is read from
+// L2 once per block instead of once per wave tile (the register-direct kernel above re-reads operands ~60x on these
+// shapes and is L2-bandwidth bound).  4 waves as 2 (pixels) x 2 (channels); wave tile 64 px x 16*WN ch.
+template <int WN, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ in,
+                                                         const bf16_t* __restrict__ whbase,
+                                                         const float* __restrict__ wbase, size_t model_stride, int k0,
+                                                         size_t w_off, size_t b_off, const bf16_t* __restrict__ res,
+                                                         void* __restrict__ out, int M, int Cin, int Cout, int relu6,
+                                                         size_t act_model_stride_in, size_t act_model_stride_out) {
+  constexpr int BM = 128, BN = 32 * WN, LD = 40;  // LD: bf16 elements per LDS row (32 + 8 pad -> 80 B rows)
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BN + BM) * LD];
+  bf16_t* As[2] = {lds, lds + (BN + BM) * LD};
+  bf16_t* Bs[2] = {lds + BN * LD, lds + (BN + BM) * LD + BN * LD};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int wp = wave >> 1, wc = wave & 1;
+  const int k = blockIdx.z;
+  const int p0 = blockIdx.x * BM, c0 = blockIdx.y * BN;
+  const bf16_t* A = whbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const bf16_t* X = in + (size_t)k * act_model_stride_in;
+  const bf16_t* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
+
+  // global -> register staging: 16-byte chunks; chunk e of a tile = (row e / 4, 8 K-values (e % 4) * 8)
+  constexpr int A_CH = BN * 4 / 256, B_CH = BM * 4 / 256;  // chunks per thread
+  uint4 areg[A_CH], breg[B_CH];
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int e = tid + 256 * i, row = e >> 2, kk = kt * 32 + (e & 3) * 8;
+      const int co = c0 + row;
+      areg[i] = (co < Cout && kk < Cin) ? *reinterpret_cast<const uint4*>(A + (size_t)co * Cin + kk) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int e = tid + 256 * i, row = e >> 2, kk = kt * 32 + (e & 3) * 8;
+      const int p = p0 + row;
+      breg[i] = (p < M && kk < Cin) ? *reinterpret_cast<const uint4*>(X + (size_t)p * Cin + kk) : zero;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<uint4*>(As[buf] + (e >> 2) * LD + (e & 3) * 8) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<uint4*>(Bs[buf] + (e >> 2) * LD + (e & 3) * 8) = breg[i];
+    }
+  };
+
+  f32x4 acc[WN][4];
+#pragma unroll
+  for (int i = 0; i < WN; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (Cin + 31) / 32;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);  // in flight under this step's MFMAs
+    uint4 af[WN], bf[4];
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+      af[i] = *reinterpret_cast<const uint4*>(As[buf] + (wc * 16 * WN + 16 * i + n) * LD + 8 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bf[j] = *reinterpret_cast<const uint4*>(Bs[buf] + (wp * 64 + 16 * j + n) * LD + 8 * q);
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(af[i]), as_bf16x8(bf[j]), acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) store_tiles(buf ^ 1);  // the other buffer was last read before the previous barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (+ residual) (+ ReLU6); lane (n, q) holds channels 4q..4q+3 of tile i for pixel n of tile j
+  if (OUT_F32) {
+    float* O = reinterpret_cast<float*>(out) + (size_t)k * act_model_stride_out;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int co = c0 + wc * 16 * WN + 16 * i + 4 * q;
+      if (co < Cout) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = p0 + wp * 64 + 16 * j + n;
+          if (p < M) {
+            float4 v = make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
+            if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+            *reinterpret_cast<float4*>(O + (size_t)p * Cout + co) = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // bf16: stage the wave's [64 px][16*WN ch] tile in (now free) LDS, write back as 16-byte NHWC chunks
+  constexpr int ROWB = WN * 32 + 16;
+  unsigned char* st = reinterpret_cast<unsigned char*>(lds) + wave * 64 * ROWB;
+  static_assert(4 * 64 * ROWB <= (int)sizeof(lds), "staging must fit the operand buffers");
+  bf16_t* O = reinterpret_cast<bf16_t*>(out) + (size_t)k * act_model_stride_out;
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    const int co = c0 + wc * 16 * WN + 16 * i + 4 * q;
+    const bool cval = co < Cout;
+    const float4 bb = cval ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = p0 + wp * 64 + 16 * j + n;
+      float4 v = make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
+      if (R != nullptr && cval && p < M) {
+        const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+        v.x += bf2f(r.x & 0xffffu);
+        v.y += bf2f(r.x >> 16);
+        v.z += bf2f(r.y & 0xffffu);
+        v.w += bf2f(r.y >> 16);
+      }
+      if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+      uint2 o;
+      o.x = pack2(v.x, v.y);
+      o.y = pack2(v.z, v.w);
+      *reinterpret_cast<uint2*>(st + (16 * j + n) * ROWB + i * 32 + q * 8) = o;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  constexpr int CPR = WN * 2;  // 16-byte chunks per pixel row
+#pragma unroll
+  for (int jj = 0; jj < CPR; ++jj) {  // 64 rows * CPR chunks = 64 * CPR -> CPR per lane
+    const int c = lane + 64 * jj;
+    const int row = c / CPR, col = c - row * CPR;
+    const int p = p0 + wp * 64 + row, co = c0 + wc * 16 * WN + col * 8;
+    if (p < M && co < Cout)
+      *reinterpret_cast<uint4*>(O + (size_t)p * Cout + co) = *reinterpret_cast<const uint4*>(st + row * ROWB + col * 16);
+  }
+}
+
+template <int WN>
+void launch_gemm(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc, const Layer& l,
+                 const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
+  const dim3 grid((M + 127) / 128, (l.cout + 32 * WN - 1) / (32 * WN), kc);
+  if (out_f32)
+    hipLaunchKernelGGL((gemm_bf16_kernel<WN, true>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off, l.b_off,
+                       res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<WN, false>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off,
+                       l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+}
+
+template <int CT, int PT, int UNROLL, int KSPLIT>
+void launch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc, const Layer& l,
+                const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
+  const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
+  const int groups = (n_pt + PT - 1) / PT;
+  const dim3 grid(KSPLIT == 1 ? (groups + 3) / 4 : groups, (n_ct + CT - 1) / CT, kc);
+  if (out_f32)
+    hipLaunchKernelGGL((pw_bf16_kernel<CT, PT, UNROLL, KSPLIT, true>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0,
+                       l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+  else
+    hipLaunchKernelGGL((pw_bf16_kernel<CT, PT, UNROLL, KSPLIT, false>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms,
+                       k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin,
+                       (size_t)M * l.cout);
+}
+
+void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc,
+                  const Layer& l, const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
+  const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
+  auto jobs = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
+  // occupancy first: these GEMMs are load-latency bound, so ask for >= 4 waves per SIMD; when one wave per tile
+  // cannot deliver that and K is long enough, the block's 4 waves split K (4x the waves for the same tile).
+  const long want = 1024;
+  const bool ks = l.cin >= 128;
+#define PWB_GO(CT_, PT_, U_, KS_) \
+  return launch_pwb<CT_, PT_, U_, KS_>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, s)
+  if (n_ct >= 5) {
+    if (jobs(6, 2) >= want) PWB_GO(6, 2, 2, 1);
+    if (ks && jobs(6, 2) * 4 >= want) PWB_GO(6, 2, 2, 4);
+  }
+  if (n_ct >= 3) {
+    if (jobs(4, 2) >= want) PWB_GO(4, 2, 2, 1);
+    if (ks && jobs(4, 2) * 4 >= want) PWB_GO(4, 2, 2, 4);
+  }
+  if (n_ct >= 2) {
+    if (jobs(2, 2) >= want) PWB_GO(2, 2, 4, 1);
+    if (ks && jobs(2, 2) * 4 >= want) PWB_GO(2, 2, 4, 4);
+  }
+  if (jobs(1, 2) >= want) PWB_GO(1, 2, 8, 1);
+  if (ks && jobs(1, 2) * 4 >= want) PWB_GO(1, 2, 4, 4);
+  if (ks) PWB_GO(1, 1, 4, 4);
+  PWB_GO(1, 1, 8, 1);
+#undef PWB_GO
+}
+
+}  // namespace
+
+hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
+                               const float* visual, const float* vec, int B, float* const bufs[4], float* z,
+                               float* feat, hipStream_t s) {
+  const size_t ms = plan.blob_floats;
+  for (size_t li = 0; li < plan.layers.size(); ++li) {
+    const Layer& l = plan.layers[li];
+    bf16_t* dst = reinterpret_cast<bf16_t*>(bufs[l.dst]);
+    if (l.kind == L_STEM) {
+      const int total = B * l.h_out * l.h_out * 4;
+      hipLaunchKernelGGL(stem_bf16_kernel, dim3((total + 255) / 256, 1, kc), dim3(256), 0, s, visual, enc_w, ms, k0,
+                         l.w_off, l.b_off, B, l.cin, l.h_in, l.h_out, dst);
+    } else if (l.kind == L_DW) {
+      const long total = (long)B * l.h_out * l.h_out * (l.cout / 8);
+      hipLaunchKernelGGL(dw_bf16_kernel, dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), 0, s,
+                         reinterpret_cast<const bf16_t*>(bufs[l.src]), enc_w, ms, k0, l.w_off, l.b_off, B, l.cout,
+                         l.h_in, l.h_out, l.stride, dst);
+    } else {
+      const int M = B * l.h_out * l.h_out;
+      const bool last = li + 1 == plan.layers.size();  // features.18 feeds the fp32 tail
+      const bf16_t* res = l.residual ? reinterpret_cast<const bf16_t*>(bufs[l.res]) : nullptr;
+      dispatch_pwb(reinterpret_cast<const bf16_t*>(bufs[l.src]), enc_wh, enc_w, ms, k0, kc, l, res,
+                   reinterpret_cast<void*>(bufs[l.dst]), M, last, s);
+    }
+  }
+  return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], vec, B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
+}
+
+}  // namespace rip

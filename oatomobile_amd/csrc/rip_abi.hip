@@ -22,6 +22,7 @@ struct rip_handle {
   int K = 0, C = 0, max_batch = 0, device = 0;
   EncoderPlan plan;
   float* enc_w = nullptr;   // [K][plan.blob_floats]
+  unsigned short* enc_wh = nullptr;  // [K][plan.blob_floats] bf16 copy of the folded blob (bf16 encoder)
   float* flow_w = nullptr;  // [K][FW_SIZE]
   float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the MFMA search kernel
   void* tape = nullptr;     // scratch of the MFMA search kernel
@@ -101,6 +102,11 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int devi
     }                                                                             \
   } while (0)
   ALLOC(h->enc_w, (size_t)K * h->plan.blob_floats);
+  {
+    float* tmp = nullptr;
+    ALLOC(tmp, ((size_t)K * h->plan.blob_floats + 1) / 2);
+    h->enc_wh = reinterpret_cast<unsigned short*>(tmp);
+  }
   ALLOC(h->flow_w, (size_t)K * FW_SIZE);
   ALLOC(h->mfma_w, (size_t)K * MW_SIZE);
   for (int i = 0; i < 4; ++i) ALLOC(h->bufs[i], h->buf_floats);
@@ -115,7 +121,7 @@ int rip_destroy(rip_handle* h) {
   if (h == nullptr) return RIP_OK;
   (void)hipSetDevice(h->device);
   if (h->tape != nullptr) (void)hipFree(h->tape);
-  float* ptrs[] = {h->enc_w, h->flow_w, h->mfma_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
@@ -151,6 +157,15 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
   if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpy(h->enc_w + (size_t)k * h->plan.blob_floats, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice));
+  {
+    std::vector<unsigned short> wh(enc.size());
+    for (size_t i = 0; i < enc.size(); ++i) {  // round to nearest even
+      unsigned u;
+      std::memcpy(&u, &enc[i], 4);
+      wh[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    HIP_TRY(hipMemcpy(h->enc_wh + (size_t)k * h->plan.blob_floats, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
   h->loaded[k] = true;
@@ -171,7 +186,12 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   if (rc != RIP_OK) return rc;
   REQUIRE(visual_dev != nullptr && vec_dev != nullptr && z_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
-  REQUIRE(enc_dtype == RIP_ENC_FP32, "encoder dtype %d not supported yet (fp32 only)", enc_dtype);
+  REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
+  if (enc_dtype == RIP_ENC_BF16) {
+    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
+                                feat_dev, (hipStream_t)stream));
+    return RIP_OK;
+  }
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
                          h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream));
   return RIP_OK;

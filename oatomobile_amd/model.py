@@ -250,7 +250,8 @@ class ImitativeModel(nn.Module):
     ], dim=-1).contiguous()  # dim/model.py:206-214 (the cat is 5 floats per row: plumbing)
     z = torch.empty(b, arch.HIDDEN_SIZE, device=vis.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.rip_encode(self._handle().raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, 1, 0, _lib.ptr(z), None,
+    _lib.check(lib.rip_encode(self._handle().raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, 1,
+                              _lib.ENC_DTYPES[getattr(self, "encoder_dtype", "fp32")], _lib.ptr(z), None,
                               _lib.current_stream()))
     return z
 

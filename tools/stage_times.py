@@ -14,6 +14,7 @@ def main():
   ap.add_argument("--models", type=int, default=4)
   ap.add_argument("--candidates", type=int, default=128)
   ap.add_argument("--algorithm", default="WCM")
+  ap.add_argument("--enc", default="fp32")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
   dev = torch.device("cuda", 0)
@@ -29,7 +30,7 @@ def main():
   def run(e=None):
     s = _lib.current_stream()
     if e: e[0].record(st)
-    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, _lib.ptr(vec), B, 0, K, 0, _lib.ptr(z), s))
+    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, _lib.ptr(vec), B, 0, K, _lib.ENC_DTYPES[args.enc], _lib.ptr(z), s))
     if e: e[1].record(st)
     _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x0), B, N, goal.shape[1], _lib.ALGORITHMS[args.algorithm],
                               10, 0.1, 1.0, _lib.ptr(plan), None, _lib.ptr(loss), None, None, None, s))
