@@ -111,7 +111,9 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=5)
-  ap.add_argument("--obs-batch", type=int, default=64, help="observations (= act() calls) per step per GPU")
+  ap.add_argument("--obs-batch", type=int, default=256, help="observations (= act() calls) per step per GPU")
+  ap.add_argument("--encoder-dtype", default="bf16", choices=["bf16", "fp32"],
+                  help="MobileNetV2 encoder arithmetic; BASELINE configs[2] names bf16 encoder + fp32 flow")
   ap.add_argument("--models", type=int, default=4)
   ap.add_argument("--candidates", type=int, default=128)
   ap.add_argument("--channels", type=int, default=2, help="BEV channels (reference sensor: 2; BASELINE.json text: 4)")
@@ -149,8 +151,9 @@ def main():
   seeds = [100 + k for k in range(K)]
   models = [ImitativeModel.synthetic(s, in_channels=C, max_batch=1) for s in seeds]
   agent = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, num_steps=args.search_steps,
-                   max_batch=B, seed=0, device=dev)
+                   max_batch=B, seed=0, device=dev, encoder_dtype=args.encoder_dtype)
   lib = _lib.load()
+  enc_dtype = _lib.ENC_DTYPES[args.encoder_dtype]
   h = agent._handle.raw
 
   # distinct observation batches per rank and per step parity (resident in HBM before timing)
@@ -173,7 +176,7 @@ def main():
     s = _lib.current_stream()
     if ev is not None:
       ev[0].record(stream)
-    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, _lib.ptr(vec), B, 0, K, 0, _lib.ptr(z), s))
+    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, _lib.ptr(vec), B, 0, K, enc_dtype, _lib.ptr(z), s))
     if ev is not None:
       ev[1].record(stream)
     _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x0), B, N, G, algo, args.search_steps, 0.1, 1.0,
@@ -209,7 +212,7 @@ def main():
   online = None
   if rank == 0 and args.online_calls > 0:
     a1 = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, num_steps=args.search_steps,
-                  max_batch=1, seed=0, device=dev)
+                  max_batch=1, seed=0, device=dev, encoder_dtype=args.encoder_dtype)
     l1, v1, g1 = (t[:1].contiguous() for t in batches[0])
     for _ in range(10):
       a1.plan_batch(l1, v1, g1).cpu()
@@ -233,7 +236,8 @@ def main():
     mfma_per_block_step = K * (3 * 251 + (2 * 274 + 82))
     exec_flops = blocks16 * args.search_steps * mfma_per_block_step * 2048.0
     use_mfma = (B * N >= 1024 and N % 16 == 0 and K <= 4)
-    enc_bytes = B * (200 * 200 * C * 4 + 100 * 100 * C * 4) + K * (B * (ENC_ACT_ELEMS + 10000 * (C - 2)) * 4 + ENC_WEIGHT_ELEMS * 4)
+    sb = 2 if args.encoder_dtype == "bf16" else 4  # bytes per encoder element (SURVEY §8d `s`)
+    enc_bytes = B * (200 * 200 * C * 4 + 100 * 100 * C * 4) + K * (B * (ENC_ACT_ELEMS + 10000 * (C - 2)) * sb + ENC_WEIGHT_ELEMS * sb)
     roof = {
         "kernel": ("search_mfma2_kernel<%d> (pipelined MFMA plan search: F_0 + %d inverses + adjoints + Adam, %d steps in one launch)"
                    % (min(K, 4), K - 1, args.search_steps)) if use_mfma else
@@ -243,7 +247,10 @@ def main():
         "peak": PEAK_FP32_TFLOPS,
         "unit": "TFLOP/s",
         "frac": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-        "traffic": None,
+        # HBM-side bytes per launch: the adjoint tape (K passes x 3 steps x 22 KiB written per 16-candidate block and
+        # Adam step, read back once); measured with rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE in
+        # separate passes: 1.36 GB + 1.43 GB at obs_batch 64 (profiles/r1/search_mfma2_pmc_{fetch,write}_v2.csv)
+        "traffic": (2.0 * blocks16 * args.search_steps * K * 3 * 22 * 1024) if use_mfma else None,
         "ms_per_launch": search_ms,
         "executed_tflops": (exec_flops / (search_ms * 1e-3) / 1e12) if use_mfma else None,
         "executed_frac": (exec_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if use_mfma else None,
@@ -254,7 +261,7 @@ def main():
                 "HBM traffic of this kernel is negligible (weights 132 KiB/model from L2, tape in L2-resident scratch).",
         "encoder": {"ms_per_step": enc_ms, "algorithmic_GBps": enc_bytes / (enc_ms * 1e-3) / 1e9,
                     "frac_hbm": enc_bytes / (enc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                    "note": "transform + stem + 17 depthwise + 34 pointwise(MFMA) + pool/classifier + merger launches, fp32; "
+                    "note": "transform + stem + 17 depthwise + 34 pointwise(MFMA) + pool/classifier + merger launches, %s; " % args.encoder_dtype +
                             "layer-wise compulsory bytes (SURVEY §8d bytes_pre+bytes_enc) / encoder time vs 8 TB/s"},
     }
     out = {
@@ -268,10 +275,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16 encoder (bf16 MFMA, fp32 accumulate) + f32 flow/search" if args.encoder_dtype == "bf16" else "f32",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV, "
-                               "fp32 encoder + fp32 flow" % (K, args.algorithm, N, args.search_steps, C),
+                               "%s encoder + fp32 flow" % (K, args.algorithm, N, args.search_steps, C, args.encoder_dtype),
                    "obs_per_step_per_gpu": B, "models": K, "candidates": N, "bev_channels": C,
                    "parallelism": "observation-parallel replicas x%d (no data-path collective)" % world},
         "roofline": roof,

@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                                                          size_t act_model_stride_in, size_t act_model_stride_out) {
   constexpr int BM = 128, BN = 32 * WN, LD = 40;  // LD: bf16 elements per LDS row (32 + 8 pad -> 80 B rows)
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BN + BM) * LD];
-  bf16_t* As[2] = {lds, lds + (BN + BM) * LD};
-  bf16_t* Bs[2] = {lds + BN * LD, lds + (BN + BM) * LD + BN * LD};
+  auto As = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD; };
+  auto Bs = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD + BN * LD; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int wp = wave >> 1, wc = wave & 1;
@@ -365,12 +365,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int e = tid + 256 * i;
-      *reinterpret_cast<uint4*>(As[buf] + (e >> 2) * LD + (e & 3) * 8) = areg[i];
+      *reinterpret_cast<uint4*>(As(buf) + (e >> 2) * LD + (e & 3) * 8) = areg[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int e = tid + 256 * i;
-      *reinterpret_cast<uint4*>(Bs[buf] + (e >> 2) * LD + (e & 3) * 8) = breg[i];
+      *reinterpret_cast<uint4*>(Bs(buf) + (e >> 2) * LD + (e & 3) * 8) = breg[i];
     }
   };
 
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     uint4 af[WN], bf[4];
 #pragma unroll
     for (int i = 0; i < WN; ++i)
-      af[i] = *reinterpret_cast<const uint4*>(As[buf] + (wc * 16 * WN + 16 * i + n) * LD + 8 * q);
+      af[i] = *reinterpret_cast<const uint4*>(As(buf) + (wc * 16 * WN + 16 * i + n) * LD + 8 * q);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      bf[j] = *reinterpret_cast<const uint4*>(Bs[buf] + (wp * 64 + 16 * j + n) * LD + 8 * q);
+      bf[j] = *reinterpret_cast<const uint4*>(Bs(buf) + (wp * 64 + 16 * j + n) * LD + 8 * q);
 #pragma unroll
     for (int i = 0; i < WN; ++i)
 #pragma unroll
@@ -496,6 +496,12 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
                   const Layer& l, const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
   const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   auto jobs = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
+  // compute-heavy shapes (K >= 64 and enough 128-pixel tiles to fill the chip): LDS-tiled block GEMM
+  if (l.cin >= 64 && M >= 1024) {
+    const long blocks128 = (long)((M + 127) / 128) * ((l.cout + 127) / 128) * kc;
+    if (l.cout > 64 && blocks128 >= 192) return launch_gemm<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, s);
+    return launch_gemm<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, s);
+  }
   // occupancy first: these GEMMs are load-latency bound, so ask for >= 4 waves per SIMD; when one wave per tile
   // cannot deliver that and K is long enough, the block's 4 waves split K (4x the waves for the same tile).
   const long want = 1024;
