@@ -362,6 +362,29 @@ def test_batched_act_matches_single(dev):
     np.testing.assert_allclose(plans[i], single, atol=1e-6)
 
 
+def test_replay_cached_observations(dev, tmp_path):
+  """BASELINE config 5 in miniature: .npz episode -> batched replay == per-observation __call__."""
+  from oatomobile_amd import RIPAgent, replay
+  from oatomobile_amd.agents import interpolate_plan
+  models = [hip_model(300 + k, dev) for k in range(2)]
+  agent = RIPAgent(None, algorithm="MA", models=models, num_candidates=4, max_batch=4)
+  rng = np.random.default_rng(3)
+  ep = replay.Episode(str(tmp_path), "ep")
+  obs = []
+  for i in range(6):
+    o = synth_observation(np.random.default_rng(800 + i))
+    fut = np.cumsum(np.abs(rng.normal(size=(80, 3))), axis=0).astype(np.float32)
+    ep.append("t%d" % i, lidar=o["lidar"], velocity=o["velocity"], is_at_traffic_light=o["is_at_traffic_light"],
+              traffic_light_state=o["traffic_light_state"], player_future=fut)
+    obs.append((o, fut))
+  plans = replay.replay(agent, ep.files(), batch_size=4)
+  assert plans.shape == (6, 4, 2)
+  for i, (o, fut) in enumerate(obs):
+    single = dict(o)
+    single["goal"] = np.c_[replay.goal_from_future(fut), np.zeros((10, 1), np.float32)]
+    np.testing.assert_allclose(interpolate_plan(plans[i]), agent(single), atol=1e-5)
+
+
 def test_four_channel_bev(dev):
   """BASELINE.json quotes a 200x200x4 BEV; the reference sensor has 2 channels.  C=4 parity vs the oracle."""
   from oracle import reference_cpu as O

@@ -139,3 +139,27 @@ def test_encoder_plan_matches_arch_tables():
   assert len(blocks) == 17 and blocks[-1].h_out == 4 and blocks[-1].oup == 320
   assert [b.index for b in blocks if b.residual] == [3, 5, 6, 8, 9, 10, 12, 13, 15, 16]
   assert arch.packed_numel(2) + 52 == sum(int(np.prod(s)) if s else 1 for _, s in arch.state_dict_spec(2))
+
+
+def test_replay_datum_and_episode_format(tmp_path):
+  """N1: the reference's on-disk layout (core/dataset.py:32-109) and `load_datum` semantics (datasets/carla.py:107-164)."""
+  from oatomobile_amd import replay
+  rng = np.random.default_rng(0)
+  ep = replay.Episode(str(tmp_path), "episode0")
+  frames = []
+  for i in range(3):
+    fr = dict(lidar=rng.random((200, 200, 2)), velocity=rng.normal(size=3), is_at_traffic_light=np.int64(i % 2),
+              traffic_light_state=np.int64(i), player_future=np.cumsum(np.abs(rng.normal(size=(80, 3))), axis=0))
+    frames.append(fr)
+    ep.append("tok%d" % i, **fr)
+  assert ep.fetch() == ["tok0", "tok1", "tok2"]
+  d = replay.load_datum(ep.files()[1], mode=True)
+  assert d["lidar"].dtype == np.float32 and d["lidar"].shape == (200, 200, 2)
+  assert d["is_at_traffic_light"].shape == (1,) and d["is_at_traffic_light"][0] == 1.0
+  np.testing.assert_allclose(d["velocity"], frames[1]["velocity"].astype(np.float32))
+  assert d["mode"].shape == (1,) and d["name"].endswith("tok1.npz")
+  chw = replay.load_datum(ep.files()[0], modalities=("lidar",), dataformat="CHW")
+  assert chw["lidar"].shape == (2, 200, 200)
+  g = replay.goal_from_future(frames[0]["player_future"])
+  np.testing.assert_allclose(g, frames[0]["player_future"][7::8][:10, :2].astype(np.float32))
+  assert replay.goal_from_future(frames[0]["player_future"][:20]).shape == (10, 2)  # padded
