@@ -77,55 +77,82 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
   *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * 32 + oc8 * 8) = o;
 }
 
-// ---- depthwise 3x3: thread = (output pixel, 8 channels): 16-byte bf16 loads/stores, fp32 taps ----
+// ---- depthwise 3x3: thread = (run of R output pixels along x, 8 channels).  Sliding window: every input column of
+// the 3-row band is loaded once (16 bytes) and feeds all outputs of the run that tap it; the 9x8 fp32 tap weights are
+// loaded once per thread.  ~9 load instructions per 16-byte output instead of 27 (the kernel is TA-issue bound).
+template <int STRIDE, int R>
 __global__ __launch_bounds__(256) void dw_bf16_kernel(const bf16_t* __restrict__ in, const float* __restrict__ wbase,
                                                        size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
-                                                       int C, int Hin, int Ho, int stride, bf16_t* __restrict__ out) {
+                                                       int C, int Hin, int Ho, bf16_t* __restrict__ out) {
   const int k = blockIdx.z;
   const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
   const int C8 = C >> 3;
-  const long total = (long)B * Ho * Ho * C8;
+  const int runs = (Ho + R - 1) / R;
+  const long total = (long)B * Ho * runs * C8;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int c8 = (int)(idx % C8);
-  const long pix = idx / C8;
-  const int ox = (int)(pix % Ho), oy = (int)((pix / Ho) % Ho), b = (int)(pix / ((long)Ho * Ho));
+  long rest = idx / C8;
+  const int run = (int)(rest % runs);
+  rest /= runs;
+  const int oy = (int)(rest % Ho), b = (int)(rest / Ho);
+  const int ox0 = run * R;
   const bf16_t* ip = in + ((size_t)k * B + b) * Hin * Hin * C + c8 * 8;
-  float acc[8];
+  float wt[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float4 w0 = *reinterpret_cast<const float4*>(w + t * C + c8 * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + t * C + c8 * 8 + 4);
+    wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+    wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+  }
+  float acc[R][8];
   {
     const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
     const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
-    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
-    acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
-  }
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy * stride - 1 + ky;
-    if (iy < 0 || iy >= Hin) continue;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox * stride - 1 + kx;
-      if (ix < 0 || ix >= Hin) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(ip + ((size_t)iy * Hin + ix) * C);
-      const float4 w0 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c8 * 8);
-      const float4 w1 = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c8 * 8 + 4);
-      acc[0] = fmaf(bf2f(v.x & 0xffffu), w0.x, acc[0]);
-      acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
-      acc[2] = fmaf(bf2f(v.y & 0xffffu), w0.z, acc[2]);
-      acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
-      acc[4] = fmaf(bf2f(v.z & 0xffffu), w1.x, acc[4]);
-      acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
-      acc[6] = fmaf(bf2f(v.w & 0xffffu), w1.z, acc[6]);
-      acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+    for (int r = 0; r < R; ++r) {
+      acc[r][0] = b0.x; acc[r][1] = b0.y; acc[r][2] = b0.z; acc[r][3] = b0.w;
+      acc[r][4] = b1.x; acc[r][5] = b1.y; acc[r][6] = b1.z; acc[r][7] = b1.w;
     }
   }
-  uint4 o;
-  o.x = pack2(relu6f(acc[0]), relu6f(acc[1]));
-  o.y = pack2(relu6f(acc[2]), relu6f(acc[3]));
-  o.z = pack2(relu6f(acc[4]), relu6f(acc[5]));
-  o.w = pack2(relu6f(acc[6]), relu6f(acc[7]));
-  *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * C + c8 * 8) = o;
+  constexpr int COLS = (R - 1) * STRIDE + 3;  // input columns the run touches
+  const int ix0 = ox0 * STRIDE - 1;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * STRIDE - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+    const bf16_t* rowp = ip + (size_t)iy * Hin * C;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      const int ix = ix0 + j;
+      if (ix < 0 || ix >= Hin) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(rowp + (size_t)ix * C);
+      const float f[8] = {bf2f(v.x & 0xffffu), bf2f(v.x >> 16), bf2f(v.y & 0xffffu), bf2f(v.y >> 16),
+                          bf2f(v.z & 0xffffu), bf2f(v.z >> 16), bf2f(v.w & 0xffffu), bf2f(v.w >> 16)};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int kx = j - r * STRIDE;  // compile-time after unrolling
+        if (kx >= 0 && kx < 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r][e] = fmaf(f[e], wt[ky * 3 + kx][e], acc[r][e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int ox = ox0 + r;
+    if (ox < Ho) {
+      uint4 o;
+      o.x = pack2(relu6f(acc[r][0]), relu6f(acc[r][1]));
+      o.y = pack2(relu6f(acc[r][2]), relu6f(acc[r][3]));
+      o.z = pack2(relu6f(acc[r][4]), relu6f(acc[r][5]));
+      o.w = pack2(relu6f(acc[r][6]), relu6f(acc[r][7]));
+      *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * C + c8 * 8) = o;
+    }
+  }
 }
 
 // ---- pointwise GEMM on v_mfma_f32_16x16x32_bf16 (see encoder.hip pw_kernel for the tiling / KSPLIT scheme) ----
@@ -541,10 +568,15 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
       hipLaunchKernelGGL(stem_bf16_kernel, dim3((total + 255) / 256, 1, kc), dim3(256), 0, s, visual, enc_w, ms, k0,
                          l.w_off, l.b_off, B, l.cin, l.h_in, l.h_out, dst);
     } else if (l.kind == L_DW) {
-      const long total = (long)B * l.h_out * l.h_out * (l.cout / 8);
-      hipLaunchKernelGGL(dw_bf16_kernel, dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), 0, s,
-                         reinterpret_cast<const bf16_t*>(bufs[l.src]), enc_w, ms, k0, l.w_off, l.b_off, B, l.cout,
-                         l.h_in, l.h_out, l.stride, dst);
+      constexpr int R = 4;
+      const long total = (long)B * l.h_out * ((l.h_out + R - 1) / R) * (l.cout / 8);
+      const dim3 grid((unsigned)((total + 255) / 256), 1, kc);
+      if (l.stride == 1)
+        hipLaunchKernelGGL((dw_bf16_kernel<1, R>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t*>(bufs[l.src]),
+                           enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);
+      else
+        hipLaunchKernelGGL((dw_bf16_kernel<2, R>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t*>(bufs[l.src]),
+                           enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);
     } else {
       const int M = B * l.h_out * l.h_out;
       const bool last = li + 1 == plan.layers.size();  // features.18 feeds the fp32 tail
