@@ -235,7 +235,7 @@ def main():
     blocks16 = B * N / 16.0
     mfma_per_block_step = K * (3 * 251 + (2 * 274 + 82))
     exec_flops = blocks16 * args.search_steps * mfma_per_block_step * 2048.0
-    use_mfma = (B * N >= 1024 and N % 16 == 0 and K <= 4)
+    use_mfma = (B * N >= 2048 and N % 16 == 0 and K <= 4)
     sb = 2 if args.encoder_dtype == "bf16" else 4  # bytes per encoder element (SURVEY §8d `s`)
     enc_bytes = B * (200 * 200 * C * 4 + 100 * 100 * C * 4) + K * (B * (ENC_ACT_ELEMS + 10000 * (C - 2)) * sb + ENC_WEIGHT_ELEMS * sb)
     roof = {

@@ -160,7 +160,7 @@ int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const floa
             int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
- *   RIP_OPT_SEARCH_KERNEL: 0 = auto (MFMA-batched when B*N >= 1024, N % 16 == 0, K <= 4, no traces),
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (MFMA-batched when B*N >= 2048, N % 16 == 0, K <= 4, no traces),
  *     1 = wave-per-chain kernel (lowest latency, any K/N, supports traces),
  *     2 = MFMA-batched kernel (16 candidates per wave).  Both implement rip/agent.py:78-137.
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused

@@ -138,7 +138,7 @@ class RIPAgent(SetPointAgent):
     max_batch: observations per `plan_batch` call.
     encoder_dtype: "fp32" (parity mode, default) or "bf16" (BASELINE config 3: bf16 activations/weights in the
       MobileNetV2 encoder with fp32 accumulation; the flow and the search stay fp32).
-    search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 1024 (N % 16 == 0, K <= 4), else the
+    search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 2048 (N % 16 == 0, K <= 4), else the
       wave-per-chain kernel; both are the same algorithm.
   """
 

@@ -264,6 +264,7 @@ __device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, c
       x1 = in8[1];
       yp0 = pre.dloc0 + pre.s0 * x0;  // (0 + dloc) + scale * x, sequence.py:136
       yp1 = pre.dloc1 + pre.s1 * x1;
+      o.sq = fmaf(x0, x0, x1 * x1);
       if (lane == 0) {
         out8[0] = yp0;
         out8[1] = yp1;
@@ -326,6 +327,7 @@ __device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, c
       x1 = in8[2 * t + 1];
       y0 = (yp0 + o0) + s0 * x0;  // sequence.py:136
       y1 = (yp1 + o1) + s1 * x1;
+      o.sq = fmaf(x0, x0, fmaf(x1, x1, o.sq));
       if (lane == 0) {
         out8[2 * t] = y0;
         out8[2 * t + 1] = y1;
@@ -362,8 +364,11 @@ __device__ __forceinline__ ChainOut chain_forward(int mode, const FlowRegs& W, c
 //   MODE_FWD: given dL/dy in in8          ->  writes dL/dx to out8.
 // Step 0 has no hidden-state dependence on the candidate (see Prefix), so only steps T-1..1 run the
 // head / GRU adjoint; nothing flows into h_0 = z or y_0 = 0.
+// w0 (MODE_FWD only): weight of model 0's own posterior q_0 = -0.5|x|^2 - logabsdet_F in the loss; because
+// inverse_0(F_0(x)) == x it is evaluated on the forward pass itself and its gradient enters here:
+// d(-w0 q_0)/dx_t = w0 x_t, d(-w0 q_0)/ds_t = w0 / s_t (s_0 belongs to the candidate-independent prefix).
 __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, const float* w1row, const float* tape,
-                                               const float* in8, float* out8, int lane) {
+                                               const float* in8, float* out8, int lane, float w0 = 0.f) {
   const bool upper = lane >= 32;
   float dhdir = 0.f, dpr = 0.f, dpz = 0.f, dghn = 0.f;
   float carry0 = 0.f, carry1 = 0.f;
@@ -389,15 +394,15 @@ __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, cons
       const float D0 = in8[2 * t] + carry0;
       const float D1 = in8[2 * t + 1] + carry1;
       if (lane == 0) {
-        out8[2 * t] = D0 * s0;
-        out8[2 * t + 1] = D1 * s1;
+        out8[2 * t] = fmaf(D0, s0, w0 * x0);
+        out8[2 * t + 1] = fmaf(D1, s1, w0 * x1);
       }
       c0 = D0;
       c1 = D1;
       dd0 = D0;
       dd1 = D1;
-      dos0 = D0 * x0 * sg0;
-      dos1 = D1 * x1 * sg1;
+      dos0 = (D0 * x0 + w0 * rcpf_(s0)) * sg0;
+      dos1 = (D1 * x1 + w0 * rcpf_(s1)) * sg1;
     }
     // ---- head adjoint ----
     const float* tl = tape + t * TAPE_Q * 64 + lane;
@@ -429,8 +434,8 @@ __device__ __forceinline__ void chain_backward(int mode, const FlowRegs& W, cons
       out8[0] = carry0 - tu[0] * rcpf_(tu[2]);
       out8[1] = carry1 - tu[1] * rcpf_(tu[3]);
     } else {
-      out8[0] = (in8[0] + carry0) * tu[2];
-      out8[1] = (in8[1] + carry1) * tu[3];
+      out8[0] = fmaf(in8[0] + carry0, tu[2], w0 * tu[0]);
+      out8[1] = fmaf(in8[1] + carry1, tu[3], w0 * tu[1]);
     }
   }
 }
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
         k = wave == 0 ? 0 : -1;
       } else {
         const int kk = wave + (ph - 1) * NW;
-        k = kk < K ? kk : -1;
+        k = (kk < K && kk != 0) ? kk : -1;  // model 0 needs no inverse pass: inverse_0(F_0(x)) == x
       }
       if (k >= 0) {
         if (k != loaded) {
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
         const ChainOut o = chain_forward<true>(mode, W, w1row, pre, ph == 0 ? sh.xbuf : sh.ybuf,
                                                ph == 0 ? sh.ybuf : nullptr, tape, lane);
         if (ph == 0) {
+          if (lane == 0) sh.q[0] = (-0.5f * o.sq - 4.0f * LOG_2PI) - o.lad;  // posterior of model 0 (shortcut)
           if (goal != nullptr && !final_pass) {
             float g0, g1;
             __builtin_amdgcn_wave_barrier();
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
         k = wave == 0 ? 0 : -1;
       } else {
         const int kk = wave + (ph - 1) * NW;
-        k = kk < K ? kk : -1;
+        k = (kk < K && kk != 0) ? kk : -1;
       }
       const bool needed = ph == 0 || mean_mode || k == ksel;
       if (k >= 0 && !needed && lane < 8) sh.gk[k][lane] = 0.f;
@@ -659,16 +665,17 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
           if (lane < 8) {
             float g = 0.f;
             if (mean_mode) {
-              for (int kk = 0; kk < K; ++kk) g += sh.gk[kk][lane];
+              for (int kk = 1; kk < K; ++kk) g += sh.gk[kk][lane];
               g /= (float)K;
-            } else {
+            } else if (ksel != 0) {
               g = sh.gk[ksel][lane];
             }
             if (lane >= 6) g += sh.gl[lane - 5];
             sh.gsum[lane] = -g * a.grad_scale;
           }
           __builtin_amdgcn_wave_barrier();
-          chain_backward(MODE_FWD, W, w1row, tapes, sh.gsum, sh.dxbuf, lane);
+          const float w0 = (mean_mode ? 1.0f / (float)K : (ksel == 0 ? 1.0f : 0.0f)) * a.grad_scale;
+          chain_backward(MODE_FWD, W, w1row, tapes, sh.gsum, sh.dxbuf, lane, w0);
         } else {
           chain_backward(MODE_INV, W, w1row, tapes + (1 + k) * TAPE, nullptr, sh.gk[k], lane);
         }
@@ -697,6 +704,293 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
   }
   // plan = F_0(x_best) is in ybuf (rip/agent.py:137)
   if (wave == 0) {
+    if (a.plans != nullptr && lane < 8) a.plans[(size_t)bn * 8 + lane] = sh.ybuf[lane];
+    if (a.loss_best != nullptr && lane == 0) a.loss_best[bn] = loss_best;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Step-pipelined plan search (2 <= K <= 4, K waves): same algorithm as search_kernel, shorter critical path.
+//   * wave 0 runs F_0 only (model 0's posterior comes from the self-inverse shortcut); wave k >= 1 runs the
+//     inverse of model k.  Inverse step t needs y_{t-1} for its GRU + head and y_t only for the final
+//     x_t = (y_t - mu_t) / s_t, so all waves advance through the T steps together, one barrier per step, and the
+//     inverses finish a division after F_0 does.
+//   * adjoint: dq_k/dy_t = carry_t - x_t/s_t is known at the START of inverse-adjoint iteration t, so it is
+//     published first and the F_0 adjoint of the same step runs concurrently with the rest of that iteration.
+//   Per Adam step the critical path is ~(T-1) forward + (T-1) adjoint steps instead of 4 (T-1).
+// ------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void search_pipe_kernel(SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int K = NW;
+  float* w1_all = smem;                 // K * W1_LDS
+  float* tapes = w1_all + K * W1_LDS;   // K * TAPE (wave w's pass)
+  SearchShared& sh = *reinterpret_cast<SearchShared*>(tapes + K * TAPE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int k = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave == model
+  const bool upper = lane >= 32;
+  const int bn = blockIdx.x;
+  const int b = bn / a.N;
+  for (int kk = 0; kk < K; ++kk) stage_w1(w1_all + kk * W1_LDS, a.flow_w + (size_t)(a.k0 + kk) * FW_SIZE, tid, NW * 64);
+  FlowRegs W;
+  load_flow_regs(W, a.flow_w + (size_t)(a.k0 + k) * FW_SIZE, lane);
+  if (a.goal != nullptr)
+    for (int i = tid; i < 2 * a.G; i += NW * 64) sh.goal[i] = a.goal[(size_t)b * a.G * 2 + i];
+  __syncthreads();
+  const float* w1row = w1_all + k * W1_LDS + (lane & 31) * W1_STRIDE;
+  const Prefix pre = chain_prefix(W, w1row, a.z[((size_t)k * a.B + b) * 64 + lane]);
+  float* tape = tapes + k * TAPE;
+  const float* goal = a.goal != nullptr ? sh.goal : nullptr;
+
+  float x = 0.f, am = 0.f, av = 0.f, xbest = 0.f;
+  if (lane < 8) x = a.x0[(size_t)bn * 8 + lane];
+  xbest = x;
+  float loss_best = 1000.0f;
+  double b1p = 1.0, b2p = 1.0;
+  const bool mean_mode = a.algorithm == ALGO_MA;
+
+#pragma unroll 1
+  for (int step = 0; step <= a.num_steps; ++step) {
+    const bool final_pass = step == a.num_steps;
+    // =============================== forward: all waves in lock step ===============================
+    float sq = 0.f, lad = pre.lad;
+    float yp0, yp1;
+    if (k == 0) {
+      if (lane < 8) sh.xbuf[lane] = final_pass ? xbest : x;
+      __builtin_amdgcn_wave_barrier();
+      const float x0 = sh.xbuf[0], x1 = sh.xbuf[1];
+      yp0 = pre.dloc0 + pre.s0 * x0;
+      yp1 = pre.dloc1 + pre.s1 * x1;
+      sq = fmaf(x0, x0, x1 * x1);
+      if (lane == 0) {
+        sh.ybuf[0] = yp0;
+        sh.ybuf[1] = yp1;
+        float* tu = tape + TAPE_LANE;
+        tu[0] = x0;
+        tu[1] = x1;
+        tu[2] = pre.s0;
+        tu[3] = pre.s1;
+      }
+    }
+    __syncthreads();
+    if (k != 0) {
+      yp0 = sh.ybuf[0];
+      yp1 = sh.ybuf[1];
+      const float x0 = (yp0 - pre.dloc0) * rcpf_(pre.s0), x1 = (yp1 - pre.dloc1) * rcpf_(pre.s1);
+      sq = fmaf(x0, x0, x1 * x1);
+      if (lane == 0) {
+        float* tu = tape + TAPE_LANE;
+        tu[0] = x0;
+        tu[1] = x1;
+        tu[2] = pre.s0;
+        tu[3] = pre.s1;
+      }
+    }
+    const bool inv_active = !final_pass || k == 0;  // the final pass only needs F_0
+    float h = pre.h1;
+    float gh[3] = {pre.gh[0], pre.gh[1], pre.gh[2]};
+    float a1 = 0.f;
+#pragma unroll 1
+    for (int t = 1; t < T; ++t) {
+      float o0 = 0.f, o1 = 0.f, s0 = 1.f, s1 = 1.f, o2 = 0.f, o3 = 0.f;
+      if (inv_active) {
+        const float gir = fmaf(W.wih[0][1], yp1, fmaf(W.wih[0][0], yp0, W.bih[0]));
+        const float giz = fmaf(W.wih[1][1], yp1, fmaf(W.wih[1][0], yp0, W.bih[1]));
+        const float gin = fmaf(W.wih[2][1], yp1, fmaf(W.wih[2][0], yp0, W.bih[2]));
+        const float r = sigmoidf_(gir + gh[0]);
+        const float zg = sigmoidf_(giz + gh[1]);
+        const float n = tanhf_(fmaf(r, gh[2], gin));
+        const float hn = fmaf(zg, h - n, n);
+        float* tl = tape + t * TAPE_Q * 64 + lane;
+        tl[0 * 64] = h;
+        tl[1 * 64] = r;
+        tl[2 * 64] = zg;
+        tl[3 * 64] = n;
+        tl[4 * 64] = gh[2];
+        h = hn;
+        if (t < T - 1) {
+          matvec<true, true>(W, w1row, h, gh, a1);
+        } else {
+          matvec<false, true>(W, w1row, h, gh, a1);
+        }
+        tl[5 * 64] = a1;
+        head_finish(W, a1, o0, o1, o2, o3);
+        s0 = softplusf_(o2) + 1e-3f;
+        s1 = softplusf_(o3) + 1e-3f;
+        lad += __logf(s0 * s1);
+      }
+      float y0 = 0.f, y1 = 0.f;
+      if (k == 0) {
+        const float x0 = sh.xbuf[2 * t], x1 = sh.xbuf[2 * t + 1];
+        y0 = (yp0 + o0) + s0 * x0;
+        y1 = (yp1 + o1) + s1 * x1;
+        sq = fmaf(x0, x0, fmaf(x1, x1, sq));
+        if (lane == 0) {
+          sh.ybuf[2 * t] = y0;
+          sh.ybuf[2 * t + 1] = y1;
+          float* tu = tape + TAPE_LANE + t * 8;
+          tu[0] = x0;
+          tu[1] = x1;
+          tu[2] = s0;
+          tu[3] = s1;
+          tu[4] = softplus_gradf_(o2);
+          tu[5] = softplus_gradf_(o3);
+        }
+      }
+      __syncthreads();
+      if (k != 0) {
+        y0 = sh.ybuf[2 * t];
+        y1 = sh.ybuf[2 * t + 1];
+        if (inv_active) {
+          const float x0 = (y0 - (yp0 + o0)) * rcpf_(s0), x1 = (y1 - (yp1 + o1)) * rcpf_(s1);
+          sq = fmaf(x0, x0, fmaf(x1, x1, sq));
+          if (lane == 0) {
+            float* tu = tape + TAPE_LANE + t * 8;
+            tu[0] = x0;
+            tu[1] = x1;
+            tu[2] = s0;
+            tu[3] = s1;
+            tu[4] = softplus_gradf_(o2);
+            tu[5] = softplus_gradf_(o3);
+          }
+        }
+      }
+      yp0 = y0;
+      yp1 = y1;
+    }
+    if (final_pass) break;
+    if (k == 0) {
+      float gl = 0.f, g0 = 0.f, g1 = 0.f;
+      if (goal != nullptr) gl = goal_ll(goal, a.G, a.epsilon, yp0, yp1, &g0, &g1);
+      if (lane == 0) {
+        sh.gl[0] = gl;
+        sh.gl[1] = g0;
+        sh.gl[2] = g1;
+      }
+    }
+    if (lane == 0) sh.q[k] = (-0.5f * sq - 4.0f * LOG_2PI) - lad;
+    __syncthreads();
+
+    // =============================== aggregate (rip/agent.py:121-127, as coded) ===============================
+    const float gl = sh.gl[0];
+    int ksel = 0;
+    float qsel = sh.q[0], qmean = sh.q[0];
+#pragma unroll
+    for (int kk = 1; kk < K; ++kk) {
+      const float qk = sh.q[kk];
+      qmean += qk;
+      const bool take = a.algorithm == ALGO_WCM ? (qk > qsel) : (qk < qsel);
+      if (take) {
+        qsel = qk;
+        ksel = kk;
+      }
+    }
+    qmean /= (float)K;
+    const float loss = -((mean_mode ? qmean : qsel) + gl);
+    if (a.trace_post != nullptr && lane == 0)
+      a.trace_post[(((size_t)step * K + k) * a.B + b) * a.N + (bn - b * a.N)] = sh.q[k] + gl;
+    const float wk = mean_mode ? 1.0f / (float)K : (ksel == k ? 1.0f : 0.0f);  // this wave's model in the loss
+    const bool active = k == 0 || wk != 0.f;
+    const float w0 = k == 0 ? wk * a.grad_scale : 0.f;
+
+    // =============================== adjoint: F_0 trails the inverses by one hand-off ===============================
+    float dhdir = 0.f, dpr = 0.f, dpz = 0.f, dghn = 0.f, carry0 = 0.f, carry1 = 0.f;
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+      const float* tu = tape + TAPE_LANE + t * 8;
+      const float x0 = tu[0], x1 = tu[1], s0 = tu[2], s1 = tu[3];
+      float xs0 = 0.f, xs1 = 0.f, i0 = 0.f, i1 = 0.f;
+      if (k != 0) {  // publish dq_k/dy_t = carry - x/s (weighted), known before this iteration's heavy part
+        i0 = rcpf_(s0);
+        i1 = rcpf_(s1);
+        xs0 = x0 * i0;
+        xs1 = x1 * i1;
+        if (lane == 0) {
+          sh.gk[k][2 * t] = active ? wk * (carry0 - xs0) : 0.f;
+          sh.gk[k][2 * t + 1] = active ? wk * (carry1 - xs1) : 0.f;
+        }
+      }
+      __syncthreads();
+      if (!active) continue;  // barriers above are unconditional; nothing below synchronises
+      float dd0, dd1, dos0 = 0.f, dos1 = 0.f, c0, c1;
+      if (k == 0) {
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int kk = 1; kk < K; ++kk) {
+          g0 += sh.gk[kk][2 * t];
+          g1 += sh.gk[kk][2 * t + 1];
+        }
+        if (t == T - 1) {
+          g0 += sh.gl[1];
+          g1 += sh.gl[2];
+        }
+        const float D0 = -g0 * a.grad_scale + carry0, D1 = -g1 * a.grad_scale + carry1;
+        if (lane == 0) {
+          sh.dxbuf[2 * t] = fmaf(D0, s0, w0 * x0);
+          sh.dxbuf[2 * t + 1] = fmaf(D1, s1, w0 * x1);
+        }
+        c0 = D0;
+        c1 = D1;
+        dd0 = D0;
+        dd1 = D1;
+        if (t > 0) {
+          dos0 = (D0 * x0 + w0 * rcpf_(s0)) * tu[4];
+          dos1 = (D1 * x1 + w0 * rcpf_(s1)) * tu[5];
+        }
+      } else {
+        c0 = xs0;
+        c1 = xs1;
+        dd0 = xs0;
+        dd1 = xs1;
+        if (t > 0) {
+          dos0 = (x0 * x0 - 1.0f) * i0 * tu[4];
+          dos1 = (x1 * x1 - 1.0f) * i1 * tu[5];
+        }
+      }
+      if (t == 0) break;  // step 0 is the candidate-independent prefix: coupling only
+      const float* tl = tape + t * TAPE_Q * 64 + lane;
+      const float part = W.w2a * (upper ? dos0 : dd0) + W.w2b * (upper ? dos1 : dd1);
+      float da1 = xor32_sum(part);
+      da1 = tl[5 * 64] > 0.f ? da1 : 0.f;
+      const float da1h = upper ? 0.f : da1;
+      const float dh = transposed_matvec(W, w1row, da1h, dpr, dpz, dghn, lane) + dhdir;
+      const float hprev = tl[0 * 64], r = tl[1 * 64], zg = tl[2 * 64], n = tl[3 * 64], ghn = tl[4 * 64];
+      const float dn = dh * (1.0f - zg);
+      const float dzg = dh * (hprev - n);
+      dhdir = dh * zg;
+      const float dpn = dn * (1.0f - n * n);
+      const float dr = dpn * ghn;
+      dghn = dpn * r;
+      dpr = dr * r * (1.0f - r);
+      dpz = dzg * zg * (1.0f - zg);
+      const float du0 = wave_sum(fmaf(W.wih[0][0], dpr, fmaf(W.wih[1][0], dpz, W.wih[2][0] * dpn)));
+      const float du1 = wave_sum(fmaf(W.wih[0][1], dpr, fmaf(W.wih[1][1], dpz, W.wih[2][1] * dpn)));
+      carry0 = c0 + du0;
+      carry1 = c1 + du1;
+    }
+
+    // =============================== Adam + bookkeeping (wave 0) ===============================
+    if (k == 0) {
+      b1p *= 0.9;
+      b2p *= 0.999;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 8) {
+        const float g = sh.dxbuf[lane];
+        am = am + (g - am) * 0.1f;
+        av = av * 0.999f + 0.001f * g * g;
+        const float step_size = (float)((double)a.lr / (1.0 - b1p));
+        const float bc2s = (float)sqrt(1.0 - b2p);
+        x = x - step_size * (am / (sqrtf(av) / bc2s + 1e-8f));
+        if (loss < loss_best) xbest = x;  // post-step x vs pre-step loss (rip/agent.py:131-135)
+        if (a.trace_x != nullptr) a.trace_x[((size_t)step * a.B * a.N + bn) * 8 + lane] = x;
+      }
+      if (loss < loss_best) loss_best = loss;
+      if (a.trace_loss != nullptr && lane == 0) a.trace_loss[(size_t)step * a.B * a.N + bn] = loss;
+    }
+    __syncthreads();
+  }
+  if (k == 0) {
     if (a.plans != nullptr && lane < 8) a.plans[(size_t)bn * 8 + lane] = sh.ybuf[lane];
     if (a.loss_best != nullptr && lane == 0) a.loss_best[bn] = loss_best;
   }
@@ -847,7 +1141,20 @@ size_t search_lds_bytes(int K) {
   return (size_t)(K * W1_LDS + (1 + K) * TAPE) * sizeof(float) + sizeof(SearchShared);
 }
 
+template <int NW>
+static hipError_t launch_pipe(const SearchArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)(NW * W1_LDS + NW * TAPE) * sizeof(float) + sizeof(SearchShared);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_pipe_kernel<NW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(search_pipe_kernel<NW>, dim3(a.B * a.N), dim3(NW * 64), lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
+  if (a.K == 2) return launch_pipe<2>(a, s);
+  if (a.K == 3) return launch_pipe<3>(a, s);
+  if (a.K == 4) return launch_pipe<4>(a, s);
   const size_t lds = search_lds_bytes(a.K);
   const dim3 grid(a.B * a.N);
   const int nw = a.K >= 4 ? 4 : a.K;

@@ -317,7 +317,7 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   a.trace_loss = nullptr;
   // kernel choice: the MFMA-batched kernel wins once there are enough 16-candidate blocks to fill the chip;
   // the wave-per-chain kernel has the lower latency for a single observation.
-  bool use_mfma = search_mfma_supported(a) && h->search_mode != 1 && (h->search_mode == 2 || (size_t)B * N >= 1024);
+  bool use_mfma = search_mfma_supported(a) && h->search_mode != 1 && (h->search_mode == 2 || (size_t)B * N >= 2048);
   if (h->search_mode == 2 && !search_mfma_supported(a))
     return fail(RIP_EINVAL, "MFMA search kernel needs K<=4, N%%16==0 and no trace outputs (K=%d N=%d)", h->K, N);
   if (use_mfma) {
