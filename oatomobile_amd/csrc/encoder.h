@@ -58,7 +58,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
                           hipStream_t s);
 
-hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last,
+hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last, int hw,
                        const float* vec, int B, float* scratch, float* z, float* feat, hipStream_t s);
 
 // bf16 encoder (encoder_bf16.hip): bf16 NHWC activations, bf16 pointwise weights (enc_wh: same offsets as the fp32

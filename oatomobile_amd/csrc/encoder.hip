@@ -161,6 +161,21 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in, c
 // ------------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// sum over each row of 16 lanes (DPP), replicated in the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float x) {
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  x += dpp_f<0x141>(x);
+  x += dpp_f<0x140>(x);
+  return x;
+}
+
+// `flags`: bit 0 = ReLU6 after the folded BN; bit 1 = global-average-pool epilogue: a 16-pixel tile is one whole
+// 4x4 image (features.18), so the mean over the tile's 16 lanes is written to out[tile][Cout] instead of 16 rows.
 // KSPLIT = 1: the block's 4 waves take 4 different pixel-tile groups.  KSPLIT = 4: they take the 4 quarters of the
 // K range of ONE (CT x PT) tile and reduce through LDS — big register tiles (little operand re-reading from L2)
 // and still enough waves when M is small (7x7 / 4x4 stages, or a single observation).
@@ -168,8 +183,9 @@ template <int CT, int PT, int UNROLL, int KSPLIT>
 __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
                                                   size_t model_stride, int k0, size_t w_off, size_t b_off,
                                                   const float* __restrict__ res, float* __restrict__ out, int M,
-                                                  int Cin, int Cout, int relu6, size_t act_model_stride_in,
+                                                  int Cin, int Cout, int flags, size_t act_model_stride_in,
                                                   size_t act_model_stride_out) {
+  const int relu6 = flags & 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int k = blockIdx.z;
@@ -272,7 +288,20 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
-        if (p < M && (KSPLIT == 1 || ((ct * PT + pt) & (KSPLIT - 1)) == wave)) {
+        if (KSPLIT != 1 && ((ct * PT + pt) & (KSPLIT - 1)) != wave) continue;  // wave-uniform
+        if (flags & 2) {
+          float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
+                                 acc[ct][pt][3] + bb.w);
+          if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+          if (p >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          v.x = row_sum16(v.x) * 0.0625f;
+          v.y = row_sum16(v.y) * 0.0625f;
+          v.z = row_sum16(v.z) * 0.0625f;
+          v.w = row_sum16(v.w) * 0.0625f;
+          if (n == 0 && (ptile0 + pt) * 16 < M) *reinterpret_cast<float4*>(O + (size_t)(ptile0 + pt) * Cout + co) = v;
+          continue;
+        }
+        if (p < M) {
           float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                  acc[ct][pt][3] + bb.w);
           if (R != nullptr) {
@@ -297,22 +326,23 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
 
 template <int CT, int PT, int UNROLL, int KSPLIT>
 void launch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc, const Layer& l, const float* res,
-               float* dst, int M, hipStream_t s) {
+               float* dst, int M, bool pool, hipStream_t s) {
   const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   const int groups = (n_pt + PT - 1) / PT;
   const dim3 grid(KSPLIT == 1 ? (groups + 3) / 4 : groups, (n_ct + CT - 1) / CT, kc);
   hipLaunchKernelGGL((pw_kernel<CT, PT, UNROLL, KSPLIT>), grid, dim3(256), 0, s, in, enc_w, ms, k0, l.w_off, l.b_off,
-                     res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+                     res, dst, M, l.cin, l.cout, l.relu6 | (pool ? 2 : 0), (size_t)M * l.cin,
+                     pool ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout);
 }
 
 // Tile choice: the biggest wave tile that still yields >= ~1024 waves.  When even that is impossible with one
 // wave per tile (small M) and the reduction is long enough, the 4 waves of a block split K instead.
 void dispatch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc, const Layer& l, const float* res,
-                 float* dst, int M, hipStream_t s) {
+                 float* dst, int M, bool pool, hipStream_t s) {
   const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   auto jobs = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
   const long want = 1024;
-#define PW_GO(CT_, PT_, U_, KS_) return launch_pw<CT_, PT_, U_, KS_>(in, enc_w, ms, k0, kc, l, res, dst, M, s)
+#define PW_GO(CT_, PT_, U_, KS_) return launch_pw<CT_, PT_, U_, KS_>(in, enc_w, ms, k0, kc, l, res, dst, M, pool, s)
   if (n_ct >= 5 && jobs(6, 2) >= want) PW_GO(6, 2, 2, 1);
   if (n_ct >= 3 && jobs(4, 2) >= want) PW_GO(4, 2, 2, 1);
   if (n_ct >= 2 && jobs(2, 2) >= want) PW_GO(2, 2, 4, 1);
@@ -664,20 +694,22 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     } else {
       const int M = B * l.h_out * l.h_out;
       const float* res = l.residual ? bufs[l.res] : nullptr;
-      dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, s);
+      const bool pool = li + 1 == plan.layers.size() && plan.final_hw == 4;  // features.18: fuse the 4x4 average pool
+      dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, pool, s);
     }
   }
-  return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], vec, B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
+  return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], plan.final_hw == 4 ? 1 : plan.final_hw * plan.final_hw, vec,
+                     B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
 }
 
-// avg-pool + classifier + merger on the fp32 features.18 output `act_last` [kc][B][HW][1280]
-hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last,
+// avg-pool + classifier + merger on the fp32 features.18 output `act_last` [kc][B][hw][1280] (hw = 1: already pooled)
+hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last, int hw,
                        const float* vec, int B, float* scratch, float* z, float* feat, hipStream_t s) {
   const size_t ms = plan.blob_floats;
   // classifier logits go to `feat` if the caller wants them, else to scratch
   float* feat_buf = feat != nullptr ? feat : scratch;
   hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, act_last,
-                     enc_w, ms, k0, plan.cls_w_off, plan.cls_b_off, B, plan.final_hw * plan.final_hw, feat_buf);
+                     enc_w, ms, k0, plan.cls_w_off, plan.cls_b_off, B, hw, feat_buf);
   hipLaunchKernelGGL(merger_kernel, dim3(B, kc), dim3(64), 0, s, (const float*)feat_buf, enc_w, ms, k0,
                      plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1], plan.mrg_b_off[1], plan.mrg_w_off[2],
                      plan.mrg_b_off[2], vec, B, z);

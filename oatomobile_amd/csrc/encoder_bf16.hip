@@ -24,6 +24,17 @@ __device__ __forceinline__ unsigned f2bf(float f) {  // round to nearest even
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float x) {  // sum over each row of 16 lanes, replicated in the row
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  x += dpp_f<0x141>(x);
+  x += dpp_f<0x140>(x);
+  return x;
+}
 
 // ---- stem: fp32 NCHW input -> bf16 NHWC [K][B][Ho][Ho][32]; thread = (pixel, 4 output channels) ----
 __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
@@ -169,8 +180,9 @@ template <int CT, int PT, int UNROLL, int KSPLIT, bool OUT_F32>
 __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ whbase,
                                                        const float* __restrict__ wbase, size_t model_stride, int k0,
                                                        size_t w_off, size_t b_off, const bf16_t* __restrict__ res,
-                                                       void* __restrict__ out, int M, int Cin, int Cout, int relu6,
+                                                       void* __restrict__ out, int M, int Cin, int Cout, int flags,
                                                        size_t act_model_stride_in, size_t act_model_stride_out) {
+  const int relu6 = flags & 1;  // bit 1: 4x4 average-pool epilogue (fp32 outputs only), see encoder.hip pw_kernel
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int k = blockIdx.z;
@@ -313,7 +325,21 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
-        if (p < M && (KSPLIT == 1 || ((ct * PT + pt) & (KSPLIT - 1)) == wave)) {
+        if (KSPLIT != 1 && ((ct * PT + pt) & (KSPLIT - 1)) != wave) continue;  // wave-uniform
+        if (OUT_F32 && (flags & 2)) {
+          float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
+                                 acc[ct][pt][3] + bb.w);
+          if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+          if (p >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          v.x = row_sum16(v.x) * 0.0625f;
+          v.y = row_sum16(v.y) * 0.0625f;
+          v.z = row_sum16(v.z) * 0.0625f;
+          v.w = row_sum16(v.w) * 0.0625f;
+          float* O = reinterpret_cast<float*>(out) + (size_t)k * act_model_stride_out;
+          if (n == 0 && (ptile0 + pt) * 16 < M) *reinterpret_cast<float4*>(O + (size_t)(ptile0 + pt) * Cout + co) = v;
+          continue;
+        }
+        if (p < M) {
           float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                  acc[ct][pt][3] + bb.w);
           if (R != nullptr) {
@@ -354,8 +380,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                                                          const bf16_t* __restrict__ whbase,
                                                          const float* __restrict__ wbase, size_t model_stride, int k0,
                                                          size_t w_off, size_t b_off, const bf16_t* __restrict__ res,
-                                                         void* __restrict__ out, int M, int Cin, int Cout, int relu6,
+                                                         void* __restrict__ out, int M, int Cin, int Cout, int flags,
                                                          size_t act_model_stride_in, size_t act_model_stride_out) {
+  const int relu6 = flags & 1;
   constexpr int BM = 128, BN = 32 * WN, LD = 40;  // LD: bf16 elements per LDS row (32 + 8 pad -> 80 B rows)
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BN + BM) * LD];
   auto As = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD; };
@@ -442,9 +469,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int p = p0 + wp * 64 + 16 * j + n;
-          if (p < M) {
-            float4 v = make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
-            if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+          float4 v = make_float4(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w);
+          if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+          if (flags & 2) {  // 4x4 average pool: the tile's 16 pixels are one image
+            if (p >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = row_sum16(v.x) * 0.0625f;
+            v.y = row_sum16(v.y) * 0.0625f;
+            v.z = row_sum16(v.z) * 0.0625f;
+            v.w = row_sum16(v.w) * 0.0625f;
+            const int tile = (p0 + wp * 64 + 16 * j) / 16;
+            if (n == 0 && tile * 16 < M) *reinterpret_cast<float4*>(O + (size_t)tile * Cout + co) = v;
+          } else if (p < M) {
             *reinterpret_cast<float4*>(O + (size_t)p * Cout + co) = v;
           }
         }
@@ -494,47 +529,50 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 
 template <int WN>
 void launch_gemm(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc, const Layer& l,
-                 const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
+                 const bf16_t* res, void* dst, int M, bool out_f32, bool pool, hipStream_t s) {
+  const int flags = l.relu6 | (pool ? 2 : 0);
+  const size_t sout = pool ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
   const dim3 grid((M + 127) / 128, (l.cout + 32 * WN - 1) / (32 * WN), kc);
   if (out_f32)
     hipLaunchKernelGGL((gemm_bf16_kernel<WN, true>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off, l.b_off,
-                       res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+                       res, dst, M, l.cin, l.cout, flags, (size_t)M * l.cin, sout);
   else
     hipLaunchKernelGGL((gemm_bf16_kernel<WN, false>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off,
-                       l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+                       l.b_off, res, dst, M, l.cin, l.cout, flags, (size_t)M * l.cin, sout);
 }
 
 template <int CT, int PT, int UNROLL, int KSPLIT>
 void launch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc, const Layer& l,
-                const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
+                const bf16_t* res, void* dst, int M, bool out_f32, bool pool, hipStream_t s) {
+  const int flags = l.relu6 | (pool ? 2 : 0);
+  const size_t sout = pool ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
   const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   const int groups = (n_pt + PT - 1) / PT;
   const dim3 grid(KSPLIT == 1 ? (groups + 3) / 4 : groups, (n_ct + CT - 1) / CT, kc);
   if (out_f32)
     hipLaunchKernelGGL((pw_bf16_kernel<CT, PT, UNROLL, KSPLIT, true>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0,
-                       l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout);
+                       l.w_off, l.b_off, res, dst, M, l.cin, l.cout, flags, (size_t)M * l.cin, sout);
   else
     hipLaunchKernelGGL((pw_bf16_kernel<CT, PT, UNROLL, KSPLIT, false>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms,
-                       k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin,
-                       (size_t)M * l.cout);
+                       k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, flags, (size_t)M * l.cin, sout);
 }
 
 void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc,
-                  const Layer& l, const bf16_t* res, void* dst, int M, bool out_f32, hipStream_t s) {
+                  const Layer& l, const bf16_t* res, void* dst, int M, bool out_f32, bool pool, hipStream_t s) {
   const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   auto jobs = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
   // compute-heavy shapes (K >= 64 and enough 128-pixel tiles to fill the chip): LDS-tiled block GEMM
   if (l.cin >= 64 && M >= 1024) {
     const long blocks128 = (long)((M + 127) / 128) * ((l.cout + 127) / 128) * kc;
-    if (l.cout > 64 && blocks128 >= 192) return launch_gemm<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, s);
-    return launch_gemm<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, s);
+    if (l.cout > 64 && blocks128 >= 192) return launch_gemm<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s);
+    return launch_gemm<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s);
   }
   // occupancy first: these GEMMs are load-latency bound, so ask for >= 4 waves per SIMD; when one wave per tile
   // cannot deliver that and K is long enough, the block's 4 waves split K (4x the waves for the same tile).
   const long want = 1024;
   const bool ks = l.cin >= 128;
 #define PWB_GO(CT_, PT_, U_, KS_) \
-  return launch_pwb<CT_, PT_, U_, KS_>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, s)
+  return launch_pwb<CT_, PT_, U_, KS_>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s)
   if (n_ct >= 5) {
     if (jobs(6, 2) >= want) PWB_GO(6, 2, 2, 1);
     if (ks && jobs(6, 2) * 4 >= want) PWB_GO(6, 2, 2, 4);
@@ -568,24 +606,32 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
       hipLaunchKernelGGL(stem_bf16_kernel, dim3((total + 255) / 256, 1, kc), dim3(256), 0, s, visual, enc_w, ms, k0,
                          l.w_off, l.b_off, B, l.cin, l.h_in, l.h_out, dst);
     } else if (l.kind == L_DW) {
-      constexpr int R = 4;
-      const long total = (long)B * l.h_out * ((l.h_out + R - 1) / R) * (l.cout / 8);
-      const dim3 grid((unsigned)((total + 255) / 256), 1, kc);
-      if (l.stride == 1)
-        hipLaunchKernelGGL((dw_bf16_kernel<1, R>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t*>(bufs[l.src]),
-                           enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);
-      else
-        hipLaunchKernelGGL((dw_bf16_kernel<2, R>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t*>(bufs[l.src]),
-                           enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);
+      // runs of 4 outputs per thread once there are plenty of threads; single outputs for small launches
+      const long total1 = (long)B * l.h_out * l.h_out * (l.cout / 8);
+      const bf16_t* src = reinterpret_cast<const bf16_t*>(bufs[l.src]);
+#define DW_GO(S_, R_)                                                                                         \
+  {                                                                                                           \
+    const long total = (long)B * l.h_out * ((l.h_out + R_ - 1) / R_) * (l.cout / 8);                          \
+    hipLaunchKernelGGL((dw_bf16_kernel<S_, R_>), dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), 0, s, \
+                       src, enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);                 \
+  }
+      if (total1 * kc >= 4 * 65536) {
+        if (l.stride == 1) DW_GO(1, 4) else DW_GO(2, 4)
+      } else {
+        if (l.stride == 1) DW_GO(1, 1) else DW_GO(2, 1)
+      }
+#undef DW_GO
     } else {
       const int M = B * l.h_out * l.h_out;
       const bool last = li + 1 == plan.layers.size();  // features.18 feeds the fp32 tail
       const bf16_t* res = l.residual ? reinterpret_cast<const bf16_t*>(bufs[l.res]) : nullptr;
+      const bool pool = last && plan.final_hw == 4;  // features.18: fuse the 4x4 average pool into the epilogue
       dispatch_pwb(reinterpret_cast<const bf16_t*>(bufs[l.src]), enc_wh, enc_w, ms, k0, kc, l, res,
-                   reinterpret_cast<void*>(bufs[l.dst]), M, last, s);
+                   reinterpret_cast<void*>(bufs[l.dst]), M, last, pool, s);
     }
   }
-  return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], vec, B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
+  return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], plan.final_hw == 4 ? 1 : plan.final_hw * plan.final_hw, vec,
+                     B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
 }
 
 }  // namespace rip
