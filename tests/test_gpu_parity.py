@@ -347,6 +347,46 @@ def test_model_parallel_scoring_layout(dev, algo):
   np.testing.assert_allclose(S_full.cpu().numpy()[:, 0], So, rtol=2e-5, atol=2e-3)
 
 
+def test_full_size_properties(dev):
+  """Size-independent properties at BASELINE's full sizes (config 4: K=8, N=512; config 5-like row counts)."""
+  from oatomobile_amd import RIPAgent, _lib
+  from oracle import reference_cpu as O
+  # (1) flow round trip and determinant consistency on 10 000 rows
+  m = hip_model(1, dev)
+  rng = np.random.default_rng(11)
+  n = 10000
+  z = torch.from_numpy(np.maximum(rng.normal(size=(n, 64)), 0).astype(np.float32)).to(dev)
+  x = torch.from_numpy(rng.normal(size=(n, 4, 2)).astype(np.float32)).to(dev)
+  y, lad_f = m._forward(x, z)
+  xr, lp, lad_i = m._inverse(y, z)
+  np.testing.assert_allclose(xr.cpu().numpy(), x.cpu().numpy(), atol=TOL)
+  np.testing.assert_allclose(lad_f.cpu().numpy(), lad_i.cpu().numpy(), atol=TOL)
+  np.testing.assert_allclose(lp.cpu().numpy(), -0.5 * (x.cpu().numpy().reshape(n, -1)**2).sum(1) - 4 * np.log(2 * np.pi),
+                             rtol=1e-5, atol=1e-3)
+  # (2) config 4 size: K=8 models, N=512 candidates, against the oracle and under a permutation of the candidates
+  K, N = 8, 512
+  models = [hip_model(500 + k, dev) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, seed=3)
+  ob = synth_observation(np.random.default_rng(123))
+  lidar = torch.from_numpy(ob["lidar"]).to(dev)[None]
+  vec = torch.tensor([[*ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"]]], device=dev)
+  goal = torch.from_numpy(ob["goal"][None, :, :2].copy()).to(dev)
+  plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
+  assert torch.isfinite(plan).all() and torch.isfinite(loss).all()
+  assert float(loss.max()) < 1000.0  # every candidate improved on the sentinel (rip/agent.py:100)
+  refs = [oracle_model(500 + k) for k in range(K)]
+  _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"], ob["goal"],
+                      x0=agent._x0_rows.cpu()[:64], algorithm="WCM")  # the first 64 candidates suffice for the oracle
+  lo, lh = res["loss_best"].numpy(), loss.cpu().numpy()[0, :64]
+  assert (np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.97
+  perm = torch.randperm(N, generator=torch.Generator().manual_seed(0))
+  agent._x0_rows = agent._x0_rows[perm.to(dev)].contiguous()
+  agent._x0_cache = {}
+  plan_p, loss_p = agent.plan_batch(lidar, vec, goal, return_loss=True)
+  np.testing.assert_allclose(loss_p.cpu().numpy()[0], loss.cpu().numpy()[0][perm.numpy()], rtol=1e-6, atol=1e-6)
+  np.testing.assert_allclose(plan_p.cpu().numpy(), plan.cpu().numpy(), atol=1e-6)
+
+
 def test_batched_act_matches_single(dev):
   """plan_batch over B observations == B single calls (observation-parallel replay)."""
   from oatomobile_amd import RIPAgent
