@@ -36,56 +36,70 @@ __device__ __forceinline__ float row_sum16(float x) {  // sum over each row of 1
   return x;
 }
 
-// ---- stem: fp32 NCHW input -> bf16 NHWC [K][B][Ho][Ho][32]; thread = (pixel, 4 output channels) ----
+// ---- stem: fp32 NCHW input -> bf16 NHWC [K][B][Ho][Ho][32].  One block per (observation, band of output rows, model):
+// the band's input rows are staged once in LDS (coalesced fp32 reads), the model's 576-float tap table too; a thread
+// owns (pixel, 8 output channels) and writes 16 bytes.  Replaces per-tap scalar global loads.
+constexpr int STEM_ROWS = 5;  // output rows per block -> 11 input rows of 100 floats per channel
+template <int CMAX>
 __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
                                                          size_t model_stride, int k0, size_t w_off, size_t b_off,
                                                          int B, int C, int Hin, int Ho, bf16_t* __restrict__ out) {
-  const int k = blockIdx.z;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int IR = 2 * STEM_ROWS + 1;     // input rows of the band (incl. halo)
+  float* xs = smem;                     // [C][IR][Hin + 2] with zero borders
+  float* ws = xs + C * IR * (Hin + 2);  // [9][C][32]
+  const int k = blockIdx.z, b = blockIdx.y, band = blockIdx.x;
+  const int oy0 = band * STEM_ROWS;
+  const int iy0 = oy0 * 2 - 1;
+  const int tid = threadIdx.x;
   const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
-  const int total = B * Ho * Ho * 4;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int oc8 = idx & 3;
-  const int pix = idx >> 2;
-  const int ox = pix % Ho, oy = (pix / Ho) % Ho, b = pix / (Ho * Ho);
-  float acc[8];
-  {
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + oc8 * 8);
-    const float4 b1 = *reinterpret_cast<const float4*>(bias + oc8 * 8 + 4);
-    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
-    acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  const int IW = Hin + 2;
+  for (int e = tid; e < C * IR * IW; e += 256) {
+    const int ix = e % IW - 1, r = (e / IW) % IR, c = e / (IW * IR);
+    const int iy = iy0 + r;
+    xs[e] = (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin) ? in[((size_t)b * C + c) * Hin * Hin + (size_t)iy * Hin + ix] : 0.f;
   }
-  for (int c = 0; c < C; ++c) {
-    const float* ip = in + ((size_t)b * C + c) * Hin * Hin;
+  for (int e = tid; e < 9 * C * 32; e += 256) ws[e] = w[e];
+  __syncthreads();
+  const int rows = min(STEM_ROWS, Ho - oy0);
+  for (int e = tid; e < rows * Ho * 4; e += 256) {
+    const int oc8 = e & 3, pix = e >> 2;
+    const int ox = pix % Ho, oyl = pix / Ho;
+    float acc[8];
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + oc8 * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(bias + oc8 * 8 + 4);
+      acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
+      acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    }
+    for (int c = 0; c < C; ++c) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * 2 - 1 + ky;
-      if (iy < 0 || iy >= Hin) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const float* xr = xs + (c * IR + 2 * oyl + ky) * IW + 2 * ox;  // input col 2*ox - 1 + kx  (+1 border)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * 2 - 1 + kx;
-        if (ix < 0 || ix >= Hin) continue;
-        const float v = ip[(size_t)iy * Hin + ix];
-        const float* wp = w + ((ky * 3 + kx) * C + c) * 32 + oc8 * 8;
-        const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
-        acc[0] = fmaf(v, w0.x, acc[0]);
-        acc[1] = fmaf(v, w0.y, acc[1]);
-        acc[2] = fmaf(v, w0.z, acc[2]);
-        acc[3] = fmaf(v, w0.w, acc[3]);
-        acc[4] = fmaf(v, w1.x, acc[4]);
-        acc[5] = fmaf(v, w1.y, acc[5]);
-        acc[6] = fmaf(v, w1.z, acc[6]);
-        acc[7] = fmaf(v, w1.w, acc[7]);
+        for (int kx = 0; kx < 3; ++kx) {
+          const float v = xr[kx];
+          const float* wp = ws + ((ky * 3 + kx) * C + c) * 32 + oc8 * 8;
+          const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+          acc[0] = fmaf(v, w0.x, acc[0]);
+          acc[1] = fmaf(v, w0.y, acc[1]);
+          acc[2] = fmaf(v, w0.z, acc[2]);
+          acc[3] = fmaf(v, w0.w, acc[3]);
+          acc[4] = fmaf(v, w1.x, acc[4]);
+          acc[5] = fmaf(v, w1.y, acc[5]);
+          acc[6] = fmaf(v, w1.z, acc[6]);
+          acc[7] = fmaf(v, w1.w, acc[7]);
+        }
       }
     }
+    uint4 o;
+    o.x = pack2(relu6f(acc[0]), relu6f(acc[1]));
+    o.y = pack2(relu6f(acc[2]), relu6f(acc[3]));
+    o.z = pack2(relu6f(acc[4]), relu6f(acc[5]));
+    o.w = pack2(relu6f(acc[6]), relu6f(acc[7]));
+    *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)(oy0 + oyl) * Ho + ox) * 32 + oc8 * 8) = o;
   }
-  uint4 o;
-  o.x = pack2(relu6f(acc[0]), relu6f(acc[1]));
-  o.y = pack2(relu6f(acc[2]), relu6f(acc[3]));
-  o.z = pack2(relu6f(acc[4]), relu6f(acc[5]));
-  o.w = pack2(relu6f(acc[6]), relu6f(acc[7]));
-  *reinterpret_cast<uint4*>(out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * 32 + oc8 * 8) = o;
 }
 
 // ---- depthwise 3x3: thread = (run of R output pixels along x, 8 channels).  Sliding window: every input column of
@@ -602,9 +616,10 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     const Layer& l = plan.layers[li];
     bf16_t* dst = reinterpret_cast<bf16_t*>(bufs[l.dst]);
     if (l.kind == L_STEM) {
-      const int total = B * l.h_out * l.h_out * 4;
-      hipLaunchKernelGGL(stem_bf16_kernel, dim3((total + 255) / 256, 1, kc), dim3(256), 0, s, visual, enc_w, ms, k0,
-                         l.w_off, l.b_off, B, l.cin, l.h_in, l.h_out, dst);
+      const int bands = (l.h_out + STEM_ROWS - 1) / STEM_ROWS;
+      const size_t lds = ((size_t)l.cin * (2 * STEM_ROWS + 1) * (l.h_in + 2) + 9 * (size_t)l.cin * 32) * sizeof(float);
+      hipLaunchKernelGGL((stem_bf16_kernel<16>), dim3(bands, B, kc), dim3(256), lds, s, visual, enc_w, ms, k0, l.w_off,
+                         l.b_off, B, l.cin, l.h_in, l.h_out, dst);
     } else if (l.kind == L_DW) {
       // runs of 4 outputs per thread once there are plenty of threads; single outputs for small launches
       const long total1 = (long)B * l.h_out * l.h_out * (l.cout / 8);
