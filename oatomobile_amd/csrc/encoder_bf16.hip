@@ -385,6 +385,116 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
   }
 }
 
+// ---- streaming GEMM for the early, HBM-bound layers (Cin <= 32: one K chunk) ----
+// The CT weight tiles (one 16-byte operand each) stay in registers; a wave walks a strided list of 32-pixel groups:
+// load 2 pixel operands -> CT*2 MFMAs -> bias/ReLU6/residual -> LDS-staged 16-byte NHWC stores, with the next
+// group's operands requested before the current epilogue.  Amortises the per-wave set-up the one-shot kernel pays
+// per 6 KB of output (its waves live ~6 us, PMC) and keeps more bytes in flight per CU.
+template <int CT>
+__global__ __launch_bounds__(256) void pw_stream_bf16_kernel(const bf16_t* __restrict__ in,
+                                                              const bf16_t* __restrict__ whbase,
+                                                              const float* __restrict__ wbase, size_t model_stride,
+                                                              int k0, size_t w_off, size_t b_off,
+                                                              const bf16_t* __restrict__ res, bf16_t* __restrict__ out,
+                                                              int M, int Cin, int Cout, int relu6,
+                                                              size_t act_model_stride_in, size_t act_model_stride_out,
+                                                              int groups_per_wave) {
+  constexpr int PT = 2;
+  constexpr int ROWB = CT * 32 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][PT * 16 * ROWB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.z;
+  const int ctile0 = blockIdx.y * CT;
+  const bf16_t* A = whbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const bf16_t* X = in + (size_t)k * act_model_stride_in;
+  const bf16_t* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
+  bf16_t* O = out + (size_t)k * act_model_stride_out;
+  unsigned char* st = stage[wave];
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  const bool kval = 8 * q < Cin;
+
+  uint4 av[CT];
+  float4 bb[CT];
+  bool cval[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + n;
+    av[ct] = (kval && co < Cout) ? *reinterpret_cast<const uint4*>(A + (size_t)co * Cin + 8 * q) : zero;
+    const int cb = (ctile0 + ct) * 16 + 4 * q;
+    cval[ct] = cb < Cout;
+    bb[ct] = cval[ct] ? *reinterpret_cast<const float4*>(bias + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int n_groups = (M + 31) / 32;
+  const int g0 = (blockIdx.x * 4 + wave) * groups_per_wave;
+  const int g1 = min(n_groups, g0 + groups_per_wave);
+  auto load_b = [&](int g, int pt) -> uint4 {
+    const int p = g * 32 + pt * 16 + n;
+    return (kval && g < g1) ? *reinterpret_cast<const uint4*>(X + (size_t)min(p, M - 1) * Cin + 8 * q) : zero;
+  };
+  uint4 b0 = load_b(g0, 0), b1 = load_b(g0, 1);
+#pragma unroll 1
+  for (int g = g0; g < g1; ++g) {
+    const uint4 c0 = b0, c1 = b1;
+    b0 = load_b(g + 1, 0);  // next group in flight during this group's MFMAs + epilogue
+    b1 = load_b(g + 1, 1);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[ct]), as_bf16x8(c0), z4, 0, 0, 0);
+      const f32x4 r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[ct]), as_bf16x8(c1), z4, 0, 0, 0);
+      const int co = (ctile0 + ct) * 16 + 4 * q;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const f32x4 a4 = pt == 0 ? r0 : r1;
+        const int p = g * 32 + pt * 16 + n;
+        float4 v = make_float4(a4[0] + bb[ct].x, a4[1] + bb[ct].y, a4[2] + bb[ct].z, a4[3] + bb[ct].w);
+        if (R != nullptr && cval[ct] && p < M) {
+          const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+          v.x += bf2f(r.x & 0xffffu);
+          v.y += bf2f(r.x >> 16);
+          v.z += bf2f(r.y & 0xffffu);
+          v.w += bf2f(r.y >> 16);
+        }
+        if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+        uint2 o;
+        o.x = pack2(v.x, v.y);
+        o.y = pack2(v.z, v.w);
+        *reinterpret_cast<uint2*>(st + (pt * 16 + n) * ROWB + ct * 32 + q * 8) = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = CT * 2, CHUNKS = PT * 16 * CPR;
+#pragma unroll
+    for (int j = 0; j < (CHUNKS + 63) / 64; ++j) {
+      const int c = lane + 64 * j;
+      if (c < CHUNKS) {
+        const int row = c / CPR, col = c - row * CPR;
+        const int p = g * 32 + row, co = ctile0 * 16 + col * 8;
+        if (p < M && co < Cout)
+          *reinterpret_cast<uint4*>(O + (size_t)p * Cout + co) = *reinterpret_cast<const uint4*>(st + row * ROWB + col * 16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the stage is rewritten by the next group
+  }
+}
+
+template <int CT>
+void launch_stream(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc, const Layer& l,
+                   const bf16_t* res, void* dst, int M, hipStream_t s) {
+  const int n_groups = (M + 31) / 32, n_ct = (l.cout + 15) / 16;
+  // ~8 waves per SIMD worth of blocks, each wave walking a contiguous run of groups
+  const int cgroups = (n_ct + CT - 1) / CT;
+  int gpw = (int)(((long)n_groups * cgroups * kc + 8191) / 8192);
+  if (gpw < 1) gpw = 1;
+  if (gpw > 16) gpw = 16;
+  const dim3 grid((n_groups + 4 * gpw - 1) / (4 * gpw), cgroups, kc);
+  hipLaunchKernelGGL((pw_stream_bf16_kernel<CT>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off, l.b_off, res,
+                     reinterpret_cast<bf16_t*>(dst), M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout,
+                     gpw);
+}
+
 // ---- LDS-tiled block GEMM for the compute-heavy layers (13x13 / 7x7 / 4x4 stages with many observations) ----
 // Block tile: 128 pixels x (32*WN) channels, K steps of 32, double-buffered LDS.  Each operand row is read from
 // L2 once per block instead of once per wave tile (the register-direct kernel above re-reads operands ~60x on these
@@ -575,6 +685,12 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
                   const Layer& l, const bf16_t* res, void* dst, int M, bool out_f32, bool pool, hipStream_t s) {
   const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   auto jobs = [&](int ct, int pt) { return ((n_pt + pt - 1) / pt) * ((n_ct + ct - 1) / ct) * kc; };
+  // early layers (one K chunk, lots of pixels): streaming GEMM with register-resident weights
+  if (l.cin <= 32 && !out_f32 && M >= 32768) {
+    if (n_ct == 1) return launch_stream<1>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+    if (n_ct == 2) return launch_stream<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+    return launch_stream<6>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+  }
   // compute-heavy shapes (K >= 64 and enough 128-pixel tiles to fill the chip): LDS-tiled block GEMM
   if (l.cin >= 64 && M >= 1024) {
     const long blocks128 = (long)((M + 127) / 128) * ((l.cout + 127) / 128) * kc;
