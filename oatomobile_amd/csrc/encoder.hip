@@ -31,35 +31,84 @@ __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6
 // K1: bilinear (H,W)->(O,O), align_corners=True, then swap H/W.  out[b][c][i][j] = interp[b][c][j][i].
 // ATen computes scale=(in-1)/(out-1) and src=scale*dst in fp32 (UpSample.h area_pixel_compute_*).
 // ------------------------------------------------------------------------------------------------
-__global__ void transform_kernel(const float* __restrict__ in, int B, int C, int H, int W, int channels_last, int O,
-                                 float* __restrict__ out) {
+// ATen rounds scale*dst to fp32 before taking the fraction (UpSample.h area_pixel_compute_source_index); hipcc's
+// default fp-contract=fast would fuse the product into the subtraction and change lambda by up to half an ulp of
+// the coordinate (1e-5 at 199), so contraction is switched off for exactly this computation.
+__device__ __forceinline__ void src_coord(float scale, int dst, int size, int& lo, int& hi, float& lambda) {
+#pragma clang fp contract(off)
+  const float f = scale * (float)dst;
+  lo = (int)f;
+  hi = lo + (lo < size - 1 ? 1 : 0);
+  lambda = f - (float)lo;
+}
+
+__device__ __forceinline__ float bilerp_fetch(const float* __restrict__ in, int b, int c, int y, int x, int C, int H,
+                                              int W, int channels_last) {
+  return channels_last ? in[(((size_t)b * H + y) * W + x) * C + c] : in[(((size_t)b * C + c) * H + y) * W + x];
+}
+
+// Tiled through LDS: output (i, j) samples input row ~ j*scale and column ~ i*scale, so a naive thread-per-output
+// mapping reads one input ROW per consecutive thread.  A block owns a TxT output tile, stages the matching input
+// patch with coalesced row reads, then every thread interpolates from LDS and writes NCHW rows coalesced.
+constexpr int TR_T = 32;       // output tile edge
+constexpr int TR_P = 2 * TR_T + 4;  // input patch edge bound for scale <= 2.02 (200 -> 100)
+__global__ __launch_bounds__(256) void transform_kernel(const float* __restrict__ in, int B, int C, int H, int W,
+                                                         int channels_last, int O, float* __restrict__ out) {
+  extern __shared__ float patch[];  // [C][py][px]
+  const float sh = O > 1 ? (float)(H - 1) / (float)(O - 1) : 0.f;
+  const float sw = O > 1 ? (float)(W - 1) / (float)(O - 1) : 0.f;
+  const int tiles = (O + TR_T - 1) / TR_T;
+  const int b = blockIdx.z, ti = blockIdx.y, tj = blockIdx.x;  // ti: output rows i (input x), tj: output cols j (input y)
+  const int i0 = ti * TR_T, j0 = tj * TR_T;
+  const int y0 = (int)(sh * (float)j0), x0 = (int)(sw * (float)i0);
+  const int py = min(TR_P, H - y0), px = min(TR_P, W - x0);
+  const int tid = threadIdx.x;
+  (void)tiles;
+  if (channels_last) {
+    for (int e = tid; e < py * px * C; e += 256) {
+      const int c = e % C, x = (e / C) % px, y = e / (C * px);
+      patch[(c * TR_P + y) * TR_P + x] = in[(((size_t)b * H + y0 + y) * W + x0 + x) * C + c];
+    }
+  } else {
+    for (int e = tid; e < C * py * px; e += 256) {
+      const int x = e % px, y = (e / px) % py, c = e / (px * py);
+      patch[(c * TR_P + y) * TR_P + x] = in[(((size_t)b * C + c) * H + y0 + y) * W + x0 + x];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < C * TR_T * TR_T; e += 256) {
+    const int jl = e % TR_T, il = (e / TR_T) % TR_T, c = e / (TR_T * TR_T);
+    const int i = i0 + il, j = j0 + jl;
+    if (i >= O || j >= O) continue;
+    int ya, yb, xa, xb;
+    float ly, lx;
+    src_coord(sh, j, H, ya, yb, ly);
+    src_coord(sw, i, W, xa, xb, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* pc = patch + c * TR_P * TR_P;
+    const float v00 = pc[(ya - y0) * TR_P + xa - x0], v01 = pc[(ya - y0) * TR_P + xb - x0];
+    const float v10 = pc[(yb - y0) * TR_P + xa - x0], v11 = pc[(yb - y0) * TR_P + xb - x0];
+    out[(((size_t)b * C + c) * O + i) * O + j] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
+// generic fallback (any scale): one thread per output element
+__global__ void transform_generic_kernel(const float* __restrict__ in, int B, int C, int H, int W, int channels_last,
+                                         int O, float* __restrict__ out) {
   const int total = B * C * O * O;
   const float sh = O > 1 ? (float)(H - 1) / (float)(O - 1) : 0.f;
   const float sw = O > 1 ? (float)(W - 1) / (float)(O - 1) : 0.f;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int j = idx % O;          // output column  == interpolated row
-    const int i = (idx / O) % O;    // output row     == interpolated column
-    const int c = (idx / (O * O)) % C;
-    const int b = idx / (O * O * C);
-    const float fy = sh * (float)j, fx = sw * (float)i;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const int j = idx % O, i = (idx / O) % O, c = (idx / (O * O)) % C, b = idx / (O * O * C);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_coord(sh, j, H, y0, y1, ly);
+    src_coord(sw, i, W, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    float v00, v01, v10, v11;
-    if (channels_last) {
-      const float* p = in + (size_t)b * H * W * C + c;
-      v00 = p[((size_t)y0 * W + x0) * C];
-      v01 = p[((size_t)y0 * W + x1) * C];
-      v10 = p[((size_t)y1 * W + x0) * C];
-      v11 = p[((size_t)y1 * W + x1) * C];
-    } else {
-      const float* p = in + ((size_t)b * C + c) * H * W;
-      v00 = p[(size_t)y0 * W + x0];
-      v01 = p[(size_t)y0 * W + x1];
-      v10 = p[(size_t)y1 * W + x0];
-      v11 = p[(size_t)y1 * W + x1];
-    }
+    const float v00 = bilerp_fetch(in, b, c, y0, x0, C, H, W, channels_last);
+    const float v01 = bilerp_fetch(in, b, c, y0, x1, C, H, W, channels_last);
+    const float v10 = bilerp_fetch(in, b, c, y1, x0, C, H, W, channels_last);
+    const float v11 = bilerp_fetch(in, b, c, y1, x1, C, H, W, channels_last);
     out[idx] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
   }
 }
@@ -650,10 +699,18 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
 
 hipError_t launch_transform(const float* in, int B, int C, int H, int W, int channels_last, int out_hw, float* out,
                             hipStream_t s) {
-  const int total = B * C * out_hw * out_hw;
-  int grid = (total + 255) / 256;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(transform_kernel, dim3(grid), dim3(256), 0, s, in, B, C, H, W, channels_last, out_hw, out);
+  const float scale = out_hw > 1 ? (float)((H > W ? H : W) - 1) / (float)(out_hw - 1) : 0.f;
+  const size_t lds = (size_t)C * TR_P * TR_P * sizeof(float);
+  if (scale * (TR_T - 1) + 3.f <= (float)TR_P && lds <= 64 * 1024) {
+    const int tiles = (out_hw + TR_T - 1) / TR_T;
+    hipLaunchKernelGGL(transform_kernel, dim3(tiles, tiles, B), dim3(256), lds, s, in, B, C, H, W, channels_last, out_hw,
+                       out);
+  } else {
+    const int total = B * C * out_hw * out_hw;
+    int grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(transform_generic_kernel, dim3(grid), dim3(256), 0, s, in, B, C, H, W, channels_last, out_hw, out);
+  }
   return hipGetLastError();
 }
 
