@@ -50,33 +50,53 @@ __device__ __forceinline__ float bilerp_fetch(const float* __restrict__ in, int 
 // Tiled through LDS: output (i, j) samples input row ~ j*scale and column ~ i*scale, so a naive thread-per-output
 // mapping reads one input ROW per consecutive thread.  A block owns a TxT output tile, stages the matching input
 // patch with coalesced row reads, then every thread interpolates from LDS and writes NCHW rows coalesced.
-constexpr int TR_T = 32;       // output tile edge
+constexpr int TR_T = 32;            // output tile edge
 constexpr int TR_P = 2 * TR_T + 4;  // input patch edge bound for scale <= 2.02 (200 -> 100)
-__global__ __launch_bounds__(256) void transform_kernel(const float* __restrict__ in, int B, int C, int H, int W,
-                                                         int channels_last, int O, float* __restrict__ out) {
-  extern __shared__ float patch[];  // [C][py][px]
+template <int C, bool CL>
+__global__ __launch_bounds__(256) void transform_kernel(const float* __restrict__ in, int H, int W, int O,
+                                                         float* __restrict__ out) {
+  // The patch keeps the memory order of the input; all staging loads of a thread are issued before the first LDS
+  // write (the kernel is pure latency otherwise), and the row pitch is odd so the interpolation reads (consecutive
+  // lanes sit two patch rows apart) spread over the banks.
+  constexpr int ROW = CL ? TR_P * C : TR_P;
+  constexpr int NROWS = CL ? TR_P : TR_P * C;
+  constexpr int PITCH = ROW + 1;
+  constexpr int TOTAL = ROW * NROWS;
+  constexpr int ITER = (TOTAL + 255) / 256;
+  extern __shared__ float patch[];
   const float sh = O > 1 ? (float)(H - 1) / (float)(O - 1) : 0.f;
   const float sw = O > 1 ? (float)(W - 1) / (float)(O - 1) : 0.f;
-  const int tiles = (O + TR_T - 1) / TR_T;
   const int b = blockIdx.z, ti = blockIdx.y, tj = blockIdx.x;  // ti: output rows i (input x), tj: output cols j (input y)
   const int i0 = ti * TR_T, j0 = tj * TR_T;
   const int y0 = (int)(sh * (float)j0), x0 = (int)(sw * (float)i0);
   const int py = min(TR_P, H - y0), px = min(TR_P, W - x0);
   const int tid = threadIdx.x;
-  (void)tiles;
-  if (channels_last) {
-    for (int e = tid; e < py * px * C; e += 256) {
-      const int c = e % C, x = (e / C) % px, y = e / (C * px);
-      patch[(c * TR_P + y) * TR_P + x] = in[(((size_t)b * H + y0 + y) * W + x0 + x) * C + c];
+  float v[ITER];
+#pragma unroll
+  for (int k = 0; k < ITER; ++k) {
+    const int e = tid + 256 * k, r = e / ROW, t = e - r * ROW;
+    bool ok;
+    const float* src;
+    if (CL) {
+      ok = r < py && t < px * C;
+      src = in + (((size_t)b * H + y0 + r) * W + x0) * C + t;
+    } else {
+      const int c = r / TR_P, y = r - c * TR_P;
+      ok = c < C && y < py && t < px;
+      src = in + (((size_t)b * C + c) * H + y0 + y) * W + x0 + t;
     }
-  } else {
-    for (int e = tid; e < C * py * px; e += 256) {
-      const int x = e % px, y = (e / px) % py, c = e / (px * py);
-      patch[(c * TR_P + y) * TR_P + x] = in[(((size_t)b * C + c) * H + y0 + y) * W + x0 + x];
-    }
+    v[k] = ok ? *src : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < ITER; ++k) {
+    const int e = tid + 256 * k, r = e / ROW, t = e - r * ROW;
+    if (e < TOTAL) patch[r * PITCH + t] = v[k];
   }
   __syncthreads();
-  for (int e = tid; e < C * TR_T * TR_T; e += 256) {
+  constexpr int XS = CL ? C : 1;  // element stride along x
+#pragma unroll
+  for (int k = 0; k < C * TR_T * TR_T / 256; ++k) {
+    const int e = tid + 256 * k;
     const int jl = e % TR_T, il = (e / TR_T) % TR_T, c = e / (TR_T * TR_T);
     const int i = i0 + il, j = j0 + jl;
     if (i >= O || j >= O) continue;
@@ -85,11 +105,20 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
     src_coord(sh, j, H, ya, yb, ly);
     src_coord(sw, i, W, xa, xb, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* pc = patch + c * TR_P * TR_P;
-    const float v00 = pc[(ya - y0) * TR_P + xa - x0], v01 = pc[(ya - y0) * TR_P + xb - x0];
-    const float v10 = pc[(yb - y0) * TR_P + xa - x0], v11 = pc[(yb - y0) * TR_P + xb - x0];
+    const float* pc = CL ? patch + c : patch + c * TR_P * PITCH;
+    const float v00 = pc[(ya - y0) * PITCH + (xa - x0) * XS], v01 = pc[(ya - y0) * PITCH + (xb - x0) * XS];
+    const float v10 = pc[(yb - y0) * PITCH + (xa - x0) * XS], v11 = pc[(yb - y0) * PITCH + (xb - x0) * XS];
     out[(((size_t)b * C + c) * O + i) * O + j] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
   }
+}
+
+template <int C, bool CL>
+void launch_transform_tiled(const float* in, int B, int H, int W, int O, float* out, hipStream_t s) {
+  constexpr int ROW = CL ? TR_P * C : TR_P;
+  constexpr int NROWS = CL ? TR_P : TR_P * C;
+  const int tiles = (O + TR_T - 1) / TR_T;
+  hipLaunchKernelGGL((transform_kernel<C, CL>), dim3(tiles, tiles, B), dim3(256), (size_t)(ROW + 1) * NROWS * sizeof(float),
+                     s, in, H, W, O, out);
 }
 
 // generic fallback (any scale): one thread per output element
@@ -700,11 +729,15 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
 hipError_t launch_transform(const float* in, int B, int C, int H, int W, int channels_last, int out_hw, float* out,
                             hipStream_t s) {
   const float scale = out_hw > 1 ? (float)((H > W ? H : W) - 1) / (float)(out_hw - 1) : 0.f;
-  const size_t lds = (size_t)C * TR_P * TR_P * sizeof(float);
-  if (scale * (TR_T - 1) + 3.f <= (float)TR_P && lds <= 64 * 1024) {
-    const int tiles = (out_hw + TR_T - 1) / TR_T;
-    hipLaunchKernelGGL(transform_kernel, dim3(tiles, tiles, B), dim3(256), lds, s, in, B, C, H, W, channels_last, out_hw,
-                       out);
+  const bool tiled = scale * (TR_T - 1) + 3.f <= (float)TR_P && C >= 1 && C <= 3;
+  if (tiled && channels_last) {
+    if (C == 1) launch_transform_tiled<1, true>(in, B, H, W, out_hw, out, s);
+    if (C == 2) launch_transform_tiled<2, true>(in, B, H, W, out_hw, out, s);
+    if (C == 3) launch_transform_tiled<3, true>(in, B, H, W, out_hw, out, s);
+  } else if (tiled) {
+    if (C == 1) launch_transform_tiled<1, false>(in, B, H, W, out_hw, out, s);
+    if (C == 2) launch_transform_tiled<2, false>(in, B, H, W, out_hw, out, s);
+    if (C == 3) launch_transform_tiled<3, false>(in, B, H, W, out_hw, out, s);
   } else {
     const int total = B * C * out_hw * out_hw;
     int grid = (total + 255) / 256;
