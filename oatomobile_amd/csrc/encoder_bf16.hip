@@ -180,6 +180,159 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const bf16_t* __restrict__
   }
 }
 
+// ---- depthwise 3x3, row-streaming variant (large launches).  A wave owns (model, observation, band of output rows,
+// 64-lane group of (run of R outputs, 8 channels)) and walks down the band; everything row-dependent is wave-uniform,
+// so each input row gets a buffer descriptor built on the scalar unit (num_records = 0 for rows outside the image)
+// and every tap outside the row lands outside the descriptor: the hardware returns zeros for the padding and the
+// loop body has no address arithmetic, no predication and no weight loads.  Loads of the next row(s) are issued
+// before the current row is computed.  fp32 math runs on v_pk_fma_f32; bf16 packing on v_cvt_pk_bf16_f32.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_srd(const bf16_t* row, int bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(row);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x2 bfpair(unsigned u) {
+  f32x2 r;
+  r.x = __uint_as_float(u << 16);
+  r.y = __uint_as_float(u & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ unsigned pack_relu6(f32x2 v) {
+  v = __builtin_elementwise_min(__builtin_elementwise_max(v, f32x2{0.f, 0.f}), f32x2{6.f, 6.f});
+  union {
+    bf16x2 h;
+    unsigned u;
+  } c;
+  c.h = __builtin_convertvector(v, bf16x2);
+  return c.u;
+}
+
+constexpr int DW_OOB = 0x40000000;  // byte offset beyond any row descriptor
+
+template <int STRIDE, int R>
+__global__ __launch_bounds__(256, 2) void dw_rows_bf16_kernel(const bf16_t* __restrict__ in,
+                                                               const float* __restrict__ wbase, size_t model_stride,
+                                                               int k0, size_t w_off, size_t b_off, int B, int C, int Hin,
+                                                               int Ho, int band_rows, int bands, int lane_groups,
+                                                               bf16_t* __restrict__ out) {
+  constexpr int COLS = (R - 1) * STRIDE + 3;
+  constexpr int NEW = STRIDE;  // new input rows per output row
+  const int k = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  int wi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (wi >= B * bands * lane_groups) return;
+  const int lg = wi % lane_groups;
+  wi /= lane_groups;
+  const int band = wi % bands, b = wi / bands;
+  const int C8 = C >> 3, runs = (Ho + R - 1) / R;
+  const int li = lg * 64 + lane;
+  const bool active = li < runs * C8;
+  const int run = active ? li / C8 : 0, c8 = active ? li - run * C8 : 0;
+  const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off + c8 * 8;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off + c8 * 8;
+  f32x2 wt[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float4 w0 = *reinterpret_cast<const float4*>(w + t * C);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + t * C + 4);
+    wt[t][0] = f32x2{w0.x, w0.y};
+    wt[t][1] = f32x2{w0.z, w0.w};
+    wt[t][2] = f32x2{w1.x, w1.y};
+    wt[t][3] = f32x2{w1.z, w1.w};
+  }
+  f32x2 bb[4];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + 4);
+    bb[0] = f32x2{b0.x, b0.y};
+    bb[1] = f32x2{b0.z, b0.w};
+    bb[2] = f32x2{b1.x, b1.y};
+    bb[3] = f32x2{b1.z, b1.w};
+  }
+  int voff[COLS], ooff[R];
+  const int ix0 = run * R * STRIDE - 1;
+#pragma unroll
+  for (int j = 0; j < COLS; ++j) {
+    const int ix = ix0 + j;
+    voff[j] = (active && ix >= 0 && ix < Hin) ? (ix * C + c8 * 8) * 2 : DW_OOB;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int ox = run * R + r;
+    ooff[r] = (active && ox < Ho) ? (ox * C + c8 * 8) * 2 : DW_OOB;
+  }
+  const int in_row_bytes = Hin * C * 2, out_row_bytes = Ho * C * 2;
+  const bf16_t* img = in + ((size_t)k * B + b) * Hin * Hin * C;
+  bf16_t* oimg = out + ((size_t)k * B + b) * Ho * Ho * C;
+  auto load_row = [&](int iy, u32x4(&row)[COLS]) {
+    const bool ok = iy >= 0 && iy < Hin;
+    const __amdgpu_buffer_rsrc_t srd = row_srd(img + (size_t)(ok ? iy : 0) * Hin * C, ok ? in_row_bytes : 0);
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) row[j] = __builtin_amdgcn_raw_buffer_load_b128(srd, voff[j], 0, 0);
+  };
+  const int oy0 = band * band_rows, oy1 = min(Ho, oy0 + band_rows);
+  u32x4 win[3][COLS], nxt[NEW][COLS];
+  load_row(oy0 * STRIDE - 1, win[0]);
+  load_row(oy0 * STRIDE, win[1]);
+  load_row(oy0 * STRIDE + 1, win[2]);
+#pragma unroll 1
+  for (int oy = oy0; oy < oy1; ++oy) {
+    if (oy + 1 < oy1) {  // rows the next output row adds, in flight under this row's math
+#pragma unroll
+      for (int i = 0; i < NEW; ++i) load_row((oy + 1) * STRIDE + 2 - NEW + i, nxt[i]);
+    }
+    f32x2 acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r][e] = bb[e];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int j = 0; j < COLS; ++j) {
+        const u32x4 v = win[ky][j];
+        const f32x2 f[4] = {bfpair(v.x), bfpair(v.y), bfpair(v.z), bfpair(v.w)};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int kx = j - r * STRIDE;
+          if (kx >= 0 && kx < 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][e] = __builtin_elementwise_fma(f[e], wt[ky * 3 + kx][e], acc[r][e]);
+          }
+        }
+      }
+    }
+    const __amdgpu_buffer_rsrc_t osrd = row_srd(oimg + (size_t)oy * Ho * C, out_row_bytes);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      u32x4 o;
+      o.x = pack_relu6(acc[r][0]);
+      o.y = pack_relu6(acc[r][1]);
+      o.z = pack_relu6(acc[r][2]);
+      o.w = pack_relu6(acc[r][3]);
+      __builtin_amdgcn_raw_buffer_store_b128(o, osrd, ooff[r], 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      if (STRIDE == 1) {
+        win[0][j] = win[1][j];
+        win[1][j] = win[2][j];
+        win[2][j] = nxt[0][j];
+      } else {
+        win[0][j] = win[2][j];
+        win[1][j] = nxt[0][j];
+        win[2][j] = nxt[1][j];
+      }
+    }
+  }
+}
+
 // ---- pointwise GEMM on v_mfma_f32_16x16x32_bf16 (see encoder.hip pw_kernel for the tiling / KSPLIT scheme) ----
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) {
   union {
@@ -746,7 +899,25 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     hipLaunchKernelGGL((dw_bf16_kernel<S_, R_>), dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), 0, s, \
                        src, enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);                 \
   }
-      if (total1 * kc >= 4 * 65536) {
+      if (total1 * kc >= 16 * 65536) {
+        // row-streaming kernel: waves = observations x bands x lane groups; bands sized for >= ~8k waves
+        const int R = l.stride == 1 ? 4 : 2;
+        const int runs = (l.h_out + R - 1) / R;
+        const int lane_groups = (runs * (l.cout / 8) + 63) / 64;
+        int bands = (int)((8192 + (long)B * kc * lane_groups - 1) / ((long)B * kc * lane_groups));
+        if (bands > (l.h_out + 3) / 4) bands = (l.h_out + 3) / 4;
+        if (bands < 1) bands = 1;
+        const int band_rows = (l.h_out + bands - 1) / bands;
+        bands = (l.h_out + band_rows - 1) / band_rows;
+        const long waves = (long)B * bands * lane_groups;
+        const dim3 grid((unsigned)((waves + 3) / 4), 1, kc);
+        if (l.stride == 1)
+          hipLaunchKernelGGL((dw_rows_bf16_kernel<1, 4>), grid, dim3(256), 0, s, src, enc_w, ms, k0, l.w_off, l.b_off, B,
+                             l.cout, l.h_in, l.h_out, band_rows, bands, lane_groups, dst);
+        else
+          hipLaunchKernelGGL((dw_rows_bf16_kernel<2, 2>), grid, dim3(256), 0, s, src, enc_w, ms, k0, l.w_off, l.b_off, B,
+                             l.cout, l.h_in, l.h_out, band_rows, bands, lane_groups, dst);
+      } else if (total1 * kc >= 4 * 65536) {
         if (l.stride == 1) DW_GO(1, 4) else DW_GO(2, 4)
       } else {
         if (l.stride == 1) DW_GO(1, 1) else DW_GO(2, 1)

@@ -156,6 +156,32 @@ def test_bf16_encoder_close_to_fp32(dev):
   assert not np.array_equal(z16, z32)  # really a different arithmetic
 
 
+def test_bf16_encoder_large_batch_kernels_match_small_batch(dev):
+  """The row-streaming depthwise kernels (buffer-descriptor padding, packed fp32 math) only engage for launches of
+  >= 1M (pixel, 8-channel) items: 640 observations put every one of the 17 depthwise layers on that path.  Same
+  arithmetic as the small-batch kernels except bf16 rounding via v_cvt_pk_bf16_f32 and fma pairing."""
+  B = 640
+  m = hip_model(23, dev, max_batch=B)
+  m.encoder_dtype = "bf16"
+  rng = np.random.default_rng(77)
+  vis = torch.from_numpy(rng.random((B, 2, 100, 100), dtype=np.float32)).to(dev)
+  vis[:, :, 40:60, 30:70] = 0  # empty patches, like a BEV
+  ctx = dict(visual_features=vis,
+             velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
+             is_at_traffic_light=torch.from_numpy(rng.integers(0, 2, size=(B, 1)).astype(np.float32)).to(dev),
+             traffic_light_state=torch.from_numpy(rng.integers(0, 4, size=(B, 1)).astype(np.float32)).to(dev))
+  z_big = m._params(**ctx).cpu().numpy()
+  z_small = np.concatenate([m._params(**{k: v[i:i + 4].contiguous() for k, v in ctx.items()}).cpu().numpy()
+                            for i in range(0, 64, 4)])
+  assert np.isfinite(z_big).all()
+  d = np.abs(z_big[:64] - z_small)
+  print("large vs small batch kernels: max|dz| = %.3g of max|z| = %.3g" % (d.max(), np.abs(z_small).max()))
+  assert d.max() <= 0.03 * np.abs(z_small).max()
+  # rows are independent: the tail of the batch equals the same observations computed alone
+  z_tail = m._params(**{k: v[B - 4:].contiguous() for k, v in ctx.items()}).cpu().numpy()
+  assert np.abs(z_big[B - 4:] - z_tail).max() <= 0.03 * np.abs(z_small).max()
+
+
 def test_params_missing_key_raises(dev):
   m = hip_model(5, dev)
   with pytest.raises(ValueError, match="Missing `velocity`"):
