@@ -63,9 +63,16 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
 
 // bf16 encoder (encoder_bf16.hip): bf16 NHWC activations, bf16 pointwise weights (enc_wh: same offsets as the fp32
 // blob, 2 bytes per element), fp32 accumulation / bias / ReLU6 / residual math; features.18 is written in fp32.
+//   fused_blocks: the first `fused_blocks` inverted-residual blocks (at most the large-image stages the fused kernel
+//   supports) run as one row-streaming kernel each (encoder_bf16_irb.hip); -1 = choose by batch.
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
-                               float* feat, hipStream_t s);
+                               float* feat, int fused_blocks, hipStream_t s);
+
+bool irb_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
+hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
+                           const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
+                           const unsigned short* x, unsigned short* y, hipStream_t s);
 
 hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                               size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);

@@ -879,10 +879,34 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
 
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
-                               float* feat, hipStream_t s) {
+                               float* feat, int fused_blocks, hipStream_t s) {
   const size_t ms = plan.blob_floats;
+  // leading inverted-residual blocks as one fused kernel each; auto: whenever a launch has >= 256 (model, observation)
+  // pairs to spread over the CUs (one workgroup per pair and row band)
+  if (fused_blocks < 0) fused_blocks = (long)B * kc >= 256 ? 7 : 0;
+  std::vector<char> in_block(plan.layers.size(), 0);
+  std::vector<int> block_of(plan.layers.size(), -1);
+  for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
+    const FusedBlock& fb = plan.blocks[bi];
+    if (!irb_bf16_supported(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw], plan.layers[fb.project]))
+      continue;
+    if (fb.expand >= 0) in_block[fb.expand] = 1;
+    in_block[fb.dw] = 1;
+    in_block[fb.project] = 2;  // the block is launched where its last layer sits
+    block_of[fb.project] = (int)bi;
+  }
   for (size_t li = 0; li < plan.layers.size(); ++li) {
     const Layer& l = plan.layers[li];
+    if (in_block[li] == 1) continue;
+    if (in_block[li] == 2) {
+      const FusedBlock& fb = plan.blocks[block_of[li]];
+      hipError_t e = launch_irb_bf16(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw],
+                                     plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc, B,
+                                     reinterpret_cast<const unsigned short*>(bufs[fb.src]),
+                                     reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     bf16_t* dst = reinterpret_cast<bf16_t*>(bufs[l.dst]);
     if (l.kind == L_STEM) {
       const int bands = (l.h_out + STEM_ROWS - 1) / STEM_ROWS;

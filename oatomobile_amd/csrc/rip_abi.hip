@@ -189,7 +189,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
   if (enc_dtype == RIP_ENC_BF16) {
     HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
-                                feat_dev, (hipStream_t)stream));
+                                feat_dev, h->encoder_fused, (hipStream_t)stream));
     return RIP_OK;
   }
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
