@@ -189,6 +189,14 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const bf16_t* __restrict__
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 u) {
+  union {
+    u32x4 u;
+    bf16x8 v;
+  } c;
+  c.u = u;
+  return c.v;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_srd(const bf16_t* row, int bytes) {
   const unsigned long long p = reinterpret_cast<unsigned long long>(row);
@@ -804,6 +812,165 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   }
 }
 
+// ---- persistent variant of the block GEMM for the 7x7 / 4x4 stages with many observations ----
+// Same 128 x 32*WN tile and LDS layout, but a workgroup keeps its channel slice and walks a strided list of pixel
+// tiles, with the (tile, K-step) sequence flattened into one software pipeline: operand chunks are requested two
+// steps ahead (two register sets), so a tile's first K-step is already in flight during the previous tile's epilogue.
+// The one-shot kernel pays a full global -> LDS -> MFMA latency chain per tile, which with K = 64..160 (3-5 steps)
+// is most of its time (~110 TFLOP/s on the expand layers).  Outputs go straight from the accumulators (8-byte
+// stores; the 4 q-lanes of a pixel write 32 contiguous bytes).
+template <int WN>
+__global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __restrict__ in,
+                                                              const bf16_t* __restrict__ whbase,
+                                                              const float* __restrict__ wbase, size_t model_stride,
+                                                              int k0, size_t w_off, size_t b_off,
+                                                              const bf16_t* __restrict__ res, bf16_t* __restrict__ out,
+                                                              int M, int Cin, int Cout, int relu6,
+                                                              size_t act_model_stride_in, size_t act_model_stride_out,
+                                                              int n_ptiles) {
+  constexpr int BM = 128, BN = 32 * WN, LD = 40;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BN + BM) * LD];
+  auto As = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD; };
+  auto Bs = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD + BN * LD; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int wp = wave >> 1, wc = wave & 1;
+  const int k = blockIdx.z;
+  const int c0 = blockIdx.y * BN;
+  const bf16_t* A = whbase + (size_t)(k0 + k) * model_stride + w_off;
+  const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
+  const bf16_t* X = in + (size_t)k * act_model_stride_in;
+  const bf16_t* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
+  bf16_t* O = out + (size_t)k * act_model_stride_out;
+  const int nk = (Cin + 31) / 32;
+  const int nt = ((int)blockIdx.x < n_ptiles) ? (n_ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int total = nt * nk;
+  if (total == 0) return;
+
+  constexpr int A_CH = BN * 4 / 256, B_CH = BM * 4 / 256;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  // load stream position (tile, K-step), advanced once per load_tiles call
+  int l_tile = blockIdx.x, l_kt = 0;
+  auto load_tiles = [&](u32x4(&areg)[A_CH], u32x4(&breg)[B_CH]) __attribute__((always_inline)) {
+    const int p0 = l_tile * BM;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int e = tid + 256 * i, row = e >> 2, kk = l_kt * 32 + (e & 3) * 8;
+      const int co = c0 + row;
+      areg[i] = (co < Cout && kk < Cin) ? *reinterpret_cast<const u32x4*>(A + (size_t)co * Cin + kk) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int e = tid + 256 * i, row = e >> 2, kk = l_kt * 32 + (e & 3) * 8;
+      const int p = p0 + row;
+      breg[i] = (p < M && kk < Cin) ? *reinterpret_cast<const u32x4*>(X + (size_t)p * Cin + kk) : zero;
+    }
+    if (++l_kt == nk) {
+      l_kt = 0;
+      l_tile += gridDim.x;
+    }
+  };
+  auto store_tiles = [&](int buf, const u32x4(&areg)[A_CH], const u32x4(&breg)[B_CH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<u32x4*>(As(buf) + (e >> 2) * LD + (e & 3) * 8) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<u32x4*>(Bs(buf) + (e >> 2) * LD + (e & 3) * 8) = breg[i];
+    }
+  };
+
+  f32x4 acc[WN][4];
+#pragma unroll
+  for (int i = 0; i < WN; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 bb[WN];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    const int co = c0 + wc * 16 * WN + 16 * i + 4 * q;
+    bb[i] = co < Cout ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  int c_tile = blockIdx.x, c_kt = 0;  // compute stream position
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    u32x4 af[WN], bf[4];
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+      af[i] = *reinterpret_cast<const u32x4*>(As(buf) + (wc * 16 * WN + 16 * i + n) * LD + 8 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bf[j] = *reinterpret_cast<const u32x4*>(Bs(buf) + (wp * 64 + 16 * j + n) * LD + 8 * q);
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(af[i]), as_bf16x8(bf[j]), acc[i][j], 0, 0, 0);
+    if (++c_kt == nk) {  // tile finished: bias (+ residual) (+ ReLU6), store, restart the accumulators
+      const int p0 = c_tile * BM;
+#pragma unroll
+      for (int i = 0; i < WN; ++i) {
+        const int co = c0 + wc * 16 * WN + 16 * i + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = p0 + wp * 64 + 16 * j + n;
+          float4 v = make_float4(acc[i][j][0] + bb[i].x, acc[i][j][1] + bb[i].y, acc[i][j][2] + bb[i].z,
+                                 acc[i][j][3] + bb[i].w);
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p < M && co < Cout) {
+            if (R != nullptr) {
+              const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+              v.x += bf2f(r.x & 0xffffu);
+              v.y += bf2f(r.x >> 16);
+              v.z += bf2f(r.y & 0xffffu);
+              v.w += bf2f(r.y >> 16);
+            }
+            if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+            uint2 o;
+            o.x = pack2(v.x, v.y);
+            o.y = pack2(v.z, v.w);
+            *reinterpret_cast<uint2*>(O + (size_t)p * Cout + co) = o;
+          }
+        }
+      }
+      c_kt = 0;
+      c_tile += gridDim.x;
+    }
+  };
+
+  u32x4 a0[A_CH], b0[B_CH], a1[A_CH], b1[B_CH];
+  load_tiles(a0, b0);
+  if (total > 1) load_tiles(a1, b1);
+#pragma unroll 1
+  for (int s = 0; s < total; s += 2) {
+    store_tiles(0, a0, b0);
+    __syncthreads();
+    if (s + 2 < total) load_tiles(a0, b0);
+    compute(0);
+    if (s + 1 >= total) break;
+    store_tiles(1, a1, b1);
+    __syncthreads();
+    if (s + 3 < total) load_tiles(a1, b1);
+    compute(1);
+  }
+}
+
+template <int WN>
+void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc,
+                      const Layer& l, const bf16_t* res, void* dst, int M, hipStream_t s) {
+  const int n_ptiles = (M + 127) / 128, n_slices = (l.cout + 32 * WN - 1) / (32 * WN);
+  const int per_cu = WN == 4 ? 2 : 3;  // resident workgroups per CU (registers)
+  int px = (per_cu * 256 + n_slices * kc - 1) / (n_slices * kc);
+  if (px > n_ptiles) px = n_ptiles;
+  if (px < 1) px = 1;
+  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN>), dim3(px, n_slices, kc), dim3(256), 0, s, in, enc_wh, enc_w, ms, k0,
+                     l.w_off, l.b_off, res, reinterpret_cast<bf16_t*>(dst), M, l.cin, l.cout, l.relu6,
+                     (size_t)M * l.cin, (size_t)M * l.cout, n_ptiles);
+}
+
 template <int WN>
 void launch_gemm(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc, const Layer& l,
                  const bf16_t* res, void* dst, int M, bool out_f32, bool pool, hipStream_t s) {
@@ -847,6 +1014,11 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
   // compute-heavy shapes (K >= 64 and enough 128-pixel tiles to fill the chip): LDS-tiled block GEMM
   if (l.cin >= 64 && M >= 1024) {
     const long blocks128 = (long)((M + 127) / 128) * ((l.cout + 127) / 128) * kc;
+    // many more tiles than the chip holds at once: persistent workgroups with a cross-tile software pipeline
+    if (!out_f32 && !pool && blocks128 >= 192) {
+      if (l.cout > 64) return launch_gemm_pers<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+      return launch_gemm_pers<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+    }
     if (l.cout > 64 && blocks128 >= 192) return launch_gemm<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s);
     return launch_gemm<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s);
   }
