@@ -819,12 +819,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 // The one-shot kernel pays a full global -> LDS -> MFMA latency chain per tile, which with K = 64..160 (3-5 steps)
 // is most of its time (~110 TFLOP/s on the expand layers).  Outputs go straight from the accumulators (8-byte
 // stores; the 4 q-lanes of a pixel write 32 contiguous bytes).
-template <int WN>
+// POOL: features.18 -- the 16 pixels of a pixel tile are one 4x4 image; the epilogue averages them and writes fp32
+// [image][Cout] (the pooled feature the classifier reads) instead of bf16 activations.
+template <int WN, bool POOL>
 __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __restrict__ in,
                                                               const bf16_t* __restrict__ whbase,
                                                               const float* __restrict__ wbase, size_t model_stride,
                                                               int k0, size_t w_off, size_t b_off,
-                                                              const bf16_t* __restrict__ res, bf16_t* __restrict__ out,
+                                                              const bf16_t* __restrict__ res, void* __restrict__ outv,
                                                               int M, int Cin, int Cout, int relu6,
                                                               size_t act_model_stride_in, size_t act_model_stride_out,
                                                               int n_ptiles) {
@@ -841,7 +843,8 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
   const bf16_t* X = in + (size_t)k * act_model_stride_in;
   const bf16_t* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
-  bf16_t* O = out + (size_t)k * act_model_stride_out;
+  bf16_t* O = reinterpret_cast<bf16_t*>(outv) + (size_t)k * act_model_stride_out;
+  float* OF = reinterpret_cast<float*>(outv) + (size_t)k * act_model_stride_out;
   const int nk = (Cin + 31) / 32;
   const int nt = ((int)blockIdx.x < n_ptiles) ? (n_ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = nt * nk;
@@ -920,7 +923,16 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
           float4 v = make_float4(acc[i][j][0] + bb[i].x, acc[i][j][1] + bb[i].y, acc[i][j][2] + bb[i].z,
                                  acc[i][j][3] + bb[i].w);
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (p < M && co < Cout) {
+          if (POOL) {
+            if (relu6) v = make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w));
+            if (p >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = row_sum16(v.x) * 0.0625f;
+            v.y = row_sum16(v.y) * 0.0625f;
+            v.z = row_sum16(v.z) * 0.0625f;
+            v.w = row_sum16(v.w) * 0.0625f;
+            const int img = (p0 + wp * 64 + 16 * j) / 16;
+            if (n == 0 && img * 16 < M && co < Cout) *reinterpret_cast<float4*>(OF + (size_t)img * Cout + co) = v;
+          } else if (p < M && co < Cout) {
             if (R != nullptr) {
               const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
               v.x += bf2f(r.x & 0xffffu);
@@ -958,7 +970,7 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
   }
 }
 
-template <int WN>
+template <int WN, bool POOL>
 void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc,
                       const Layer& l, const bf16_t* res, void* dst, int M, hipStream_t s) {
   const int n_ptiles = (M + 127) / 128, n_slices = (l.cout + 32 * WN - 1) / (32 * WN);
@@ -966,9 +978,9 @@ void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w
   int px = (per_cu * 256 + n_slices * kc - 1) / (n_slices * kc);
   if (px > n_ptiles) px = n_ptiles;
   if (px < 1) px = 1;
-  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN>), dim3(px, n_slices, kc), dim3(256), 0, s, in, enc_wh, enc_w, ms, k0,
-                     l.w_off, l.b_off, res, reinterpret_cast<bf16_t*>(dst), M, l.cin, l.cout, l.relu6,
-                     (size_t)M * l.cin, (size_t)M * l.cout, n_ptiles);
+  const size_t sout = POOL ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
+  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN, POOL>), dim3(px, n_slices, kc), dim3(256), 0, s, in, enc_wh, enc_w, ms,
+                     k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, sout, n_ptiles);
 }
 
 template <int WN>
@@ -1016,9 +1028,10 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
     const long blocks128 = (long)((M + 127) / 128) * ((l.cout + 127) / 128) * kc;
     // many more tiles than the chip holds at once: persistent workgroups with a cross-tile software pipeline
     if (!out_f32 && !pool && blocks128 >= 192) {
-      if (l.cout > 64) return launch_gemm_pers<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
-      return launch_gemm_pers<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+      if (l.cout > 64) return launch_gemm_pers<4, false>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
+      return launch_gemm_pers<2, false>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
     }
+    if (out_f32 && pool && blocks128 >= 192) return launch_gemm_pers<4, true>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, s);
     if (l.cout > 64 && blocks128 >= 192) return launch_gemm<4>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s);
     return launch_gemm<2>(in, enc_wh, enc_w, ms, k0, kc, l, res, dst, M, out_f32, pool, s);
   }
