@@ -565,7 +565,23 @@ struct MShared2 {
   float stape[2][4][T][6][CB];   // [block][0 = forward pass, k = inverse of model k]
   float dg[4][88 * 64];
   float4 wiht[4][12 * 64];
+  // point-to-point progress counters between wave 0 (F / adjoint-F + Adam) and the model waves (inverse / adjoint):
+  int flagF[2];   // F passes of the block finished            (written by wave 0)
+  int cntInv[2];  // inverse passes of the block finished        (one increment per model wave and step)
+  int cntAdj[2];  // adjoint-inverse passes of the block finished
 };
+
+// LDS operations of one wave execute in program order, so "write data, then bump the counter" / "see the counter,
+// then read data" needs no fence on the hardware side -- only the compiler must keep the order (a release fence
+// would also wait for the tape stores still in flight).
+__device__ __forceinline__ void wait_ge(const int* p, int target) {
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void signal_inc(int* p, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 struct Agg {
   int ksel;
@@ -658,23 +674,32 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
     }
     lbest[blk] = 1000.0f;
   }
+  if (tid < 2) {
+    sh.flagF[tid] = 0;
+    sh.cntInv[tid] = 0;
+    sh.cntAdj[tid] = 0;
+  }
   __syncthreads();
 
   const int S = a.num_steps;
-  const int nticks = 4 * S + 3;  // round S: final F(A), adjoint-inverse/adjoint-F(B, S-1), final F(B)
+  // Two blocks of 16 candidates per workgroup, software-pipelined against each other.  Per Adam step and block the
+  // chain is  F -> inverse_k -> adjoint-inverse_k -> adjoint-F + Adam  (1 + 1 + 2 + 2 pass units); wave 0 owns the
+  // F passes, wave k >= 1 the passes of model k, each 3 units per block-step.  The waves run their own sequences
+  //   wave 0:  F(A,i)  adjF(B,i-1)  F(B,i)  adjF(A,i)          wave k:  inv(A,i)  adj(A,i)  inv(B,i)  adj(B,i)
+  // and only wait on the counters of the passes they consume, so neither side idles while the other finishes a
+  // longer pass (a barrier per phase costs max(1,2) units per phase: 4 units per block-step instead of 3).
+  if (wave == 0) {
 #pragma unroll 1
-  for (int tick = 0; tick < nticks; ++tick) {
-    const int i = tick >> 2, p = tick & 3;
-    if (wave == 0) {
-      if (p == 0 || p == 2) {
+    for (int hs = 0; hs < 2 * (S + 1); ++hs) {
+      const int i = hs >> 1, blk = hs & 1;
+      {
         // ---------------- F(blk, i)  (or the final pass with x_best when i == S) ----------------
-        const int blk = p >> 1;
         const bool final_pass = i == S;
-        sh.xbuf[blk][c][2 * q] = final_pass ? xb[blk][0] : xv[blk][0];
-        sh.xbuf[blk][c][2 * q + 1] = final_pass ? xb[blk][1] : xv[blk][1];
+        sh.xbuf[blk][c][2 * q] = final_pass ? (blk ? xb[1][0] : xb[0][0]) : (blk ? xv[1][0] : xv[0][0]);
+        sh.xbuf[blk][c][2 * q + 1] = final_pass ? (blk ? xb[1][1] : xb[0][1]) : (blk ? xv[1][1] : xv[0][1]);
         __builtin_amdgcn_wave_barrier();
         const PassOut po = pass_forward(MODE_FWD, W, pre, sh.xbuf[blk], sh.ybuf[blk], sh.stape[blk][0],
-                                        tape_blk[blk], c, q);
+                                        blk ? tape_blk[1] : tape_blk[0], c, q);
         float gl = 0.f, g0 = 0.f, g1 = 0.f;
         if (goal != nullptr && !final_pass) {
           __builtin_amdgcn_wave_barrier();
@@ -686,29 +711,33 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
           sh.gl[blk][2][c] = g1;
           sh.q[blk][0][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // model 0's posterior via the shortcut
         }
-      } else {
-        // ---------------- adjoint-F(blk, j) + Adam: p == 1 -> (B, i-1), p == 3 -> (A, i) ----------------
-        const int blk = p == 1 ? 1 : 0;
-        const int j = p == 1 ? i - 1 : i;
+        signal_inc(&sh.flagF[blk], lane);
+      }
+      {
+        // ---------------- adjoint-F + Adam of the OTHER block: after F(A,i) -> (B, i-1); after F(B,i) -> (A, i) ----
+        const int jb = blk ^ 1;
+        const int j = blk == 0 ? i - 1 : i;
         if (j >= 0 && j < S) {
-          const Agg ag = aggregate(sh.q[blk], sh.gl[blk], K, a.algorithm, c, a.grad_scale);
+          wait_ge(&sh.cntAdj[jb], (K - 1) * (j + 1));
+          const Agg ag = aggregate(sh.q[jb], sh.gl[jb], K, a.algorithm, c, a.grad_scale);
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             const int e = 2 * q + jj;
             float g = 0.f;
-            for (int kk = 1; kk < K; ++kk) g += sh.gk[blk][kk][c][e];
-            if (e >= 6) g += sh.gl[blk][e - 5][c];
-            sh.gsum[blk][c][e] = -g * a.grad_scale;
+            for (int kk = 1; kk < K; ++kk) g += sh.gk[jb][kk][c][e];
+            if (e >= 6) g += sh.gl[jb][e - 5][c];
+            sh.gsum[jb][c][e] = -g * a.grad_scale;
           }
           __builtin_amdgcn_wave_barrier();
           float res[8];
-          pass_backward(MODE_FWD, bw, wiht, sh.gsum[blk], sh.stape[blk][0], tape_blk[blk], dgl, c, q, res, ag.w0);
+          pass_backward(MODE_FWD, bw, wiht, sh.gsum[jb], sh.stape[jb][0], jb ? tape_blk[1] : tape_blk[0], dgl, c, q,
+                        res, ag.w0);
           const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
           const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
           // select this block's Adam state with static indices
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb) {
-            if (bb == blk) {
+            if (bb == jb) {
               b1p[bb] *= 0.9;
               b2p[bb] *= 0.999;
               const float step_size = (float)((double)a.lr / (1.0 - b1p[bb]));
@@ -728,36 +757,38 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
           }
         }
       }
-    } else {
-      if (p == 1 || p == 3) {
-        // ---------------- inverse(blk, i) of model k ----------------
-        const int blk = p == 1 ? 0 : 1;
-        if (i < S) {
-          const PassOut po = pass_forward(MODE_INV, W, pre, sh.ybuf[blk], sh.ybuf[blk], sh.stape[blk][k],
-                                          tape_blk[blk], c, q);
-          if (q == 0) sh.q[blk][k][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;
-        }
-      } else {
-        // ---------------- adjoint-inverse(blk, j): p == 0 -> (B, i-1), p == 2 -> (A, i) ----------------
-        const int blk = p == 0 ? 1 : 0;
-        const int j = p == 0 ? i - 1 : i;
-        if (j >= 0 && j < S) {
-          const Agg ag = aggregate(sh.q[blk], sh.gl[blk], K, a.algorithm, c, a.grad_scale);
-          const float wk = ag.mean_mode ? 1.0f / (float)K : (ag.ksel == k ? 1.0f : 0.0f);
-          if (__any(wk != 0.f)) {
-            float res[8];
-            pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[blk][k], tape_blk[blk], dgl, c, q, res);
-            sh.gk[blk][k][c][2 * q] = wk * (q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6]);
-            sh.gk[blk][k][c][2 * q + 1] = wk * (q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7]);
-          } else {
-            sh.gk[blk][k][c][2 * q] = 0.f;
-            sh.gk[blk][k][c][2 * q + 1] = 0.f;
-          }
+    }
+  } else {
+#pragma unroll 1
+    for (int hs = 0; hs < 2 * S; ++hs) {
+      const int i = hs >> 1, blk = hs & 1;
+      // ---------------- inverse(blk, i) of model k ----------------
+      wait_ge(&sh.flagF[blk], i + 1);
+      {
+        const PassOut po = pass_forward(MODE_INV, W, pre, sh.ybuf[blk], sh.ybuf[blk], sh.stape[blk][k],
+                                        blk ? tape_blk[1] : tape_blk[0], c, q);
+        if (q == 0) sh.q[blk][k][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;
+      }
+      signal_inc(&sh.cntInv[blk], lane);
+      // ---------------- adjoint-inverse(blk, i): needs every model's posterior for the aggregation ----------------
+      wait_ge(&sh.cntInv[blk], (K - 1) * (i + 1));
+      {
+        const Agg ag = aggregate(sh.q[blk], sh.gl[blk], K, a.algorithm, c, a.grad_scale);
+        const float wk = ag.mean_mode ? 1.0f / (float)K : (ag.ksel == k ? 1.0f : 0.0f);
+        if (__any(wk != 0.f)) {
+          float res[8];
+          pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[blk][k], blk ? tape_blk[1] : tape_blk[0], dgl, c, q, res);
+          sh.gk[blk][k][c][2 * q] = wk * (q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6]);
+          sh.gk[blk][k][c][2 * q + 1] = wk * (q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7]);
+        } else {
+          sh.gk[blk][k][c][2 * q] = 0.f;
+          sh.gk[blk][k][c][2 * q + 1] = 0.f;
         }
       }
+      signal_inc(&sh.cntAdj[blk], lane);
     }
-    __syncthreads();
   }
+  __syncthreads();
   // plans = F_0(x_best) of both blocks are in ybuf (rip/agent.py:137)
   if (wave == 0) {
 #pragma unroll
