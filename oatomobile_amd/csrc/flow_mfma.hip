@@ -625,8 +625,8 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
   const int n0 = (blockIdx.x - b * wgs_per_obs) * 2 * CB;
   const int k = wave;
   const float* mwk = mw_all + (size_t)(a.k0 + k) * MW_SIZE;
-  MW W;
-  load_mw(W, mwk, lane);
+  // The 251 forward operands are (re)loaded from L2 at the start of every forward / inverse pass and are dead during
+  // the adjoint passes: that leaves the accumulation registers free there (no scratch spills next to the tape traffic).
   const float4* bw = reinterpret_cast<const float4*>(mwk + MWF_FLOATS) + lane;
 #pragma unroll
   for (int g = 0; g < 12; ++g) sh.wiht[wave][g * 64 + lane] = bw[(57 + g) * 64];
@@ -649,6 +649,8 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) H[u * 4 + r] = a.z[((size_t)k * a.B + b) * 64 + 16 * u + 4 * q + r];
     float o[4];
+    MW W;
+    load_mw(W, mwk, lane);
     fwd_step<false>(W, H, 0.f, 0.f, q, nullptr, o);
 #pragma unroll
     for (int i = 0; i < 16; ++i) pre.H1[i] = H[i];
@@ -698,6 +700,10 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
         sh.xbuf[blk][c][2 * q] = final_pass ? (blk ? xb[1][0] : xb[0][0]) : (blk ? xv[1][0] : xv[0][0]);
         sh.xbuf[blk][c][2 * q + 1] = final_pass ? (blk ? xb[1][1] : xb[0][1]) : (blk ? xv[1][1] : xv[0][1]);
         __builtin_amdgcn_wave_barrier();
+        MW W;
+        const float* mwp = mwk;
+        asm volatile("" : "+s"(mwp));  // opaque: keeps the operand loads inside the pass (no hoisting out of the loop)
+        load_mw(W, mwp, lane);
         const PassOut po = pass_forward(MODE_FWD, W, pre, sh.xbuf[blk], sh.ybuf[blk], sh.stape[blk][0],
                                         blk ? tape_blk[1] : tape_blk[0], c, q);
         float gl = 0.f, g0 = 0.f, g1 = 0.f;
@@ -765,6 +771,10 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
       // ---------------- inverse(blk, i) of model k ----------------
       wait_ge(&sh.flagF[blk], i + 1);
       {
+        MW W;
+        const float* mwp = mwk;
+        asm volatile("" : "+s"(mwp));
+        load_mw(W, mwp, lane);
         const PassOut po = pass_forward(MODE_INV, W, pre, sh.ybuf[blk], sh.ybuf[blk], sh.stape[blk][k],
                                         blk ? tape_blk[1] : tape_blk[0], c, q);
         if (q == 0) sh.q[blk][k][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;
