@@ -249,7 +249,7 @@ def main():
         "frac": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
         # HBM-side bytes per launch: the adjoint tape (K passes x 3 steps x 22 KiB written per 16-candidate block and
         # Adam step, read back once); measured with rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE in
-        # separate passes: 1.36 GB + 1.43 GB at obs_batch 64 (profiles/r1/search_mfma2_pmc_{fetch,write}_v2.csv)
+        # separate passes (profiles/r1/search_mfma2_pmc_{fetch,write}_v*.csv)
         "traffic": (2.0 * blocks16 * args.search_steps * K * 3 * 22 * 1024) if use_mfma else None,
         "ms_per_launch": search_ms,
         "executed_tflops": (exec_flops / (search_ms * 1e-3) / 1e12) if use_mfma else None,
@@ -258,11 +258,15 @@ def main():
                 "SURVEY.md §8(d) flops_flow(grad) = 2*3*(1+K)*T*14848*N*steps per act (all K adjoints, 4 full steps) x "
                 "obs_batch / launch time; the kernel executes fewer flops than that (shared step-0 prefix, self-inverse "
                 "shortcut for model 0, one adjoint per candidate under WCM): `executed_*` counts the MFMAs actually issued. "
-                "HBM traffic of this kernel is negligible (weights 132 KiB/model from L2, tape in L2-resident scratch).",
+                "`traffic` is the adjoint tape (written once, read once per pass; it does not stay in L2: rocprofv3 "
+                "FETCH_SIZE x2 + WRITE_SIZE per launch match this analytic figure, see profiles/); the operands "
+                "(64 KiB forward + 57 KiB/step transposed per model) stream from L2.",
         "encoder": {"ms_per_step": enc_ms, "algorithmic_GBps": enc_bytes / (enc_ms * 1e-3) / 1e9,
                     "frac_hbm": enc_bytes / (enc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                    "note": "transform + stem + 17 depthwise + 34 pointwise(MFMA) + pool/classifier + merger launches, %s; " % args.encoder_dtype +
-                            "layer-wise compulsory bytes (SURVEY §8d bytes_pre+bytes_enc) / encoder time vs 8 TB/s"},
+                    "note": "transform + stem + MobileNetV2 features (%s; bf16 at >= 256 model-observation pairs: "
+                            "features.2-7 as fused row-streaming blocks, 7x7/4x4 stages on the persistent block GEMM) + "
+                            "classifier + merger; layer-wise compulsory bytes (SURVEY §8d bytes_pre+bytes_enc) / encoder "
+                            "time vs 8 TB/s -- the fused blocks move fewer bytes than this layer-wise count" % args.encoder_dtype},
     }
     out = {
         "metric": "RIPAgent.act() calls/sec (K=%d, %d plans, 200x200 BEV)" % (K, N),
