@@ -182,6 +182,32 @@ def test_bf16_encoder_large_batch_kernels_match_small_batch(dev):
   assert np.abs(z_big[B - 4:] - z_tail).max() <= 0.03 * np.abs(z_small).max()
 
 
+def test_bf16_fused_blocks_match_layerwise_same_batch(dev):
+  """RIP_OPT_ENCODER_FUSED on the bf16 path: the fused row-streaming blocks (features.2-7) against the layer-wise
+  kernels on the SAME 256 observations (same large-batch depthwise / GEMM kernels elsewhere); the only differences
+  fused kernel keeps every fp32 accumulation in the layer-wise order and rounds to bf16 (RNE) at the same points, so
+  the two paths currently agree bit for bit (a rocprofv3 trace shows 6 `irb_rows_bf16_kernel` launches with the
+  option at 7 and none at 0); the tolerance leaves room for a reordered accumulation."""
+  B = 256
+  m = hip_model(29, dev, max_batch=B)
+  m.encoder_dtype = "bf16"
+  rng = np.random.default_rng(78)
+  vis = torch.from_numpy(rng.random((B, 2, 100, 100), dtype=np.float32)).to(dev)
+  vis[:, :, :, 60:] = 0
+  ctx = dict(visual_features=vis,
+             velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
+             is_at_traffic_light=torch.zeros(B, 1, device=dev),
+             traffic_light_state=torch.ones(B, 1, device=dev))
+  m.fused_encoder = 0
+  z_layer = m._params(**ctx).cpu().numpy()
+  m.fused_encoder = 7
+  z_fused = m._params(**ctx).cpu().numpy()
+  d = np.abs(z_fused - z_layer)
+  print("bf16 fused vs layer-wise: max|dz| = %.3g of max|z| = %.3g" % (d.max(), np.abs(z_layer).max()))
+  assert np.isfinite(z_fused).all()
+  assert d.max() <= 0.03 * np.abs(z_layer).max()
+
+
 def test_params_missing_key_raises(dev):
   m = hip_model(5, dev)
   with pytest.raises(ValueError, match="Missing `velocity`"):
