@@ -39,6 +39,15 @@ __device__ __forceinline__ f32x4 zero4() {
   return z;
 }
 
+// Tape accessors.  Non-temporal hints were measured and rejected: `nt` stores +14 % on the kernel (the adjoint then
+// reads the tape from HBM instead of the memory-side cache), `nt` loads +-0.
+__device__ __forceinline__ void tape_st(float4* p, float a, float b, float c, float d) {
+  *p = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ float4 tape_ld(const float4* p) {
+  return *p;
+}
+
 // register-resident forward operands of one model (see MWF_* in flow.h)
 struct MW {
   float wf[192];  // [(g*4+u')*16 + (u*4+r)]  W_hh[g*64+16u'+m][16u+4q+r]
@@ -103,11 +112,11 @@ __device__ __forceinline__ void fwd_step(const MW& W, float (&H)[16], float yp0,
       Hn[up * 4 + r] = fmaf(zz[r], H[up * 4 + r] - nn[r], nn[r]);  // (1-z)*n + z*h
     }
     if (SAVE) {
-      tape[(up * 5 + 0) * 64] = make_float4(H[up * 4], H[up * 4 + 1], H[up * 4 + 2], H[up * 4 + 3]);
-      tape[(up * 5 + 1) * 64] = make_float4(rr[0], rr[1], rr[2], rr[3]);
-      tape[(up * 5 + 2) * 64] = make_float4(zz[0], zz[1], zz[2], zz[3]);
-      tape[(up * 5 + 3) * 64] = make_float4(nn[0], nn[1], nn[2], nn[3]);
-      tape[(up * 5 + 4) * 64] = make_float4(ahn[0], ahn[1], ahn[2], ahn[3]);
+      tape_st(tape + (up * 5 + 0) * 64, H[up * 4], H[up * 4 + 1], H[up * 4 + 2], H[up * 4 + 3]);
+      tape_st(tape + (up * 5 + 1) * 64, rr[0], rr[1], rr[2], rr[3]);
+      tape_st(tape + (up * 5 + 2) * 64, zz[0], zz[1], zz[2], zz[3]);
+      tape_st(tape + (up * 5 + 3) * 64, nn[0], nn[1], nn[2], nn[3]);
+      tape_st(tape + (up * 5 + 4) * 64, ahn[0], ahn[1], ahn[2], ahn[3]);
     }
   }
 #pragma unroll
@@ -123,8 +132,8 @@ __device__ __forceinline__ void fwd_step(const MW& W, float (&H)[16], float yp0,
   a0 = mfma(W.w1x[0], bone, a0);
   a1 = mfma(W.w1x[1], bone, a1);
   if (SAVE) {
-    tape[20 * 64] = make_float4(a0[0], a0[1], a0[2], a0[3]);
-    tape[21 * 64] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    tape_st(tape + 20 * 64, a0[0], a0[1], a0[2], a0[3]);
+    tape_st(tape + 21 * 64, a1[0], a1[1], a1[2], a1[3]);
   }
   f32x4 oa = zero4(), ob = zero4();
 #pragma unroll
@@ -289,7 +298,7 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     const float4* tp = tape + (t - 1) * TAPE_STEP_F4;
     // ---- head adjoint: da1 = relu'(a1) * W2^T do ----
     const float4 w2t = bw[0];
-    const float4 a1s0 = tp[20 * 64], a1s1 = tp[21 * 64];
+    const float4 a1s0 = tape_ld(tp + 20 * 64), a1s1 = tape_ld(tp + 21 * 64);
     // Streamed operands are issued well ahead of their MFMAs (explicit register ring): the L2 round trip
     // (~700 cycles) is longer than the 16 MFMAs (512 cycles) one float4 feeds.  The contraction is one
     // sequence of 8 (W1^T, B = da1) + 48 (W_hh^T, B = dgh_{t+1}) steps; at t = T-1 only the first 8 exist.
@@ -329,8 +338,9 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
     for (int up = 0; up < 4; ++up) {
-      const float4 hp = tp[(up * 5 + 0) * 64], rr = tp[(up * 5 + 1) * 64], zz = tp[(up * 5 + 2) * 64];
-      const float4 nn = tp[(up * 5 + 3) * 64], gh = tp[(up * 5 + 4) * 64];
+      const float4 hp = tape_ld(tp + (up * 5 + 0) * 64), rr = tape_ld(tp + (up * 5 + 1) * 64);
+      const float4 zz = tape_ld(tp + (up * 5 + 2) * 64), nn = tape_ld(tp + (up * 5 + 3) * 64);
+      const float4 gh = tape_ld(tp + (up * 5 + 4) * 64);
       const float hpa[4] = {hp.x, hp.y, hp.z, hp.w}, rra[4] = {rr.x, rr.y, rr.z, rr.w};
       const float zza[4] = {zz.x, zz.y, zz.z, zz.w}, nna[4] = {nn.x, nn.y, nn.z, nn.w};
       const float gha[4] = {gh.x, gh.y, gh.z, gh.w};
@@ -684,6 +694,14 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
   __syncthreads();
 
   const int S = a.num_steps;
+#ifdef RIP_PROFILE_TICKS  // tools/search_ticks.py: where a wave's cycles go (block 0 prints at the end)
+  long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = 0;
+#define TSTART() t0_ = clock64()
+#define TSTOP(i_) tk[i_] += clock64() - t0_
+#else
+#define TSTART()
+#define TSTOP(i_)
+#endif
   // Two blocks of 16 candidates per workgroup, software-pipelined against each other.  Per Adam step and block the
   // chain is  F -> inverse_k -> adjoint-inverse_k -> adjoint-F + Adam  (1 + 1 + 2 + 2 pass units); wave 0 owns the
   // F passes, wave k >= 1 the passes of model k, each 3 units per block-step.  The waves run their own sequences
@@ -700,12 +718,14 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
         sh.xbuf[blk][c][2 * q] = final_pass ? (blk ? xb[1][0] : xb[0][0]) : (blk ? xv[1][0] : xv[0][0]);
         sh.xbuf[blk][c][2 * q + 1] = final_pass ? (blk ? xb[1][1] : xb[0][1]) : (blk ? xv[1][1] : xv[0][1]);
         __builtin_amdgcn_wave_barrier();
+        TSTART();
         MW W;
         const float* mwp = mwk;
         asm volatile("" : "+s"(mwp));  // opaque: keeps the operand loads inside the pass (no hoisting out of the loop)
         load_mw(W, mwp, lane);
         const PassOut po = pass_forward(MODE_FWD, W, pre, sh.xbuf[blk], sh.ybuf[blk], sh.stape[blk][0],
                                         blk ? tape_blk[1] : tape_blk[0], c, q);
+        TSTOP(0);
         float gl = 0.f, g0 = 0.f, g1 = 0.f;
         if (goal != nullptr && !final_pass) {
           __builtin_amdgcn_wave_barrier();
@@ -724,7 +744,9 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
         const int jb = blk ^ 1;
         const int j = blk == 0 ? i - 1 : i;
         if (j >= 0 && j < S) {
+          TSTART();
           wait_ge(&sh.cntAdj[jb], (K - 1) * (j + 1));
+          TSTOP(1);
           const Agg ag = aggregate(sh.q[jb], sh.gl[jb], K, a.algorithm, c, a.grad_scale);
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
@@ -736,8 +758,10 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
           }
           __builtin_amdgcn_wave_barrier();
           float res[8];
+          TSTART();
           pass_backward(MODE_FWD, bw, wiht, sh.gsum[jb], sh.stape[jb][0], jb ? tape_blk[1] : tape_blk[0], dgl, c, q,
                         res, ag.w0);
+          TSTOP(2);
           const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
           const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
           // select this block's Adam state with static indices
@@ -769,7 +793,10 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
     for (int hs = 0; hs < 2 * S; ++hs) {
       const int i = hs >> 1, blk = hs & 1;
       // ---------------- inverse(blk, i) of model k ----------------
+      TSTART();
       wait_ge(&sh.flagF[blk], i + 1);
+      TSTOP(3);
+      TSTART();
       {
         MW W;
         const float* mwp = mwk;
@@ -779,9 +806,13 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
                                         blk ? tape_blk[1] : tape_blk[0], c, q);
         if (q == 0) sh.q[blk][k][c] = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;
       }
+      TSTOP(4);
       signal_inc(&sh.cntInv[blk], lane);
       // ---------------- adjoint-inverse(blk, i): needs every model's posterior for the aggregation ----------------
+      TSTART();
       wait_ge(&sh.cntInv[blk], (K - 1) * (i + 1));
+      TSTOP(5);
+      TSTART();
       {
         const Agg ag = aggregate(sh.q[blk], sh.gl[blk], K, a.algorithm, c, a.grad_scale);
         const float wk = ag.mean_mode ? 1.0f / (float)K : (ag.ksel == k ? 1.0f : 0.0f);
@@ -795,9 +826,15 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
           sh.gk[blk][k][c][2 * q + 1] = 0.f;
         }
       }
+      TSTOP(6);
       signal_inc(&sh.cntAdj[blk], lane);
     }
   }
+#ifdef RIP_PROFILE_TICKS
+  if (blockIdx.x == 0 && lane == 0 && wave < 2)
+    printf("ticks wave %d: F %lld waitAdj %lld adjF %lld | waitF %lld inv %lld waitInv %lld adj %lld\n", wave, tk[0], tk[1],
+           tk[2], tk[3], tk[4], tk[5], tk[6]);
+#endif
   __syncthreads();
   // plans = F_0(x_best) of both blocks are in ybuf (rip/agent.py:137)
   if (wave == 0) {
