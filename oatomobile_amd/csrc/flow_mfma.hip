@@ -253,7 +253,16 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
                                               const float4* __restrict__ wiht4, const float (*gin)[8],
                                               const float (*st)[6][CB], const float4* __restrict__ tape,
                                               float* __restrict__ dgl, int c, int q, float (&res)[8],
-                                              float w0 = 0.f) {
+                                              float w0 = 0.f, long long* ptk = nullptr) {
+#ifdef RIP_PROFILE_TICKS
+  long long pt0_ = 0;
+#define PSTART() pt0_ = clock64()
+#define PSTOP(i_) \
+  if (ptk) ptk[i_] += clock64() - pt0_
+#else
+#define PSTART()
+#define PSTOP(i_)
+#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) dgl[(64 + i) * 64] = 0.f;
   float carry0 = 0.f, carry1 = 0.f;
@@ -261,6 +270,7 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
   for (int i = 0; i < 8; ++i) res[i] = 0.f;
 #pragma unroll 1
   for (int t = T - 1; t >= 1; --t) {
+    PSTART();
     const float x0 = st[t][0][c], x1 = st[t][1][c], s0 = st[t][2][c], s1 = st[t][3][c];
     const float sg0 = st[t][4][c], sg1 = st[t][5][c];
     float dd0, dd1, dos0, dos1, c0, c1, r0, r1;
@@ -320,21 +330,43 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     dgl[87 * 64] = a1s1.w > 0.f ? da1[3] : 0.f;
     // ---- dh_t = W1^T da1_t + W_hh^T dgh_{t+1} + dh'_{t+1} z_{t+1} ----
     f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4(), acc3 = zero4();
-#pragma unroll 1
-    for (int s0 = 0; s0 < nsteps; s0 += RING) {
+    PSTOP(0);
+    PSTART();
+    // Two straight-line bodies (with / without ring refills) instead of a per-entry `if`: the uniform branches cut
+    // the loop into one basic block per entry, and each block then read its LDS operand and waited for it
+    // (lgkmcnt(0) right after the ds_read, 56 exposed LDS round trips per step).
+    auto ring_body = [&](int s0, bool refill) __attribute__((always_inline)) {
+      float bv[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const int sl = s0 == 0 ? 80 + j : s0 - 8 + j;  // B operand slot: da1 for the first 8 steps, then dgh
+        bv[j] = dgl[sl * 64];
+      }
 #pragma unroll
       for (int j = 0; j < RING; ++j) {
         const float4 w = wb[j];
-        if (s0 + RING < nsteps) wb[j] = bw[(1 + s0 + RING + j) * 64];
-        const int sl = s0 == 0 ? 80 + j : s0 - 8 + j;  // B operand slot: da1 for the first 8 steps, then dgh
-        const float bv = dgl[sl * 64];
-        acc0 = mfma(w.x, bv, acc0);
-        acc1 = mfma(w.y, bv, acc1);
-        acc2 = mfma(w.z, bv, acc2);
-        acc3 = mfma(w.w, bv, acc3);
+        if (refill) wb[j] = bw[(1 + s0 + RING + j) * 64];
+        acc0 = mfma(w.x, bv[j], acc0);
+        acc1 = mfma(w.y, bv[j], acc1);
+        acc2 = mfma(w.z, bv[j], acc2);
+        acc3 = mfma(w.w, bv[j], acc3);
       }
-    }
+      // Keep each refill next to the entry it replaces: left alone, the scheduler clusters the 8 refill loads at the
+      // end of the body and the next iteration waits for all of them (vmcnt(0)) after two entries' worth of MFMAs --
+      // the "8-deep" ring then covers ~300 cycles instead of ~1000.
+      __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);  // the LDS operand reads first
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (refill) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    };
+#pragma unroll 1
+    for (int s0 = 0; s0 + RING < nsteps; s0 += RING) ring_body(s0, true);
+    ring_body(nsteps - RING, false);
     // ---- GRUCell adjoint, lane-local in the H layout ----
+    PSTOP(1);
+    PSTART();
     const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
     for (int up = 0; up < 4; ++up) {
@@ -360,6 +392,8 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
       }
     }
     // ---- du = W_ih^T (dpr, dpz, dpn): rows m <-> input dim m & 1 ----
+    PSTOP(2);
+    PSTART();
     f32x4 dua = zero4(), dub = zero4();
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
@@ -372,6 +406,7 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     }
     carry0 = c0 + (dua[0] + dub[0]);
     carry1 = c1 + (dua[1] + dub[1]);
+    PSTOP(3);
   }
   // ---- t = 0: coupling only ----
   {
@@ -696,6 +731,7 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
   const int S = a.num_steps;
 #ifdef RIP_PROFILE_TICKS  // tools/search_ticks.py: where a wave's cycles go (block 0 prints at the end)
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = 0;
+  long long ptk[4] = {0, 0, 0, 0};  // adjoint-F sub-phases: head adjoint + a1 wait, contraction, GRU adjoint, du
 #define TSTART() t0_ = clock64()
 #define TSTOP(i_) tk[i_] += clock64() - t0_
 #else
@@ -759,8 +795,13 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
           __builtin_amdgcn_wave_barrier();
           float res[8];
           TSTART();
+#ifdef RIP_PROFILE_TICKS
+          pass_backward(MODE_FWD, bw, wiht, sh.gsum[jb], sh.stape[jb][0], jb ? tape_blk[1] : tape_blk[0], dgl, c, q,
+                        res, ag.w0, ptk);
+#else
           pass_backward(MODE_FWD, bw, wiht, sh.gsum[jb], sh.stape[jb][0], jb ? tape_blk[1] : tape_blk[0], dgl, c, q,
                         res, ag.w0);
+#endif
           TSTOP(2);
           const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
           const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
@@ -832,8 +873,9 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
   }
 #ifdef RIP_PROFILE_TICKS
   if (blockIdx.x == 0 && lane == 0 && wave < 2)
-    printf("ticks wave %d: F %lld waitAdj %lld adjF %lld | waitF %lld inv %lld waitInv %lld adj %lld\n", wave, tk[0], tk[1],
-           tk[2], tk[3], tk[4], tk[5], tk[6]);
+    printf("ticks wave %d: F %lld waitAdj %lld adjF %lld | waitF %lld inv %lld waitInv %lld adj %lld | adjF phases: head %lld "
+           "contraction %lld gru %lld du %lld\n", wave, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], ptk[0], ptk[1],
+           ptk[2], ptk[3]);
 #endif
   __syncthreads();
   // plans = F_0(x_best) of both blocks are in ybuf (rip/agent.py:137)
