@@ -363,6 +363,11 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     };
 #pragma unroll 1
     for (int s0 = 0; s0 + RING < nsteps; s0 += RING) ring_body(s0, true);
+    // the GRU adjoint's tape rows: requested once no further operand refill has to queue behind them (vmcnt retires
+    // in order), i.e. under the last 8 entries' MFMAs instead of at their first use
+    float4 tg[20];
+#pragma unroll
+    for (int r = 0; r < 20; ++r) tg[r] = tape_ld(tp + r * 64);
     ring_body(nsteps - RING, false);
     // ---- GRUCell adjoint, lane-local in the H layout ----
     PSTOP(1);
@@ -370,9 +375,8 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
     for (int up = 0; up < 4; ++up) {
-      const float4 hp = tape_ld(tp + (up * 5 + 0) * 64), rr = tape_ld(tp + (up * 5 + 1) * 64);
-      const float4 zz = tape_ld(tp + (up * 5 + 2) * 64), nn = tape_ld(tp + (up * 5 + 3) * 64);
-      const float4 gh = tape_ld(tp + (up * 5 + 4) * 64);
+      const float4 hp = tg[up * 5 + 0], rr = tg[up * 5 + 1], zz = tg[up * 5 + 2], nn = tg[up * 5 + 3];
+      const float4 gh = tg[up * 5 + 4];
       const float hpa[4] = {hp.x, hp.y, hp.z, hp.w}, rra[4] = {rr.x, rr.y, rr.z, rr.w};
       const float zza[4] = {zz.x, zz.y, zz.z, zz.w}, nna[4] = {nn.x, nn.y, nn.z, nn.w};
       const float gha[4] = {gh.x, gh.y, gh.z, gh.w};
