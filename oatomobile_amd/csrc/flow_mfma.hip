@@ -344,12 +344,14 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
       }
 #pragma unroll
       for (int j = 0; j < RING; ++j) {
-        const float4 w = wb[j];
+        // read the entry straight out of its ring registers, refill after: a by-value copy of the float4 made the
+        // compiler funnel every A operand through ONE scratch register (v_mov + s_nop before each MFMA, and the
+        // write-after-read on that register against the MFMA in flight serialised the pipe: ~70 cycles per MFMA)
+        acc0 = mfma(wb[j].x, bv[j], acc0);
+        acc1 = mfma(wb[j].y, bv[j], acc1);
+        acc2 = mfma(wb[j].z, bv[j], acc2);
+        acc3 = mfma(wb[j].w, bv[j], acc3);
         if (refill) wb[j] = bw[(1 + s0 + RING + j) * 64];
-        acc0 = mfma(w.x, bv[j], acc0);
-        acc1 = mfma(w.y, bv[j], acc1);
-        acc2 = mfma(w.z, bv[j], acc2);
-        acc3 = mfma(w.w, bv[j], acc3);
       }
       // Keep each refill next to the entry it replaces: left alone, the scheduler clusters the 8 refill loads at the
       // end of the body and the next iteration waits for all of them (vmcnt(0)) after two entries' worth of MFMAs --
