@@ -253,7 +253,7 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
                                               const float4* __restrict__ wiht4, const float (*gin)[8],
                                               const float (*st)[6][CB], const float4* __restrict__ tape,
                                               float* __restrict__ dgl, int c, int q, float (&res)[8],
-                                              float w0 = 0.f, long long* ptk = nullptr) {
+                                              const float4 (&rw)[16], float w0 = 0.f, long long* ptk = nullptr) {
 #ifdef RIP_PROFILE_TICKS
   long long pt0_ = 0;
 #define PSTART() pt0_ = clock64()
@@ -312,11 +312,18 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     // Streamed operands are issued well ahead of their MFMAs (explicit register ring): the L2 round trip
     // (~700 cycles) is longer than the 16 MFMAs (512 cycles) one float4 feeds.  The contraction is one
     // sequence of 8 (W1^T, B = da1) + 48 (W_hh^T, B = dgh_{t+1}) steps; at t = T-1 only the first 8 exist.
+    // The first 16 entries (W1^T and the first 8 of W_hh^T) are kernel-resident registers (rw); the ring streams
+    // entries 16..55 and is first filled here, two resident bodies (~2k MFMA cycles) before its first use.  The
+    // stream is not latency- but throughput-limited: all four waves of a CU miss L1 on every operand row (4 x 57 KB
+    // per step) and the refill *issue* back-pressures the in-order instruction stream, stalling the MFMAs behind it
+    // (a 16-deep ring changed nothing, removing the refills gave -20 %), so the cure is fewer bytes: -33 % here.
     constexpr int RING = 8;
     const int nsteps = t == T - 1 ? 8 : 56;
     float4 wb[RING];
+    if (nsteps > 16) {
 #pragma unroll
-    for (int j = 0; j < RING; ++j) wb[j] = bw[(1 + j) * 64];
+      for (int j = 0; j < RING; ++j) wb[j] = bw[(17 + j) * 64];
+    }
     const float bdo = q == 0 ? dd0 : (q == 1 ? dd1 : (q == 2 ? dos0 : dos1));
     const f32x4 da0 = mfma(w2t.x, bdo, zero4());
     const f32x4 da1 = mfma(w2t.y, bdo, zero4());
@@ -339,8 +346,7 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
       float bv[RING];
 #pragma unroll
       for (int j = 0; j < RING; ++j) {
-        const int sl = s0 == 0 ? 80 + j : s0 - 8 + j;  // B operand slot: da1 for the first 8 steps, then dgh
-        bv[j] = dgl[sl * 64];
+        bv[j] = dgl[(s0 - 8 + j) * 64];  // B operand slot of entry s0 + j >= 16: dgh
       }
 #pragma unroll
       for (int j = 0; j < RING; ++j) {
@@ -363,14 +369,34 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
         if (refill) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     };
-#pragma unroll 1
-    for (int s0 = 0; s0 + RING < nsteps; s0 += RING) ring_body(s0, true);
-    // the GRU adjoint's tape rows: requested once no further operand refill has to queue behind them (vmcnt retires
-    // in order), i.e. under the last 8 entries' MFMAs instead of at their first use
-    float4 tg[20];
+    auto resident_body = [&](int r0, int slot0) __attribute__((always_inline)) {
+      float bv[8];
 #pragma unroll
-    for (int r = 0; r < 20; ++r) tg[r] = tape_ld(tp + r * 64);
-    ring_body(nsteps - RING, false);
+      for (int j = 0; j < 8; ++j) bv[j] = dgl[(slot0 + j) * 64];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc0 = mfma(rw[r0 + j].x, bv[j], acc0);
+        acc1 = mfma(rw[r0 + j].y, bv[j], acc1);
+        acc2 = mfma(rw[r0 + j].z, bv[j], acc2);
+        acc3 = mfma(rw[r0 + j].w, bv[j], acc3);
+      }
+    };
+    // the GRU adjoint's tape rows (tg) are requested once no further operand refill has to queue behind them (vmcnt
+    // retires in order), i.e. under the last 8 entries' MFMAs instead of at their first use
+    float4 tg[20];
+    if (nsteps <= 16) {
+#pragma unroll
+      for (int r = 0; r < 20; ++r) tg[r] = tape_ld(tp + r * 64);
+    }
+    resident_body(0, 80);  // entries 0..7: W1^T, B = da1
+    if (nsteps > 16) {
+      resident_body(8, 0);  // entries 8..15: W_hh^T rows of units 0..7 of d pre_r
+#pragma unroll 1
+      for (int s0 = 16; s0 + RING < nsteps; s0 += RING) ring_body(s0, true);
+#pragma unroll
+      for (int r = 0; r < 20; ++r) tg[r] = tape_ld(tp + r * 64);
+      ring_body(nsteps - RING, false);
+    }
     // ---- GRUCell adjoint, lane-local in the H layout ----
     PSTOP(1);
     PSTART();
@@ -443,6 +469,13 @@ __global__ __launch_bounds__(NW * 64) void search_mfma_kernel(SearchArgs a, cons
   MW W;
   load_mw(W, mwk, lane);
   const float4* bw = reinterpret_cast<const float4*>(mwk + MWF_FLOATS) + lane;
+  float4 rw[16];  // kernel-resident transposed operands: entries 0..15 of the adjoint contraction (see pass_backward)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    rw[i] = bw[(1 + i) * 64];
+    // opaque to the optimiser: otherwise the (constant) rows are simply re-loaded at every use
+    asm volatile("" : "+v"(rw[i].x), "+v"(rw[i].y), "+v"(rw[i].z), "+v"(rw[i].w));
+  }
 #pragma unroll
   for (int g = 0; g < 12; ++g) sh.wiht[wave][g * 64 + lane] = bw[(57 + g) * 64];  // own model, read only by this wave
   const float4* wiht = sh.wiht[wave] + lane;
@@ -541,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) void search_mfma_kernel(SearchArgs a, cons
         const float wk = mean_mode ? 1.0f / (float)K : (ksel == k ? 1.0f : 0.0f);
         if (__any(wk != 0.f)) {
           float res[8];
-          pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[1 + k], tape_inv, dgl, c, q, res);
+          pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[1 + k], tape_inv, dgl, c, q, res, rw);
           sh.gk[k][c][2 * q] = wk * (q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6]);
           sh.gk[k][c][2 * q + 1] = wk * (q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7]);
         } else {
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(NW * 64) void search_mfma_kernel(SearchArgs a, cons
         }
         __builtin_amdgcn_wave_barrier();
         float res[8];
-        pass_backward(MODE_FWD, bw, wiht, sh.gsum, sh.stape[0], tape_fwd, dgl, c, q, res);
+        pass_backward(MODE_FWD, bw, wiht, sh.gsum, sh.stape[0], tape_fwd, dgl, c, q, res, rw);
         const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
         const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
         // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
@@ -679,6 +712,13 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
   // The 251 forward operands are (re)loaded from L2 at the start of every forward / inverse pass and are dead during
   // the adjoint passes: that leaves the accumulation registers free there (no scratch spills next to the tape traffic).
   const float4* bw = reinterpret_cast<const float4*>(mwk + MWF_FLOATS) + lane;
+  float4 rw[16];  // kernel-resident transposed operands: entries 0..15 of the adjoint contraction (see pass_backward)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    rw[i] = bw[(1 + i) * 64];
+    // opaque to the optimiser: otherwise the (constant) rows are simply re-loaded at every use
+    asm volatile("" : "+v"(rw[i].x), "+v"(rw[i].y), "+v"(rw[i].z), "+v"(rw[i].w));
+  }
 #pragma unroll
   for (int g = 0; g < 12; ++g) sh.wiht[wave][g * 64 + lane] = bw[(57 + g) * 64];
   const float4* wiht = sh.wiht[wave] + lane;
@@ -803,10 +843,10 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
           TSTART();
 #ifdef RIP_PROFILE_TICKS
           pass_backward(MODE_FWD, bw, wiht, sh.gsum[jb], sh.stape[jb][0], jb ? tape_blk[1] : tape_blk[0], dgl, c, q,
-                        res, ag.w0, ptk);
+                        res, rw, ag.w0, ptk);
 #else
           pass_backward(MODE_FWD, bw, wiht, sh.gsum[jb], sh.stape[jb][0], jb ? tape_blk[1] : tape_blk[0], dgl, c, q,
-                        res, ag.w0);
+                        res, rw, ag.w0);
 #endif
           TSTOP(2);
           const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
@@ -865,7 +905,8 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
         const float wk = ag.mean_mode ? 1.0f / (float)K : (ag.ksel == k ? 1.0f : 0.0f);
         if (__any(wk != 0.f)) {
           float res[8];
-          pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[blk][k], blk ? tape_blk[1] : tape_blk[0], dgl, c, q, res);
+          pass_backward(MODE_INV, bw, wiht, nullptr, sh.stape[blk][k], blk ? tape_blk[1] : tape_blk[0], dgl, c, q, res,
+                        rw);
           sh.gk[blk][k][c][2 * q] = wk * (q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6]);
           sh.gk[blk][k][c][2 * q + 1] = wk * (q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7]);
         } else {
