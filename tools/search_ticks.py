@@ -23,7 +23,8 @@ if __name__ == "__main__":
     out = os.path.join(ROOT, "build_abl")
     os.makedirs(out, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRIP_PROFILE_TICKS"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-DRIP_PROFILE_TICKS"]
     cmd += [os.path.join(G.CSRC, s) for s in G.SOURCES] + ["-o", os.path.join(out, "lib_TICKS.so")]
     subprocess.run(cmd, check=True, cwd=ROOT)
     print("built", os.path.join(out, "lib_TICKS.so"))
