@@ -400,27 +400,43 @@ __device__ __forceinline__ void pass_backward(int mode, const float4* __restrict
     // ---- GRUCell adjoint, lane-local in the H layout ----
     PSTOP(1);
     PSTART();
+    // two units per instruction (v_pk_mul_f32 / v_pk_fma_f32): VALU work of a wave does not overlap its own MFMAs
+    // (tools/micro/mfma_mix.hip), so every VALU instruction saved here is matrix-pipe time gained.  Same operations
+    // in the same order per unit as the scalar form (mul, mul, mul; no new contraction).
+    using f2 = __attribute__((ext_vector_type(2))) float;
     const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
     for (int up = 0; up < 4; ++up) {
       const float4 hp = tg[up * 5 + 0], rr = tg[up * 5 + 1], zz = tg[up * 5 + 2], nn = tg[up * 5 + 3];
       const float4 gh = tg[up * 5 + 4];
-      const float hpa[4] = {hp.x, hp.y, hp.z, hp.w}, rra[4] = {rr.x, rr.y, rr.z, rr.w};
-      const float zza[4] = {zz.x, zz.y, zz.z, zz.w}, nna[4] = {nn.x, nn.y, nn.z, nn.w};
-      const float gha[4] = {gh.x, gh.y, gh.z, gh.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = up * 4 + r;
-        const float dh = accs[up][r] + dgl[(64 + i) * 64];
-        const float dn = dh * (1.0f - zza[r]);
-        const float dzg = dh * (hpa[r] - nna[r]);
-        dgl[(64 + i) * 64] = dh * zza[r];
-        const float dp = dn * (1.0f - nna[r] * nna[r]);
-        const float dr = dp * gha[r];
-        dgl[(48 + i) * 64] = dp;                                 // d pre_n
-        dgl[(32 + i) * 64] = dp * rra[r];                        // d gh_n
-        dgl[i * 64] = dr * rra[r] * (1.0f - rra[r]);             // d pre_r
-        dgl[(16 + i) * 64] = dzg * zza[r] * (1.0f - zza[r]);     // d pre_z
+      for (int h = 0; h < 2; ++h) {  // unit pairs (0,1), (2,3) of the tile
+        const int i = up * 4 + 2 * h;
+        const f2 hp2 = h ? f2{hp.z, hp.w} : f2{hp.x, hp.y};
+        const f2 rr2 = h ? f2{rr.z, rr.w} : f2{rr.x, rr.y};
+        const f2 zz2 = h ? f2{zz.z, zz.w} : f2{zz.x, zz.y};
+        const f2 nn2 = h ? f2{nn.z, nn.w} : f2{nn.x, nn.y};
+        const f2 gh2 = h ? f2{gh.z, gh.w} : f2{gh.x, gh.y};
+        const f2 one = {1.0f, 1.0f};
+        const f2 dh = f2{accs[up][2 * h], accs[up][2 * h + 1]} + f2{dgl[(64 + i) * 64], dgl[(65 + i) * 64]};
+        const f2 dn = dh * (one - zz2);
+        const f2 dzg = dh * (hp2 - nn2);
+        const f2 dhz = dh * zz2;
+        const f2 dp = dn * (one - nn2 * nn2);
+        const f2 dr = dp * gh2;
+        const f2 dgn = dp * rr2;
+        const f2 dpr = dr * rr2 * (one - rr2);
+        const f2 dpz = dzg * zz2 * (one - zz2);
+        dgl[(64 + i) * 64] = dhz.x;
+        dgl[(65 + i) * 64] = dhz.y;
+        dgl[(48 + i) * 64] = dp.x;   // d pre_n
+        dgl[(49 + i) * 64] = dp.y;
+        dgl[(32 + i) * 64] = dgn.x;  // d gh_n
+        dgl[(33 + i) * 64] = dgn.y;
+        dgl[i * 64] = dpr.x;         // d pre_r
+        dgl[(1 + i) * 64] = dpr.y;
+        dgl[(16 + i) * 64] = dpz.x;  // d pre_z
+        dgl[(17 + i) * 64] = dpz.y;
       }
     }
     // ---- du = W_ih^T (dpr, dpz, dpn): rows m <-> input dim m & 1 ----
