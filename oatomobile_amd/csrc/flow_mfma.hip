@@ -104,12 +104,38 @@ __device__ __forceinline__ void fwd_step(const MW& W, float (&H)[16], float yp0,
     agn = mfma(W.wx[2 * 4 + up], bin, agn);
     ahn = mfma(W.wx[3 * 4 + up], bin, ahn);
     float rr[4], zz[4], nn[4];
+    {
+      // gates on unit pairs: the non-transcendental half of the math runs as v_pk_* (same formulas as sigmoidf_ /
+      // tanhf_ in flow_math.h; VALU instructions of a wave do not overlap its own MFMAs, so fewer is faster)
+      using f2 = __attribute__((ext_vector_type(2))) float;
+      const f2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+      constexpr float L2E = 1.4426950408889634f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      rr[r] = sigmoidf_(ar[r]);
-      zz[r] = sigmoidf_(az[r]);
-      nn[r] = tanhf_(fmaf(rr[r], ahn[r], agn[r]));
-      Hn[up * 4 + r] = fmaf(zz[r], H[up * 4 + r] - nn[r], nn[r]);  // (1-z)*n + z*h
+      for (int h = 0; h < 2; ++h) {
+        const f2 pr = f2{ar[2 * h], ar[2 * h + 1]} * f2{-L2E, -L2E};
+        const f2 pz = f2{az[2 * h], az[2 * h + 1]} * f2{-L2E, -L2E};
+        const f2 er = {__builtin_amdgcn_exp2f(pr.x), __builtin_amdgcn_exp2f(pr.y)};
+        const f2 ez = {__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)};
+        const f2 dr = er + one, dz = ez + one;
+        const f2 r2 = {rcpf_(dr.x), rcpf_(dr.y)};
+        const f2 z2 = {rcpf_(dz.x), rcpf_(dz.y)};
+        const f2 pre = __builtin_elementwise_fma(r2, f2{ahn[2 * h], ahn[2 * h + 1]}, f2{agn[2 * h], agn[2 * h + 1]});
+        const f2 pn = pre * f2{2.0f * L2E, 2.0f * L2E};
+        const f2 en = {__builtin_amdgcn_exp2f(pn.x), __builtin_amdgcn_exp2f(pn.y)};
+        const f2 dn = en + one;
+        const f2 in2 = {rcpf_(dn.x), rcpf_(dn.y)};
+        const f2 n2 = one - two * in2;
+        const f2 hold = {H[up * 4 + 2 * h], H[up * 4 + 2 * h + 1]};
+        const f2 hn = __builtin_elementwise_fma(z2, hold - n2, n2);  // (1-z)*n + z*h
+        rr[2 * h] = r2.x;
+        rr[2 * h + 1] = r2.y;
+        zz[2 * h] = z2.x;
+        zz[2 * h + 1] = z2.y;
+        nn[2 * h] = n2.x;
+        nn[2 * h + 1] = n2.y;
+        Hn[up * 4 + 2 * h] = hn.x;
+        Hn[up * 4 + 2 * h + 1] = hn.y;
+      }
     }
     if (SAVE) {
       tape_st(tape + (up * 5 + 0) * 64, H[up * 4], H[up * 4 + 1], H[up * 4 + 2], H[up * 4 + 3]);
