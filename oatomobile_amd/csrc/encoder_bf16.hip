@@ -23,7 +23,18 @@ __device__ __forceinline__ unsigned f2bf(float f) {  // round to nearest even
   const unsigned u = __float_as_uint(f);
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+// two fp32 -> one packed bf16 pair, round to nearest even: a single v_cvt_pk_bf16_f32 (the integer sequence above is
+// ~10 VALU instructions per pair, and the GEMM epilogues convert 32-64 values per lane and tile)
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+  union {
+    b2_t h;
+    unsigned u;
+  } c;
+  c.h = __builtin_convertvector(f2_t{lo, hi}, b2_t);
+  return c.u;
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
