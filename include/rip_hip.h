@@ -142,6 +142,13 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
                float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
                rip_stream_t stream);
 
+/* N5 — the sensor step in front of R2: carla_lidar_measurement_to_ndarray
+ * (oatomobile/utils/carla.py:165-233) on already parsed point clouds.  points_dev [P_total,3] fp32 (x, y, z as in
+ * LidarMeasurement.raw_data, :212-213); offsets_dev [B+1] int32, observation b owns points [offsets[b], offsets[b+1]);
+ * bev_dev [B,200,200,2] fp32: per height channel (z <= -2.5 / z >= -2.5) the np.histogramdd counts over
+ * np.linspace(-50, 51, 201)^2, clipped at 5 and divided by 5.  Bit-exact with the reference.  Stateless. */
+int rip_lidar_bev(const float* points_dev, const int32_t* offsets_dev, int B, float* bev_dev, rip_stream_t stream);
+
 /* R10 — ImitativeModel.forward mode search for model k (dim/model.py:76-141):
  * z_dev [B,64] (= _params), x0_dev [B,4,2] (the caller draws the base sample,
  * :100-104), goal_dev [B,G,2] or NULL.  One scalar loss (batch mean) and one

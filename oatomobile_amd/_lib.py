@@ -29,6 +29,7 @@ SIGNATURES = [
     ("rip_score", c_int,
      [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     ("rip_aggregate_scores", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("rip_lidar_bev", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     ("rip_search", c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p,
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p

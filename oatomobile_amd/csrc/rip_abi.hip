@@ -261,6 +261,13 @@ int rip_aggregate_scores(const float* S_dev, int K, int B, int N, int algorithm,
   return RIP_OK;
 }
 
+int rip_lidar_bev(const float* points_dev, const int32_t* offsets_dev, int B, float* bev_dev, rip_stream_t stream) {
+  REQUIRE(B >= 0, "bad batch B=%d", B);
+  REQUIRE(B == 0 || (offsets_dev != nullptr && bev_dev != nullptr), "offsets_dev / bev_dev is NULL");
+  HIP_TRY(launch_lidar_bev(points_dev, offsets_dev, B, bev_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
 static int ensure_plans(rip_handle* h, size_t rows) {
   if (rows <= h->plans_cap) return RIP_OK;
   if (h->plans) (void)hipFree(h->plans);

@@ -509,3 +509,30 @@ def test_abi_error_paths(dev):
   with pytest.raises(_lib.RipError):
     hd.load_model(0, np.zeros(10, np.float32))
   hd.close()
+
+
+def test_g9_lidar_bev_bit_exact(golden, dev):
+  """rip_lidar_bev (carla_lidar_measurement_to_ndarray, utils/carla.py:165-233) against the golden
+  fixtures from the reference function and against the oracle on a ragged batch: integer work, bit-exact."""
+  from oatomobile_amd import lidar_to_bev
+  from oracle import lidar as L
+  g = golden("g9_lidar.npz")
+  clouds = [g["points%d" % i] for i in range(4)]
+  batch = lidar_to_bev(clouds, device=dev).cpu().numpy()
+  assert batch.shape == (4, 200, 200, 2) and batch.dtype == np.float32
+  for i in range(4):
+    np.testing.assert_array_equal(batch[i], g["bev%d" % i], err_msg="cloud %d" % i)
+  np.testing.assert_array_equal(lidar_to_bev(clouds[0], device=dev).cpu().numpy(), g["bev0"])  # single cloud
+  # larger ragged batch, sizes 0 .. 120k points, values straddling every edge
+  rng = np.random.default_rng(90)
+  big = []
+  for i, n in enumerate([0, 1, 63, 1024, 1025, 40000, 120000, 7]):
+    pts = np.c_[rng.uniform(-55, 56, size=(n, 2)), rng.uniform(-4, -1, size=(n, 1))].astype(np.float32)
+    pts[::5, 2] = -2.5
+    pts[1::7, 0] = L.bev_edges().astype(np.float32)[rng.integers(0, 201, size=len(pts[1::7]))]
+    big.append(pts)
+  out = lidar_to_bev(big, device=dev).cpu().numpy()
+  for i, pts in enumerate(big):
+    np.testing.assert_array_equal(out[i], L.lidar_to_bev(pts), err_msg="ragged cloud %d (%d points)" % (i, len(pts)))
+  # property at full size: the histogram of a concatenation is the clipped sum (counts <= 5 per cell and channel)
+  assert out.min() >= 0.0 and out.max() <= 1.0 and set(np.unique(out)).issubset({np.float32(k / 5) for k in range(6)})

@@ -148,3 +148,23 @@ def test_interpolate_plan_matches_scipy():
   out = O.interpolate_plan(plan)
   np.testing.assert_allclose(out[:, :2], ref, atol=1e-12)
   assert np.all(out[:, 2] == 0)
+
+
+def test_g9_lidar_bev_oracle_matches_reference(golden):
+  """oracle/lidar.py against the reference's carla_lidar_measurement_to_ndarray (utils/carla.py:165-233) on a
+  CARLA-like frame, on points exactly on bin edges / the outer edges / z == -2.5 / NaN / inf, on a saturated cell
+  and on an empty cloud: bit-exact (integer counts)."""
+  from oracle import lidar as L
+  g = golden("g9_lidar.npz")
+  for i in range(4):
+    bev = L.lidar_to_bev(g["points%d" % i])
+    assert bev.dtype == np.float32 and bev.shape == (200, 200, 2)
+    np.testing.assert_array_equal(bev, g["bev%d" % i])
+  # the bin rule the kernel restates (guess + fix-up on the float64 edge table) agrees with np.histogramdd
+  e = L.bev_edges()
+  assert len(e) == 201 and e[0] == -50.0 and e[-1] == 51.0 and abs(e[1] - e[0] - 0.505) < 1e-12
+  v = g["points1"][:, 0]
+  idx = L.bin_index(v)
+  assert idx[np.isnan(v)].tolist() == [-1] and (idx[np.isinf(v)] == -1).all()
+  assert idx[v == np.float32(51.0)].tolist() == [199] * int((v == np.float32(51.0)).sum())
+  assert (idx[v > 51.0] == -1).all() and (idx[v < -50.0] == -1).all()

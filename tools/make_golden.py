@@ -271,6 +271,52 @@ def main():
       SG.append((lp - lad).numpy() + gl)
   np.savez_compressed(os.path.join(out, "g8_scores.npz"), obs_seed=8, y=yk, zs=np.stack(zs8), S=np.stack(S), SG=np.stack(SG))
 
+  # ---- G9 LIDAR point cloud -> BEV histogram (reference function, unmodified) -----
+  # oatomobile/utils/carla.py needs `carla`, `absl.logging` and `transforms3d.euler` at import time only (the function
+  # under test touches none of them): empty stand-in modules let the reference file itself be imported and run.
+  class _Blank(types.ModuleType):  # any attribute (type annotations like carla.ServerSideSensor) resolves to `object`
+    def __getattr__(self, name):
+      if name.startswith("__"):
+        raise AttributeError(name)
+      return object
+
+  for name in ("carla", "absl", "absl.logging", "transforms3d", "transforms3d.euler"):
+    if name not in sys.modules:
+      sys.modules[name] = _Blank(name)
+  pkg_utils = types.ModuleType("oatomobile.utils")
+  pkg_utils.__path__ = [REF + "/utils"]
+  sys.modules["oatomobile.utils"] = pkg_utils
+  ref_carla = importlib.import_module("oatomobile.utils.carla")
+
+  class Measurement:  # stands for carla.LidarMeasurement: only `.raw_data` is read (utils/carla.py:212)
+    def __init__(self, points):
+      self.raw_data = np.ascontiguousarray(points, dtype=np.float32).tobytes()
+
+  rng = np.random.default_rng(9)
+  edges = np.linspace(-50, 51, 201)
+  clouds = []
+  # (a) a CARLA-like frame: dense near the car, heights around the -2.5 m split, some out of range
+  a = np.c_[rng.normal(0, 18, size=(20000, 2)), rng.normal(-2.4, 0.6, size=(20000, 1))].astype(np.float32)
+  clouds.append(a)
+  # (b) edge cases: points exactly on bin edges (as float32), on the outer edges, z exactly -2.5, NaN / inf, far outliers
+  eb = edges.astype(np.float32)
+  b = np.stack([np.r_[eb, eb[::-1], np.float32(51.0), np.float32(-50.0), np.nextafter(np.float32(51.0), np.float32(60)),
+                      np.nextafter(np.float32(-50.0), np.float32(-60)), np.float32(np.nan), np.float32(np.inf), np.float32(1e9)],
+                np.r_[eb[::-1], eb, np.float32(51.0), np.float32(-50.0), np.float32(0.0), np.float32(0.0), np.float32(0.0),
+                      np.float32(0.0), np.float32(0.0)],
+                np.r_[np.full(201, -2.5), np.full(201, -2.5), -2.5, -2.5, -3.0, -1.0, -3.0, -1.0, -3.0].astype(np.float32)], axis=1)
+  clouds.append(b.astype(np.float32))
+  # (c) one cell hit far more often than the clip, and an empty cloud
+  c = np.tile(np.array([[3.3, -7.7, -3.0]], np.float32), (1000, 1))
+  c[::2, 2] = -1.0
+  clouds.append(c)
+  clouds.append(np.zeros((0, 3), np.float32))
+  g9 = {}
+  for i, pts in enumerate(clouds):
+    g9["points%d" % i] = pts
+    g9["bev%d" % i] = ref_carla.carla_lidar_measurement_to_ndarray(Measurement(pts))
+  np.savez_compressed(os.path.join(out, "g9_lidar.npz"), **g9)
+
   tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
   print("wrote", sorted(os.listdir(out)), "total bytes", tot)
 
