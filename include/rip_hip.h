@@ -149,6 +149,16 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
  * np.linspace(-50, 51, 201)^2, clipped at 5 and divided by 5.  Bit-exact with the reference.  Stateless. */
 int rip_lidar_bev(const float* points_dev, const int32_t* offsets_dev, int B, float* bev_dev, rip_stream_t stream);
 
+/* N4 — BehaviouralModel.forward after the encoder (oatomobile/baselines/torch/cil/model.py:88-127):
+ * merger MLP over cat(features, velocity, is_at_traffic_light, traffic_light_state, mode), then the GRUCell + Linear
+ * residual rollout.  feat_dev [B,128] = MobileNetV2 logits (rip_encode's feat_dev of a handle loaded with the model's
+ * encoder); vec_dev [B,6]; weights_dev = rip_cil_blob_floats() fp32 values in BehaviouralModel.state_dict() order
+ * (_merger._model.{0,2,4}.{weight,bias}, _decoder.{weight_ih,weight_hh,bias_ih,bias_hh}, _output.{weight,bias});
+ * y_dev [B,T,2] (T = 40 in the reference).  Stateless. */
+int rip_cil_decode(const float* feat_dev, const float* vec_dev, const float* weights_dev, int B, int T, float* y_dev,
+                   rip_stream_t stream);
+int rip_cil_blob_floats(void);
+
 /* R10 — ImitativeModel.forward mode search for model k (dim/model.py:76-141):
  * z_dev [B,64] (= _params), x0_dev [B,4,2] (the caller draws the base sample,
  * :100-104), goal_dev [B,G,2] or NULL.  One scalar loss (batch mean) and one

@@ -10,6 +10,9 @@ from oatomobile_amd.agents import SetPointAgent
 from oatomobile_amd.model import ImitativeModel
 from oatomobile_amd.model import transform_visual
 
+from oatomobile_amd.cil import BehaviouralModel
+from oatomobile_amd.cil import CILAgent
 from oatomobile_amd.lidar import lidar_to_bev
 
-__all__ = ["ImitativeModel", "RIPAgent", "DIMAgent", "SetPointAgent", "transform_visual", "lidar_to_bev"]
+__all__ = ["ImitativeModel", "RIPAgent", "DIMAgent", "SetPointAgent", "transform_visual", "lidar_to_bev",
+           "BehaviouralModel", "CILAgent"]

@@ -30,6 +30,8 @@ SIGNATURES = [
      [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     ("rip_aggregate_scores", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("rip_lidar_bev", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    ("rip_cil_decode", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    ("rip_cil_blob_floats", c_int, []),
     ("rip_search", c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p,
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p

@@ -134,3 +134,36 @@ def packed_numel(in_channels: int = 2) -> int:
       m *= d
     n += m
   return n
+
+
+# ------------------------------------------------------------------------------------------------
+# BehaviouralModel (conditional imitation learning; oatomobile/baselines/torch/cil/model.py:34-66):
+# the same MobileNetV2 encoder, a merger over 128 + 3 + 1 + 1 + 1 inputs (the extra scalar is `mode`), a bare
+# GRUCell(2, 64) and a Linear(64, 2) head unrolled for T = 40 steps.
+# ------------------------------------------------------------------------------------------------
+CIL_VECTOR_INPUTS = 6
+CIL_TIMESTEPS = 40
+
+
+def cil_decoder_spec():
+  """Ordered `(key, shape)` list of the non-encoder tensors of `BehaviouralModel.state_dict()`; also the layout of the
+  fp32 blob `rip_cil_decode` consumes."""
+  spec = []
+  sizes = (NUM_FEATURES + CIL_VECTOR_INPUTS,) + MERGER_SIZES
+  for i in range(3):
+    spec.append(("_merger._model.%d.weight" % (2 * i), (sizes[i + 1], sizes[i])))
+    spec.append(("_merger._model.%d.bias" % (2 * i), (sizes[i + 1],)))
+  g = 3 * HIDDEN_SIZE
+  spec.append(("_decoder.weight_ih", (g, 2)))
+  spec.append(("_decoder.weight_hh", (g, HIDDEN_SIZE)))
+  spec.append(("_decoder.bias_ih", (g,)))
+  spec.append(("_decoder.bias_hh", (g,)))
+  spec.append(("_output.weight", (2, HIDDEN_SIZE)))
+  spec.append(("_output.bias", (2,)))
+  return spec
+
+
+def cil_state_dict_spec(in_channels: int = 2):
+  """Ordered `(key, shape)` list of the reference `BehaviouralModel.state_dict()`."""
+  enc = [(k, s) for (k, s) in state_dict_spec(in_channels) if k.startswith("_encoder.")]
+  return enc + cil_decoder_spec()

@@ -58,6 +58,8 @@ hipError_t launch_select_best(const float* plans, const float* loss_best, int B,
                               hipStream_t s);
 hipError_t launch_dim_select(const float* flow_w_k, const float* z, const float* x0, const float* trace_loss,
                              const float* trace_x, int B, int num_steps, float* y, float* trace_mean, hipStream_t s);
+hipError_t launch_cil_decode(const float* feat, const float* vec, const float* w, int B, int T, float* y, hipStream_t s);  // cil.hip
+int cil_blob_floats();
 hipError_t launch_lidar_bev(const float* points, const int* offsets, int B, float* bev, hipStream_t s);  // lidar.hip
 hipError_t launch_aggregate_scores(const float* S, int K, int B, int N, int algorithm, float* loss, int32_t* best,
                                    hipStream_t s);

@@ -268,6 +268,17 @@ int rip_lidar_bev(const float* points_dev, const int32_t* offsets_dev, int B, fl
   return RIP_OK;
 }
 
+int rip_cil_decode(const float* feat_dev, const float* vec_dev, const float* weights_dev, int B, int T, float* y_dev,
+                   rip_stream_t stream) {
+  REQUIRE(B >= 0 && T >= 1, "bad shape B=%d T=%d", B, T);
+  REQUIRE(B == 0 || (feat_dev != nullptr && vec_dev != nullptr && weights_dev != nullptr && y_dev != nullptr),
+          "NULL argument");
+  HIP_TRY(launch_cil_decode(feat_dev, vec_dev, weights_dev, B, T, y_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_cil_blob_floats(void) { return cil_blob_floats(); }
+
 static int ensure_plans(rip_handle* h, size_t rows) {
   if (rows <= h->plans_cap) return RIP_OK;
   if (h->plans) (void)hipFree(h->plans);

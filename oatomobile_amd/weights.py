@@ -65,3 +65,52 @@ def pack_state_dict(state_dict: Mapping[str, "np.ndarray"], in_channels: int = 2
                        (key, tuple(shape), tuple(t.shape)))
     parts.append(t.reshape(-1))
   return np.ascontiguousarray(np.concatenate(parts))
+
+
+def synthetic_cil_state_dict(seed: int, in_channels: int = 2) -> "collections.OrderedDict[str, np.ndarray]":
+  """`BehaviouralModel` weights (cil/model.py:34-66): the encoder tensors of `synthetic_state_dict(seed)` plus merger /
+  GRUCell / output head drawn from a second stream of the same seed."""
+  enc = synthetic_state_dict(seed, in_channels)
+  out = collections.OrderedDict((k, v) for k, v in enc.items() if k.startswith("_encoder."))
+  rng = np.random.default_rng([seed, 0xC11])
+  for key, shape in arch.cil_decoder_spec():
+    if len(shape) == 2:
+      scale = np.sqrt(3.0 / shape[1])
+      if key.startswith("_output"):
+        scale *= 0.5
+      v = rng.uniform(-1.0, 1.0, size=shape) * scale
+    else:
+      v = rng.uniform(-0.1, 0.1, size=shape)
+    out[key] = np.ascontiguousarray(v, dtype=np.float32)
+  return out
+
+
+def pack_cil_decoder(state_dict: Mapping[str, "np.ndarray"]) -> np.ndarray:
+  """The merger / GRUCell / head tensors of a `BehaviouralModel` state_dict as the flat fp32 blob of `rip_cil_decode`
+  (order = `arch.cil_decoder_spec`)."""
+  parts = []
+  for key, shape in arch.cil_decoder_spec():
+    if key not in state_dict:
+      raise KeyError("Missing key in state_dict: %s" % key)
+    t = state_dict[key]
+    if hasattr(t, "detach"):
+      t = t.detach().cpu().numpy()
+    t = np.asarray(t, dtype=np.float32)
+    if tuple(t.shape) != tuple(shape):
+      raise ValueError("size mismatch for %s: expected %s, got %s" % (key, tuple(shape), tuple(t.shape)))
+    parts.append(t.reshape(-1))
+  return np.ascontiguousarray(np.concatenate(parts))
+
+
+def encoder_only_packed(state_dict: Mapping[str, "np.ndarray"], in_channels: int = 2) -> np.ndarray:
+  """A `rip_load_model` blob that carries only the `_encoder.*` tensors of `state_dict` (merger / flow tensors zero):
+  lets a handle run the MobileNetV2 encoder (`rip_encode`'s feature output) for models that are not ImitativeModels."""
+  full = {}
+  for key, shape in arch.packed_spec(in_channels):
+    if key.startswith("_encoder."):
+      if key not in state_dict:
+        raise KeyError("Missing key in state_dict: %s" % key)
+      full[key] = state_dict[key]
+    else:
+      full[key] = np.zeros(shape, dtype=np.float32)
+  return pack_state_dict(full, in_channels)

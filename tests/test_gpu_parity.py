@@ -536,3 +536,44 @@ def test_g9_lidar_bev_bit_exact(golden, dev):
     np.testing.assert_array_equal(out[i], L.lidar_to_bev(pts), err_msg="ragged cloud %d (%d points)" % (i, len(pts)))
   # property at full size: the histogram of a concatenation is the clipped sum (counts <= 5 per cell and channel)
   assert out.min() >= 0.0 and out.max() <= 1.0 and set(np.unique(out)).issubset({np.float32(k / 5) for k in range(6)})
+
+
+def test_g10_cil_forward_and_agent(golden, dev):
+  """BehaviouralModel.forward / CILAgent.__call__ through rip_encode + rip_cil_decode against the
+  golden fixtures from the reference classes and against the oracle on a fresh batch.  1e-4 fp32 relative to the plan
+  scale (40 residual steps reach tens of metres)."""
+  from oatomobile_amd import BehaviouralModel, CILAgent, weights
+  from oracle import cil as C
+  g = golden("g10_cil.npz")
+  ws = int(g["weight_seed"])
+  m = BehaviouralModel.synthetic(ws).to(dev)
+  ctx = {k[4:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("ctx_")}
+  y = m(**ctx).cpu().numpy()
+  assert y.shape == (6, 40, 2)
+  np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=1e-4 * np.abs(g["y"]).max())
+  # agent level, one observation per command branch
+  agent = CILAgent(None, model=m, device=dev)
+  for i in range(3):
+    ob = synth_observation(np.random.default_rng(int(g["agent_obs_seed%d" % i])))
+    ob["goal"] = np.asarray(ob["goal"], np.float32).copy()
+    ob["goal"][-1, :2] = g["agent_goal_last%d" % i]
+    plan = agent(dict(ob))
+    assert plan.shape == (39, 3)
+    np.testing.assert_allclose(plan, g["agent_plan%d" % i], rtol=1e-4, atol=1e-4 * np.abs(g["agent_plan%d" % i]).max())
+  # a larger batch against the oracle (fresh weights), including the transform with the STOP -> 0 rewrite
+  mo = C.OracleBehaviouralModel.from_numpy_state_dict(weights.synthetic_cil_state_dict(31))
+  mh = BehaviouralModel.synthetic(31).to(dev)
+  rng = np.random.default_rng(310)
+  B = 37
+  raw = dict(lidar=rng.random((B, 2, 200, 200), dtype=np.float32) * (rng.random((B, 2, 200, 200)) < 0.1),
+             velocity=rng.normal(0, 3, size=(B, 3)).astype(np.float32),
+             is_at_traffic_light=rng.integers(0, 2, size=(B, 1)).astype(np.float32),
+             traffic_light_state=rng.integers(0, 4, size=(B, 1)).astype(np.float32),
+             mode=rng.integers(0, 4, size=(B, 1)).astype(np.float32))
+  so = mo.transform({k: torch.from_numpy(v.astype(np.float32).copy()) for k, v in raw.items()})
+  sh = mh.transform({k: torch.from_numpy(v.astype(np.float32).copy()).to(dev) for k, v in raw.items()})
+  np.testing.assert_array_equal(sh["mode"].cpu().numpy(), so["mode"].numpy())
+  with torch.no_grad():
+    yo = mo(**so).numpy()
+  yh = mh(**sh).cpu().numpy()
+  np.testing.assert_allclose(yh, yo, rtol=1e-4, atol=1e-4 * np.abs(yo).max())

@@ -163,3 +163,22 @@ def test_replay_datum_and_episode_format(tmp_path):
   g = replay.goal_from_future(frames[0]["player_future"])
   np.testing.assert_allclose(g, frames[0]["player_future"][7::8][:10, :2].astype(np.float32))
   assert replay.goal_from_future(frames[0]["player_future"][:20]).shape == (10, 2)  # padded
+
+
+def test_cil_model_state_dict_and_command_logic():
+  """BehaviouralModel mirrors the reference's state_dict (cil/model.py:34-66) and CILAgent's command rule
+  (cil/agent.py:66-77); no device needed."""
+  import numpy as np
+  from oatomobile_amd import BehaviouralModel, arch, weights
+  from oatomobile_amd.cil import command_from_goal
+  m = BehaviouralModel.synthetic(4)
+  sd = weights.synthetic_cil_state_dict(4)
+  assert list(m.state_dict().keys()) == list(sd.keys()) == [k for k, _ in arch.cil_state_dict_spec()]
+  for k, v in m.state_dict().items():
+    np.testing.assert_array_equal(v.numpy(), sd[k])
+  assert weights.pack_cil_decoder(sd).size == 30146
+  assert weights.encoder_only_packed(sd).size == arch.packed_numel()
+  assert [command_from_goal(g) for g in ((1.0, 0.5), (10.0, 12.0), (20.0, 1.0), (0.0, 2.9), (-5.0, 0.0))] == [1, 2, 3, 1, 2]
+  import pytest
+  with pytest.raises(ValueError, match="Missing `mode`"):
+    m(visual_features=None, velocity=None, is_at_traffic_light=None, traffic_light_state=None)

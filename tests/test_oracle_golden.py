@@ -168,3 +168,29 @@ def test_g9_lidar_bev_oracle_matches_reference(golden):
   assert idx[np.isnan(v)].tolist() == [-1] and (idx[np.isinf(v)] == -1).all()
   assert idx[v == np.float32(51.0)].tolist() == [199] * int((v == np.float32(51.0)).sum())
   assert (idx[v > 51.0] == -1).all() and (idx[v < -50.0] == -1).all()
+
+
+def test_g10_cil_oracle_matches_reference(golden):
+  """oracle/cil.py against the reference's BehaviouralModel.forward (cil/model.py:68-127) and CILAgent.__call__
+  (cil/agent.py:45-97; one observation per command branch).  Tolerance: fp32 rounding of the CPU convolutions (the
+  plans reach +-80 m after 40 residual steps)."""
+  import torch
+  from oatomobile_amd import weights
+  from oracle import cil as C
+  from tests.helpers import synth_observation
+  g = golden("g10_cil.npz")
+  sd = weights.synthetic_cil_state_dict(int(g["weight_seed"]))
+  m = C.OracleBehaviouralModel.from_numpy_state_dict(sd)
+  assert list(m.state_dict().keys()) == list(sd.keys())  # == the reference's keys (the generator loads them strict)
+  ctx = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ctx_")}
+  with torch.no_grad():
+    y = m(**ctx).numpy()
+  np.testing.assert_allclose(y, g["y"], rtol=2e-5, atol=2e-4)
+  for i, expect in enumerate((1, 2, 3)):
+    ob = synth_observation(np.random.default_rng(int(g["agent_obs_seed%d" % i])))
+    ob["goal"] = np.asarray(ob["goal"], np.float32).copy()
+    ob["goal"][-1, :2] = g["agent_goal_last%d" % i]
+    assert C.command_from_goal(ob["goal"][-1, :2]) == expect
+    plan = C.cil_call(m, ob)
+    assert plan.shape == (39, 3)
+    np.testing.assert_allclose(plan, g["agent_plan%d" % i], rtol=2e-5, atol=2e-4)

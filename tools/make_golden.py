@@ -317,6 +317,42 @@ def main():
     g9["bev%d" % i] = ref_carla.carla_lidar_measurement_to_ndarray(Measurement(pts))
   np.savez_compressed(os.path.join(out, "g9_lidar.npz"), **g9)
 
+  # ---- G10 conditional imitation learning: BehaviouralModel.forward / CILAgent.__call__ (reference classes) ------
+  pkg_cil = types.ModuleType("oatomobile.baselines.torch.cil")
+  pkg_cil.__path__ = [REF + "/baselines/torch/cil"]
+  sys.modules["oatomobile.baselines.torch.cil"] = pkg_cil
+  cil_model = importlib.import_module("oatomobile.baselines.torch.cil.model")
+  cil_agent = importlib.import_module("oatomobile.baselines.torch.cil.agent")
+  wseed = 10
+  bm = cil_model.BehaviouralModel()
+  bm.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in W.synthetic_cil_state_dict(wseed).items()}, strict=True)
+  bm.eval()
+  rng = np.random.default_rng(10)
+  Bc = 6
+  vis = rng.random((Bc, 2, 100, 100), dtype=np.float32)
+  vis[:, :, 30:70, 55:] = 0
+  ctx = dict(visual_features=vis, velocity=rng.normal(0, 3, size=(Bc, 3)).astype(np.float32),
+             is_at_traffic_light=rng.integers(0, 2, size=(Bc, 1)).astype(np.float32),
+             traffic_light_state=rng.integers(0, 4, size=(Bc, 1)).astype(np.float32),
+             mode=np.array([[0], [2], [3], [0], [2], [3]], np.float32))
+  with torch.no_grad():
+    yc = bm(**{k: torch.from_numpy(v) for k, v in ctx.items()}).numpy()
+  g10 = dict(weight_seed=wseed, y=yc, **{"ctx_" + k: v for k, v in ctx.items()})
+  # agent level: one synthetic observation per command branch (STOP / LEFT / RIGHT)
+  agent = cil_agent.CILAgent(None, model=bm)
+  agent._device = torch.device("cpu")
+  agent._model = bm
+  for i, goal_last in enumerate([(1.0, 0.5), (10.0, 12.0), (20.0, 1.0)]):
+    ob = synth_observation(np.random.default_rng(100 + i))
+    ob["goal"] = np.asarray(ob["goal"], np.float32).copy()
+    ob["goal"][-1, :2] = goal_last
+    ob["bird_view_camera_cityscapes"] = np.zeros((2, 2, 3), np.float32)
+    plan = agent(dict(ob))  # scalars stay numpy scalars: the agent wraps them with np.atleast_1d (cil/agent.py:54-57)
+    g10["agent_obs_seed%d" % i] = 100 + i
+    g10["agent_goal_last%d" % i] = np.asarray(goal_last, np.float32)
+    g10["agent_plan%d" % i] = plan
+  np.savez_compressed(os.path.join(out, "g10_cil.npz"), **g10)
+
   tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
   print("wrote", sorted(os.listdir(out)), "total bytes", tot)
 
