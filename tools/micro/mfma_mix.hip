@@ -43,19 +43,21 @@ __global__ __launch_bounds__(256) void mix_kernel(float* out, long long* cyc, in
 }
 
 template <int MODE>
-void run(const char* what, float* out, long long* cyc) {
+void run(const char* what, float* out, long long* cyc, int waves_per_simd = 1) {
   const int iters = 400;
-  hipLaunchKernelGGL((mix_kernel<MODE>), dim3(256), dim3(256), 0, 0, out, cyc, iters);
+  // 256 threads = one wave per SIMD; 256 CUs x waves_per_simd workgroups
+  hipLaunchKernelGGL((mix_kernel<MODE>), dim3(256 * waves_per_simd), dim3(256), 0, 0, out, cyc, iters);
   hipDeviceSynchronize();
   long long c;
   hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
-  printf("%-58s %.1f cycles per MFMA\n", what, (double)c / (iters * 48.0));
+  printf("%-58s %d wave(s)/SIMD: %.1f cycles per MFMA per wave = %.1f per MFMA on the pipe\n", what, waves_per_simd,
+         (double)c / (iters * 48.0), (double)c / (iters * 48.0) / waves_per_simd);
 }
 
 int main() {
   float* out;
   long long* cyc;
-  hipMalloc(&out, 256 * 256 * sizeof(float));
+  hipMalloc(&out, 4 * 256 * 256 * sizeof(float));
   hipMalloc(&cyc, sizeof(long long));
   run<0>("48 distinct VGPR A operands", out, cyc);
   run<1>("A operands pinned to AGPRs", out, cyc);
@@ -63,5 +65,11 @@ int main() {
   run<3>("+ 6 independent v_fma per MFMA", out, cyc);
   run<4>("+ v_exp + v_rcp per MFMA", out, cyc);
   run<5>("+ VALU reading the MFMA result issued 2 MFMAs earlier", out, cyc);
+  // the same mixes with two / four waves sharing a SIMD: does another wave's MFMA fill the gaps?
+  run<0>("48 distinct VGPR A operands", out, cyc, 2);
+  run<3>("+ 6 independent v_fma per MFMA", out, cyc, 2);
+  run<4>("+ v_exp + v_rcp per MFMA", out, cyc, 2);
+  run<3>("+ 6 independent v_fma per MFMA", out, cyc, 4);
+  run<4>("+ v_exp + v_rcp per MFMA", out, cyc, 4);
   return 0;
 }
