@@ -4,10 +4,10 @@
 // torchvision v0.6.0 `InvertedResidual` (reference call site oatomobile/torch/networks/perception.py:36-51), BN
 // folded.  Layer by layer these blocks are pure HBM traffic: the t-times expanded tensor is written once and read
 // once (features.2 at 256 observations x 4 models: 0.49 GB each way for 0.08 GB of block input).  Here it only ever
-// exists as three rows per 32-channel chunk in LDS.
+// exists as three rows per 48-channel chunk in LDS.
 //
-// Decomposition: a workgroup owns (model, observation, band of output rows) and has one wave per 32 hidden channels
-// (NW = ceil(HID / 32) waves).  Walking down the band, per output row each wave
+// Decomposition: a workgroup owns (model, observation, band of output rows) and has one wave per CW hidden channels
+// (CW = 48: NW = HID / 48 = 3 or 4 waves for HID = 144 / 192; CW = 32, NW = 3 for HID = 96).  Walking down the band, per output row each wave
 //   1. expands the new input row(s) for ITS hidden chunk (A = 2 weight tiles held in registers, B = 16-pixel operands
 //      loaded from the block input one row ahead) into its private 3-row LDS ring  -- wave-local, no barrier;
 //   2. runs the 3x3 depthwise for its chunk from the ring (register window over rows, packed fp32 math) and writes the
@@ -83,7 +83,6 @@ struct IrbArgs {
   int WP;               // H_out rounded up to 16
 };
 
-constexpr int ELD = 40;  // bf16 elements per ring pixel slot: 32 channels + 8 pad (80-byte pitch)
 
 // STRIDE: depthwise stride; R: outputs per depthwise lane along x; EXPAND: false for the t = 1 block; NW: waves =
 // 32-channel hidden chunks; TPW: projection tiles per wave; NPT: 16-pixel tiles per input row; WINDOW: keep the rows
@@ -91,10 +90,17 @@ constexpr int ELD = 40;  // bf16 elements per ring pixel slot: 32 channels + 8 p
 // APREG: projection weights stay in registers for the band (else re-read from L1 each row, after the depthwise);
 // WLDS: depthwise taps are read from an LDS copy per use instead of living in 72 registers (register-tight variants:
 // a spill reload waits on vmcnt, i.e. on every input prefetch still in flight).
-template <int STRIDE, int R, bool EXPAND, int NW, int TPW, int NPT, bool WINDOW, bool APREG, bool WLDS>
+template <int STRIDE, int R, bool EXPAND, int NW, int TPW, int NPT, bool WINDOW, bool APREG, bool WLDS, int CW, int KS>
 __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
   constexpr int COLS = (R - 1) * STRIDE + 3;
-  constexpr int DLD = NW * 32 + 8;  // bf16 elements per projection-operand pixel row
+  // CW: hidden channels per wave (32 or 48: HID = 96 / 144 / 192 split over 2 / 3 / 4 waves keeps every SIMD equally
+  // loaded -- with 32-channel chunks NW = 5 or 6 waves share 4 SIMDs and the row barrier waits for the SIMD that hosts
+  // two of them); KS: 32-wide K steps of the projection (ceil(HID / 32), independent of CW)
+  constexpr int CG = CW / 8;        // 8-channel groups per wave = depthwise lanes per run
+  constexpr int NHT = CW / 16;      // 16-channel MFMA tiles of the expansion per wave
+  constexpr int ELD = CW + 8;       // bf16 elements per ring pixel slot (+8 pad: odd multiple of 16 bytes)
+  constexpr int DCOLS = (NW * CW > KS * 32 ? NW * CW : KS * 32);
+  constexpr int DLD = DCOLS + 8;    // bf16 elements per projection-operand pixel row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem_raw);
   const int lane = threadIdx.x & 63;
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
   const int CIN = a.CIN, HID = a.HID, COUT = a.COUT, H_in = a.H_in, H_out = a.H_out, EW = a.EW, WP = a.WP;
   bf16_t* es = lds + (size_t)w * 3 * EW * ELD;        // this wave's ring: [3][EW][ELD]
   bf16_t* ds = lds + (size_t)NW * 3 * EW * ELD;       // [2][WP][DLD]
-  float* wl = reinterpret_cast<float*>(ds + (size_t)2 * WP * DLD);  // [9][NW*32] depthwise taps (WLDS)
-  const bf16_t* zrow = ds + (size_t)2 * WP * DLD + (WLDS ? 9 * NW * 32 * 2 : 0);  // [EW][ELD] zeros: rows off the image
+  float* wl = reinterpret_cast<float*>(ds + (size_t)2 * WP * DLD);  // [9][NW*CW] depthwise taps (WLDS)
+  const bf16_t* zrow = ds + (size_t)2 * WP * DLD + (WLDS ? 9 * NW * CW * 2 : 0);  // [EW][ELD] zeros: rows off the image
   const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
   const bf16_t* Wh = a.whbase + (size_t)(a.k0 + k) * a.model_stride;
   const bf16_t* xin = a.x + ((size_t)k * a.B + b) * H_in * H_in * CIN;
@@ -114,36 +120,36 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
 
   // ---- zero the LDS once: ring borders / unused channels must read as 0 (never NaN) ----
   {
-    const int total16 = (NW * 3 * EW * ELD + 2 * WP * DLD + (WLDS ? 9 * NW * 32 * 2 : 0) + EW * ELD) / 8;
+    const int total16 = (NW * 3 * EW * ELD + 2 * WP * DLD + (WLDS ? 9 * NW * CW * 2 : 0) + EW * ELD) / 8;
     for (int e = threadIdx.x; e < total16; e += NW * 64) reinterpret_cast<u32x4*>(lds)[e] = zero4;
   }
 
   if (WLDS) {
     __syncthreads();
-    for (int e = threadIdx.x; e < 9 * NW * 32; e += NW * 64) {
-      const int t = e / (NW * 32), c = e - t * (NW * 32);
+    for (int e = threadIdx.x; e < 9 * NW * CW; e += NW * 64) {
+      const int t = e / (NW * CW), c = e - t * (NW * CW);
       wl[e] = c < HID ? W[a.wd_off + (size_t)t * HID + c] : 0.f;
     }
   }
 
   // ---- per-wave constants ----
-  u32x4 ae[2];
-  float4 be[2];
+  u32x4 ae[NHT];
+  float4 be[NHT];
   if (EXPAND) {
 #pragma unroll
-    for (int ht = 0; ht < 2; ++ht) {
-      const int h_row = 32 * w + 16 * ht + n;
+    for (int ht = 0; ht < NHT; ++ht) {
+      const int h_row = CW * w + 16 * ht + n;
       ae[ht] = (h_row < HID && 8 * q < CIN) ? *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)h_row * CIN + 8 * q)
                                             : zero4;
-      const int hb = 32 * w + 16 * ht + 4 * q;
+      const int hb = CW * w + 16 * ht + 4 * q;
       be[ht] = hb < HID ? *reinterpret_cast<const float4*>(W + a.be_off + hb) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  // depthwise lane = (run, c8): 4 consecutive lanes cover the chunk's 32 channels of one run
+  // depthwise lane = (run, c8): CG consecutive lanes cover the chunk's CW channels of one run
   const int runs = (H_out + R - 1) / R;
-  const int c8 = lane & 3;
-  const int run_raw = lane >> 2;
-  const int hch = 32 * w + 8 * c8;  // first hidden channel of this lane
+  const int run_raw = lane / CG;
+  const int c8 = lane - run_raw * CG;
+  const int hch = CW * w + 8 * c8;  // first hidden channel of this lane
   const bool dw_active = run_raw < runs && hch < HID;
   const int run = run_raw < runs ? run_raw : 0;
   f32x2 wt[9][4], bd[4];
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
   }
   // projection tiles of this wave: tile = w + NW * t -> (pixel tile pt, channel tile ct)
   const int n_ct = (COUT + 15) / 16, TT = (WP / 16) * n_ct;
-  u32x4 ap[TPW][NW];
+  u32x4 ap[TPW][KS];
   float4 bpj[TPW];
   auto load_ap = [&]() {
 #pragma unroll
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
       const int ct = tile % n_ct;
       const int co = 16 * ct + n;
 #pragma unroll
-      for (int ks = 0; ks < NW; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const int kk = 32 * ks + 8 * q;
         ap[t][ks] = (tile < TT && co < COUT && kk < HID)
                         ? *reinterpret_cast<const u32x4*>(Wh + a.wp_off + (size_t)co * HID + kk)
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
         const int px = 16 * i + n;
         const bool pv = px < H_in;
 #pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
+        for (int ht = 0; ht < NHT; ++ht) {
           const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
           const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ae[ht]), as_bf16x8(xr[i]), z4, 0, 0, 0);
           u32x2 o;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
       if (WLDS) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const float* wp = wl + (ky * 3 + kx) * (NW * 32) + 32 * w + 8 * c8;
+          const float* wp = wl + (ky * 3 + kx) * (NW * CW) + CW * w + 8 * c8;
           const float4 w0 = *reinterpret_cast<const float4*>(wp);
           const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
           wt[ky * 3 + kx][0] = f32x2{w0.x, w0.y};
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
       const bf16_t* brow = drow + (size_t)(16 * pt + n) * DLD + 8 * q;
 #pragma unroll
-      for (int ks = 0; ks < NW; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const u32x4 bv = *reinterpret_cast<const u32x4*>(brow + 32 * ks);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ap[t][ks]), as_bf16x8(bv), c, 0, 0, 0);
       }
@@ -379,12 +385,14 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
   }
 }
 
-template <int STRIDE, int R, bool EXPAND, int NW, int TPW, int NPT, bool WINDOW, bool APREG, bool WLDS>
+template <int STRIDE, int R, bool EXPAND, int NW, int TPW, int NPT, bool WINDOW, bool APREG, bool WLDS, int CW, int KS>
 hipError_t launch_irb(const IrbArgs& a, int kc, int bands, hipStream_t s) {
-  const size_t lds = ((size_t)NW * 3 * a.EW * ELD + (size_t)2 * a.WP * (NW * 32 + 8)) * sizeof(bf16_t) +
-                     (WLDS ? (size_t)9 * NW * 32 * sizeof(float) : 0) + (size_t)a.EW * ELD * sizeof(bf16_t);
-  hipLaunchKernelGGL((irb_rows_bf16_kernel<STRIDE, R, EXPAND, NW, TPW, NPT, WINDOW, APREG, WLDS>), dim3(bands, a.B, kc), dim3(NW * 64), lds, s,
-                     a);
+  constexpr int ELD = CW + 8;
+  constexpr int DLD = (NW * CW > KS * 32 ? NW * CW : KS * 32) + 8;
+  const size_t lds = ((size_t)NW * 3 * a.EW * ELD + (size_t)2 * a.WP * DLD) * sizeof(bf16_t) +
+                     (WLDS ? (size_t)9 * NW * CW * sizeof(float) : 0) + (size_t)a.EW * ELD * sizeof(bf16_t);
+  hipLaunchKernelGGL((irb_rows_bf16_kernel<STRIDE, R, EXPAND, NW, TPW, NPT, WINDOW, APREG, WLDS, CW, KS>),
+                     dim3(bands, a.B, kc), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
 
@@ -395,9 +403,10 @@ bool irb_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp) {
   if (ld.h_in > 64 || ld.h_in < 13) return false;  // large-image stages only (features.1 .. features.7)
   if (le == nullptr) return false;  // features.1 (t = 1, one wave per workgroup): the layer-wise pair is faster
   if (le->cin > 32) return false;
-  if (nw == 3) return ld.stride == 2 && ld.h_out <= 32 && lp.cout <= 32;
-  if (nw == 5) return lp.cout <= 32 && ((ld.stride == 1 && ld.h_out <= 32) || (ld.stride == 2 && ld.h_out <= 16));
-  if (nw == 6) return ld.h_out <= 16 && ((ld.stride == 1 && lp.cout <= 32) || (ld.stride == 2 && lp.cout <= 64));
+  (void)nw;
+  if (hid == 96) return ld.stride == 2 && ld.h_out <= 27 && lp.cout <= 32;
+  if (hid == 144) return lp.cout <= 32 && ((ld.stride == 1 && ld.h_out <= 27) || (ld.stride == 2 && ld.h_out <= 16));
+  if (hid == 192) return ld.h_out <= 16 && ((ld.stride == 1 && lp.cout <= 32) || (ld.stride == 2 && ld.h_out <= 8 && lp.cout <= 64));
   return false;
 }
 
@@ -424,8 +433,11 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
   a.H_in = ld.h_in;
   a.H_out = ld.h_out;
   a.residual = lp.residual;
-  const int nw = (a.HID + 31) / 32;
-  const int R = le == nullptr ? 4 : (ld.h_out > 16 ? 2 : 1);
+  // 48 hidden channels per wave (HID = 96 / 144 / 192 -> 2 / 3 / 4 waves): 6 depthwise lanes per run, so a wave
+  // covers at most 10 runs: R = 3 outputs per lane on the 25-wide stages, 2 on the 13-wide, 1 on the 7-wide
+  // (features.2 keeps 32-channel chunks / 3 waves / R = 2: with two 48-channel waves only 4 waves fit a CU next to
+  // its 64 KB of LDS rings, 184 vs 152 us)
+  const int R = le == nullptr ? 4 : (a.HID == 96 ? 2 : (ld.h_out > 16 ? 3 : (ld.h_out > 8 ? 2 : 1)));
   const int runs = (a.H_out + R - 1) / R;
   const int ew_taps = (runs * R - 1) * ld.stride + 3;
   a.EW = ew_taps > a.H_in + 2 ? ew_taps : a.H_in + 2;
@@ -439,12 +451,15 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
   if (bands < 1) bands = 1;
   a.band_rows = (a.H_out + bands - 1) / bands;
   bands = (a.H_out + a.band_rows - 1) / a.band_rows;
-  if (le == nullptr) return launch_irb<1, 4, false, 1, 4, 4, false, false, true>(a, kc, bands, s);
-  if (nw == 3) return launch_irb<2, 2, true, 3, 2, 4, false, false, true>(a, kc, bands, s);
-  if (nw == 5 && ld.stride == 1) return launch_irb<1, 2, true, 5, 1, 2, true, true, false>(a, kc, bands, s);
-  if (nw == 5) return launch_irb<2, 1, true, 5, 1, 2, false, true, false>(a, kc, bands, s);
-  if (nw == 6 && ld.stride == 1) return launch_irb<1, 1, true, 6, 1, 1, true, true, false>(a, kc, bands, s);
-  if (nw == 6) return launch_irb<2, 1, true, 6, 1, 1, false, true, false>(a, kc, bands, s);
+  if (le == nullptr) return launch_irb<1, 4, false, 1, 4, 4, false, false, true, 32, 1>(a, kc, bands, s);
+  //                     STRIDE R EXPAND NW TPW NPT WINDOW APREG WLDS CW KS
+  if (a.HID == 96) return launch_irb<2, 2, true, 3, 2, 4, false, false, true, 32, 3>(a, kc, bands, s);    // features.2
+  if (a.HID == 144 && ld.stride == 1)
+    return launch_irb<1, 3, true, 3, 2, 2, true, false, false, 48, 5>(a, kc, bands, s);                    // features.3
+  if (a.HID == 144) return launch_irb<2, 2, true, 3, 1, 2, false, true, false, 48, 5>(a, kc, bands, s);   // features.4
+  if (a.HID == 192 && ld.stride == 1)
+    return launch_irb<1, 2, true, 4, 1, 1, true, true, false, 48, 6>(a, kc, bands, s);                     // features.5, 6
+  if (a.HID == 192) return launch_irb<2, 1, true, 4, 1, 1, false, true, false, 48, 6>(a, kc, bands, s);   // features.7
   return hipErrorInvalidValue;
 }
 
