@@ -111,7 +111,7 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=5)
-  ap.add_argument("--obs-batch", type=int, default=256, help="observations (= act() calls) per step per GPU")
+  ap.add_argument("--obs-batch", type=int, default=512, help="observations (= act() calls) per step per GPU")
   ap.add_argument("--encoder-dtype", default="bf16", choices=["bf16", "fp32"],
                   help="MobileNetV2 encoder arithmetic; BASELINE configs[2] names bf16 encoder + fp32 flow")
   ap.add_argument("--models", type=int, default=4)
