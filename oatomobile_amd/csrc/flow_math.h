@@ -34,7 +34,7 @@ __device__ __forceinline__ float goal_ll(const float* __restrict__ goal, int G, 
   float se = 0.f, a0 = 0.f, a1 = 0.f;
   for (int j = 0; j < G; ++j) {
     const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
-    const float e = expf(-(d0 * d0 + d1 * d1) * inv2 - m);
+    const float e = __expf(-(d0 * d0 + d1 * d1) * inv2 - m);  // argument <= 0; v_exp_f32 (~1 ulp) is plenty for 1e-4
     se += e;
     a0 = fmaf(e, -d0, a0);
     a1 = fmaf(e, -d1, a1);
@@ -44,7 +44,7 @@ __device__ __forceinline__ float goal_ll(const float* __restrict__ goal, int G, 
     *g0 = a0 * sc;
     *g1 = a1 * sc;
   }
-  return m + logf(se) - 2.0f * logf(eps) - LOG_2PI - logf((float)G);
+  return m + __logf(se) - 2.0f * logf(eps) - LOG_2PI - logf((float)G);  // se in [1, G]
 }
 
 
