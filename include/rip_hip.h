@@ -17,8 +17,21 @@
  *   - every `*_dev` pointer is caller-owned device memory (e.g. a PyTorch-ROCm
  *     tensor's data_ptr()), contiguous fp32 unless stated otherwise.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
- *     the call returns without synchronising.  NULL = the null stream.
- *   - a handle is bound to one device and is not thread-safe.
+ *     the call returns without synchronising: every entry point that takes a
+ *     stream only validates arguments and launches kernels — no hipMalloc /
+ *     hipFree / hipMemcpy / device synchronisation (safe under stream capture).
+ *     All device scratch is allocated by rip_create from (max_batch,
+ *     max_candidates); a call that exceeds it returns RIP_ESTATE.
+ *     rip_create / rip_destroy / rip_load_model / rip_train_* setup calls are
+ *     the only ones that allocate or copy synchronously.  NULL = the null stream.
+ *   - a handle is bound to one device: every entry point that takes a handle
+ *     makes that device current for the duration of the call and restores the
+ *     caller's current device before returning.  The stateless entry points
+ *     (rip_transform, rip_goal_likelihood, rip_lidar_bev, rip_cil_decode) launch
+ *     on the caller's current device, which must own the pointers.
+ *   - a handle's scratch is shared by its calls, so a handle is single-stream
+ *     and not thread-safe: when consecutive calls on one handle name different
+ *     streams, the later stream is made to wait (event) for the earlier one.
  *   - trajectory shape is fixed at T=4 steps x D=2, hidden size 64, like the
  *     reference's ImitativeModel(output_shape=(4, 2)) (dim/model.py:41-68).
  */
@@ -39,8 +52,7 @@ enum {
   RIP_OK = 0,
   RIP_EINVAL = -1,  /* bad argument (shape, NULL, range) */
   RIP_EHIP = -2,    /* a HIP runtime call failed */
-  RIP_ESTATE = -3,  /* model k not loaded yet, workspace too small, ... */
-  RIP_ECOMM = -4    /* RCCL failure */
+  RIP_ESTATE = -3   /* model k not loaded yet, scratch sized by rip_create too small, ... */
 };
 
 /* rip/agent.py:121-127 as coded: "WCM" = min_k(-posterior), "BCM" = max_k, "MA" = mean_k. */
@@ -59,10 +71,13 @@ int rip_abi_version(void);
 const char* rip_last_error(void);
 
 /* Replaces ImitativeModel.__init__/.to(device) for K ensemble members
- * (dim/model.py:36-74; rip/agent.py:49-50).  Allocates device weights for K
- * models with `in_channels` BEV channels and an encoder workspace for up to
- * `max_batch` observations per call on HIP device `device`. */
-int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int device);
+ * (dim/model.py:36-74; rip/agent.py:49-50).  Allocates, on HIP device `device`,
+ * the weights of K models with `in_channels` BEV channels and ALL scratch any
+ * later call may use: the encoder workspace for up to `max_batch` observations
+ * per call and the plan-search scratch (candidate plans, best losses, adjoint
+ * tape, ImitativeModel.forward traces) for up to `max_batch` x `max_candidates`
+ * latent rows.  Later calls never allocate. */
+int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_candidates, int device);
 int rip_destroy(rip_handle* h);
 
 /* Replaces model.load_state_dict(torch.load(ckpt)) (README.md:57-58,
@@ -89,10 +104,11 @@ int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channe
 int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
                int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream);
 
-/* Fused R2+R3+R4 for the agent's hot loop: raw sensor BEV [B,200,200,C]
- * (channels_last=1) or [B,C,200,200] -> z.  Same results as rip_transform + rip_encode. */
-int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, int B,
-                   int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream);
+/* Fused R2+R3+R4 for the agent's hot loop: raw sensor BEV [B,H,W,C]
+ * (channels_last=1) or [B,C,H,W] -> z (any H, W >= 1 like F.interpolate; the
+ * CARLA sensor gives 200 x 200).  Same results as rip_transform + rip_encode. */
+int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
+                   int B, int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream);
 
 /* R6 — AutoregressiveFlow._forward of model k (sequence.py:95-151).
  * x_dev [N,4,2]; z_dev [z_rows,64] with z_rows == N or 1 (broadcast);
@@ -135,12 +151,35 @@ int rip_aggregate_scores(const float* S_dev, int K, int B, int N, int algorithm,
  * plan of the candidate with the lowest best-loss wins.  N=1 is the reference.
  * Outputs (any may be NULL): plan_dev [B,4,2]; plans_dev [B,N,4,2];
  * loss_best_dev [B,N]; best_index_dev [B] int32;
- * trace_post_dev [num_steps,K,B,N] per-step posteriors;
- * trace_x_dev [num_steps,B,N,4,2] post-step latents. */
+ * trace_post_dev [num_steps,K,B,N] per-step posteriors (incl. the goal term);
+ * trace_x_dev [num_steps,B,N,4,2] post-step latents;
+ * trace_grad_dev [num_steps,B,N,4,2] dLoss/dx of every step (what Adam consumes).
+ * Both search kernels implement the traces (the MFMA-batched one for N % 32 == 0). */
 int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
                int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
                float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
-               rip_stream_t stream);
+               float* trace_grad_dev, rip_stream_t stream);
+
+/* Gradient-mode model-parallel search (BASELINE configs[3]: the K models of the ensemble live on
+ * different GPUs).  One Adam step of rip/agent.py:102-135 is cut where the ensemble is reduced; the caller moves
+ * ONE [K_local,B,N,9] block per step between ranks (all-gather, e.g. torch.distributed over RCCL):
+ *
+ *   rip_mp_local: y = F(x; z_fwd) with the flow of handle model `k_fwd` (the ensemble's model 0, whose flow
+ *     weights every rank holds), then for this rank's models [k_begin, k_begin+k_count): inverse(y; z_k) and its
+ *     adjoint -> out_dev[k,b,n,:] = (q_k = log_prob - logabsdet, dq_k/dy[8]).  first_is_fwd != 0 (the rank that
+ *     owns model 0): row 0 reports q_0 through the self-inverse shortcut with a zero gradient (it is folded into
+ *     the forward adjoint of rip_mp_update).
+ *   rip_mp_update: on the gathered [K,B,N,9] matrix (model 0 first), redundantly on every rank: ensemble
+ *     aggregation (rip/agent.py:121-127), goal term, adjoint of F, Adam step `step` (0-based) and the
+ *     loss_best / x_best bookkeeping (:131-135) on the rank-replicated state x, m, v, x_best [B,N,4,2] and
+ *     loss_best [B,N] (initialise m = v = 0, x_best = x, loss_best = 1000).  grad_dev [B,N,4,2] optional.
+ * One rank holding all K models reproduces rip_search's wave-per-chain kernel. */
+int rip_mp_local(rip_handle* h, int k_fwd, int k_begin, int k_count, int first_is_fwd, const float* z_fwd_dev,
+                 const float* z_dev, const float* x_dev, int B, int N, float* out_dev, rip_stream_t stream);
+int rip_mp_update(rip_handle* h, int k_fwd, const float* z_fwd_dev, const float* gathered_dev, int K,
+                  const float* goal_dev, int B, int N, int G, int algorithm, int step, float lr, float epsilon,
+                  float* x_dev, float* m_dev, float* v_dev, float* x_best_dev, float* loss_best_dev, float* grad_dev,
+                  rip_stream_t stream);
 
 /* N5 — the sensor step in front of R2: carla_lidar_measurement_to_ndarray
  * (oatomobile/utils/carla.py:165-233) on already parsed point clouds.  points_dev [P_total,3] fp32 (x, y, z as in
@@ -169,17 +208,18 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
                     rip_stream_t stream);
 
 /* Whole act() for B observations in one call: rip_encode_raw + rip_search.
- * lidar_dev [B,200,200,C] (channels_last=1) or [B,C,200,200]; vec_dev [B,5];
+ * lidar_dev [B,H,W,C] (channels_last=1) or [B,C,H,W]; vec_dev [B,5];
  * goal_dev [B,G,2]; x0_dev [B,N,4,2]; plan_dev [B,4,2].  Scratch lives in the
- * handle (B <= max_batch). */
-int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, const float* goal_dev,
-            const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr, float epsilon,
-            int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
+ * handle (B <= max_batch, N <= max_candidates). */
+int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
+            const float* goal_dev, const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr,
+            float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
- *   RIP_OPT_SEARCH_KERNEL: 0 = auto (MFMA-batched when B*N >= 2048, N % 16 == 0, K <= 4, no traces),
- *     1 = wave-per-chain kernel (lowest latency, any K/N, supports traces),
- *     2 = MFMA-batched kernel (16 candidates per wave).  Both implement rip/agent.py:78-137.
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (MFMA-batched when B*N >= 2048, N % 16 == 0, K <= 4),
+ *     1 = wave-per-chain kernel (lowest latency, any K/N),
+ *     2 = MFMA-batched kernel (16 candidates per wave; N % 16 == 0, K <= 4; N % 32 == 0 selects its pipelined
+ *     dual-block form, the only one with trace outputs).  Both implement rip/agent.py:78-137.
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.
@@ -193,6 +233,7 @@ int rip_set_option(rip_handle* h, int option, int value);
 int rip_num_models(const rip_handle* h);
 int rip_in_channels(const rip_handle* h);
 int rip_max_batch(const rip_handle* h);
+int rip_max_candidates(const rip_handle* h);
 
 #ifdef __cplusplus
 }

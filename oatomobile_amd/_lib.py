@@ -16,12 +16,13 @@ LIB_PATH = os.path.join(_HERE, "librip_hip.so")
 SIGNATURES = [
     ("rip_abi_version", c_int, []),
     ("rip_last_error", c_char_p, []),
-    ("rip_create", c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    ("rip_create", c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
     ("rip_destroy", c_int, [c_void_p]),
     ("rip_load_model", c_int, [c_void_p, c_int, c_void_p, c_size_t]),
     ("rip_transform", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("rip_encode", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    ("rip_encode_raw", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("rip_encode_raw", c_int,
+     [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("rip_flow_forward", c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("rip_flow_inverse", c_int,
      [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -34,20 +35,28 @@ SIGNATURES = [
     ("rip_cil_blob_floats", c_int, []),
     ("rip_search", c_int, [
         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p,
-        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p
+    ]),
+    ("rip_mp_local", c_int,
+     [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    ("rip_mp_update", c_int, [
+        c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p
     ]),
     ("rip_dim_forward", c_int,
      [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
       c_void_p]),
     ("rip_act", c_int, [
-        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
-        c_int, c_void_p, c_void_p, c_void_p
+        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+        c_float, c_float, c_int, c_void_p, c_void_p, c_void_p
     ]),
     ("rip_set_option", c_int, [c_void_p, c_int, c_int]),
     ("rip_num_models", c_int, [c_void_p]),
     ("rip_in_channels", c_int, [c_void_p]),
     ("rip_max_batch", c_int, [c_void_p]),
+    ("rip_max_candidates", c_int, [c_void_p]),
 ]
+ABI_VERSION = 2
 
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
@@ -85,27 +94,52 @@ def check(rc: int) -> None:
     raise RipError("librip_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
 
 
-def ptr(t) -> c_void_p:
-  """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or NULL for None."""
+def ptr(t, dtype=None) -> c_void_p:
+  """Device pointer of a contiguous fp32 (or `dtype`) HIP tensor, or NULL for None.  Raw pointers cross the C ABI
+  unchecked on the other side, so dtype / residency / contiguity are enforced here."""
   if t is None:
     return c_void_p(0)
-  assert t.is_cuda and t.is_contiguous(), "expected a contiguous device tensor"
+  import torch
+  want = torch.float32 if dtype is None else dtype
+  if not t.is_cuda:
+    raise RuntimeError("oatomobile_amd: expected a ROCm device tensor, got one on %s (no CPU path)" % (t.device,))
+  if t.dtype != want:
+    raise ValueError("oatomobile_amd: expected a %s tensor, got %s" % (want, t.dtype))
+  if not t.is_contiguous():
+    raise ValueError("oatomobile_amd: expected a contiguous tensor (shape %s, strides %s)" % (tuple(t.shape), t.stride()))
   return c_void_p(t.data_ptr())
 
 
-def current_stream() -> c_void_p:
+def current_stream(device=None) -> c_void_p:
+  """torch's current stream ON `device` (a torch.device, an index or a tensor) — not on torch's current device:
+  a handle on cuda:1 must never be handed cuda:0's stream."""
   import torch
-  return c_void_p(torch.cuda.current_stream().cuda_stream)
+  if device is not None and hasattr(device, "device"):
+    device = device.device
+  return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def expect_shape(t, shape, what: str) -> None:
+  """ValueError unless `t.shape` matches `shape` (None = any extent)."""
+  got = tuple(t.shape)
+  if len(got) != len(shape) or any(w is not None and w != g for w, g in zip(shape, got)):
+    raise ValueError("%s must have shape %s, got %s" % (what, "[" + ",".join("*" if w is None else str(w) for w in shape) + "]", got))
 
 
 class Handle:
   """Owns one `rip_handle*` (K models on one device)."""
 
-  def __init__(self, num_models: int, in_channels: int, max_batch: int, device_index: int) -> None:
+  def __init__(self, num_models: int, in_channels: int, max_batch: int, device_index: int,
+               max_candidates: int = 1) -> None:
     self._lib = load()
     self._h = c_void_p(0)
-    check(self._lib.rip_create(ctypes.byref(self._h), num_models, in_channels, max_batch, device_index))
+    check(self._lib.rip_create(ctypes.byref(self._h), num_models, in_channels, max_batch, max_candidates, device_index))
     self.num_models, self.in_channels, self.max_batch, self.device_index = num_models, in_channels, max_batch, device_index
+    self.max_candidates = max_candidates
+
+  def stream(self) -> c_void_p:
+    """torch's current stream on THIS handle's device."""
+    return current_stream(self.device_index)
 
   @property
   def raw(self) -> c_void_p:

@@ -91,8 +91,10 @@ class SetPointAgent:
     raise NotImplementedError
 
   def act(self, observation: Mapping[str, np.ndarray], *args, **kwargs):
-    """base.py:116-176 up to the PID call: returns dict(setpoint [3] world frame, target_speed m/s,
-    plan_world [T,3])."""
+    """base.py:116-176 up to the PID call: returns dict(setpoint [3] world frame = the location handed to
+    `map.get_waypoint`, target_speed m/s (the PID gets it in km/h, :170-172), plan_world [T,3] = the setpoint
+    buffer, predictions [T,3] = the buffer back in the ego frame, which the reference registers for rendering
+    (:145-150))."""
     current_location = np.asarray(observation["location"], dtype=np.float64)
     current_rotation = np.asarray(observation["rotation"], dtype=np.float64)
     if self._setpoints_buffer is None or self._steps_counter % self._replan_every_steps == 0:
@@ -101,22 +103,26 @@ class SetPointAgent:
                                            local_locations=plan_ego)
     else:
       self._setpoints_buffer = self._setpoints_buffer[1:]  # base.py:142
+    predictions = world2local(current_location=current_location, current_rotation=current_rotation,
+                              world_locations=self._setpoints_buffer)  # base.py:145-150
     self._steps_counter += 1
     target_speed = np.linalg.norm(np.diff(self._setpoints_buffer[:self._setpoint_index], axis=0),
                                   axis=1).mean() / self._fixed_delta_seconds_between_setpoints  # base.py:156-159
     if self._steps_counter <= 100:  # base.py:166-167
       target_speed = 20.0 / 3.6
     return dict(setpoint=self._setpoints_buffer[self._setpoint_index], target_speed=target_speed,
-                plan_world=self._setpoints_buffer)
+                plan_world=self._setpoints_buffer, predictions=predictions)
 
   def update(self, *args, **kwargs) -> None:  # core/agent.py:39-48
     return None
 
 
 def _prepare_observation(observation: Mapping[str, Any], in_channels: int):
-  """rip/agent.py:59-69 on the host (only the keys the model reads): float32 casts, goal[..., :2]."""
+  """rip/agent.py:59-69 on the host (only the keys the model reads): float32 casts (any input dtype, like
+  `.type(torch.float32)` there), goal[..., :2].  The BEV may have any H, W (the model resizes it to 100 x 100 like
+  `F.interpolate`, torch/transforms.py:39-44); shapes that the kernels cannot take raise ValueError here."""
   lidar = np.ascontiguousarray(observation["lidar"], dtype=np.float32)
-  if lidar.ndim != 3 or lidar.shape[-1] != in_channels:
+  if lidar.ndim != 3 or lidar.shape[-1] != in_channels or lidar.shape[0] < 1 or lidar.shape[1] < 1:
     raise ValueError("observation['lidar'] must be [H,W,%d], got %s" % (in_channels, lidar.shape))
   vec = np.concatenate([
       np.atleast_1d(np.asarray(observation["velocity"], dtype=np.float32)).reshape(3),
@@ -124,6 +130,8 @@ def _prepare_observation(observation: Mapping[str, Any], in_channels: int):
       np.atleast_1d(np.asarray(observation["traffic_light_state"], dtype=np.float32)).reshape(1),
   ])
   goal = np.ascontiguousarray(np.asarray(observation["goal"], dtype=np.float32)[..., :2])
+  if goal.ndim != 2 or goal.shape[0] < 1 or goal.shape[1] != 2:
+    raise ValueError("observation['goal'] must be [G,>=2], got %s" % (np.shape(observation["goal"]),))
   return lidar, vec, goal
 
 
@@ -140,27 +148,35 @@ class RIPAgent(SetPointAgent):
       MobileNetV2 encoder with fp32 accumulation; the flow and the search stay fp32).
     search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 2048 (N % 16 == 0, K <= 4), else the
       wave-per-chain kernel; both are the same algorithm.
+    graph: `__call__` (one observation per call, the reference's usage) replays ONE captured hipGraph per call
+      (H2D of the observation from pinned staging, transform, K encoders, search, D2H of the plan) instead of
+      ~60 eager launches.  Same kernels, same results.
+
+  The agent uploads a snapshot of every model's weights; the snapshot is refreshed automatically when a model's
+  `load_state_dict()` / `refresh()` ran since (the reference agent reads the live module weights).
   """
 
   def __init__(self, environment: Any = None, *, algorithm: str, models: Sequence[ImitativeModel],
                num_candidates: int = 1, num_steps: int = 10, lr: float = 1e-1, epsilon: float = 1.0, seed: int = 0,
                max_batch: int = 1, device: Optional[torch.device] = None, search_kernel: str = "auto",
-               fused_encoder: Optional[int] = None, encoder_dtype: str = "fp32", **kwargs) -> None:
+               fused_encoder: Optional[int] = None, encoder_dtype: str = "fp32", graph: bool = True, **kwargs) -> None:
     assert algorithm in ("WCM", "MA", "BCM")  # rip/agent.py:43
     self._algorithm = algorithm
     super().__init__(environment=environment, **kwargs)
     if not torch.cuda.is_available():
       raise RuntimeError("oatomobile_amd.RIPAgent needs a ROCm device; there is no CPU path.")
     self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if self._device.index is None:
+      self._device = torch.device("cuda", torch.cuda.current_device())
     self._models = [model.to(self._device) for model in models]  # rip/agent.py:50
     self._in_channels = self._models[0]._in_channels
     self._num_candidates, self._num_steps, self._lr, self._epsilon = int(num_candidates), int(num_steps), float(lr), float(epsilon)
     self._max_batch = int(max_batch)
     self._enc_dtype = _lib.ENC_DTYPES[encoder_dtype]
-    self._handle = _lib.Handle(len(self._models), self._in_channels, self._max_batch,
-                               self._device.index if self._device.index is not None else torch.cuda.current_device())
-    for k, m in enumerate(self._models):
-      self._handle.load_model(k, m.packed_weights())
+    self._handle = _lib.Handle(len(self._models), self._in_channels, self._max_batch, self._device.index,
+                               max_candidates=self._num_candidates)
+    self._versions = [None] * len(self._models)
+    self._sync_weights()
     # "auto" | "chain" (one wave per candidate x model chain) | "mfma" (16 candidates per wave on MFMA)
     self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS[search_kernel])
     if fused_encoder is None and "RIP_ENCODER_FUSED" in os.environ:
@@ -168,37 +184,139 @@ class RIPAgent(SetPointAgent):
     if fused_encoder is not None:
       self._handle.set_option(_lib.OPT_ENCODER_FUSED, int(fused_encoder))
     rng = np.random.default_rng(seed)
-    x0 = rng.standard_normal((self._num_candidates, arch_T(), 2)).astype(np.float32)
+    x0 = rng.standard_normal((self._num_candidates, arch.T, 2)).astype(np.float32)
     x0[0] = 0.0  # base distribution mean (rip/agent.py:85)
     self._x0_rows = torch.from_numpy(x0).to(self._device)
     self._x0_cache = {}
+    self._use_graph = bool(graph) and os.environ.get("RIP_NO_GRAPH", "0") != "1"
+    self._online = {}  # (H, W, G) -> captured one-observation pipeline
+
+  def _sync_weights(self) -> bool:
+    """Uploads the weights of every model whose version changed since the last upload."""
+    changed = False
+    for k, m in enumerate(self._models):
+      if self._versions[k] != m._version:
+        self._handle.load_model(k, m.packed_weights())
+        self._versions[k] = m._version
+        changed = True
+    return changed
+
+  def refresh(self) -> None:
+    """Force a re-upload of all model weights (after in-place parameter edits without `model.refresh()`)."""
+    self._versions = [None] * len(self._models)
+    self._sync_weights()
 
   def _x0(self, batch: int) -> torch.Tensor:
     if batch not in self._x0_cache:
       self._x0_cache[batch] = self._x0_rows.unsqueeze(0).expand(batch, -1, -1, -1).contiguous()
     return self._x0_cache[batch]
 
+  def _check_batch(self, lidar: torch.Tensor, vec: torch.Tensor, goal: torch.Tensor) -> None:
+    """The C ABI takes raw pointers: dtype, device and shape are enforced here (ValueError / RuntimeError)."""
+    for name, t in (("lidar", lidar), ("vec", vec), ("goal", goal)):
+      if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != self._device:
+        raise RuntimeError("plan_batch: `%s` must be a tensor on %s (got %s)" %
+                           (name, self._device, getattr(t, "device", type(t))))
+      if t.dtype != torch.float32:
+        raise ValueError("plan_batch: `%s` must be float32, got %s" % (name, t.dtype))
+    _lib.expect_shape(lidar, (None, None, None, self._in_channels), "lidar")
+    b = lidar.shape[0]
+    if b < 1 or b > self._max_batch or lidar.shape[1] < 1 or lidar.shape[2] < 1:
+      raise ValueError("plan_batch: lidar %s: batch must be in [1, max_batch=%d], H, W >= 1" %
+                       (tuple(lidar.shape), self._max_batch))
+    _lib.expect_shape(vec, (b, 5), "vec")
+    _lib.expect_shape(goal, (b, None, 2), "goal")
+    if goal.shape[1] < 1:
+      raise ValueError("plan_batch: goal needs at least one waypoint")
+
   def plan_batch(self, lidar: torch.Tensor, vec: torch.Tensor, goal: torch.Tensor,
                  return_loss: bool = False):
-    """Device-resident batched planning: lidar [B,200,200,C] (sensor layout), vec [B,5], goal [B,G,2]
-    -> plans [B,4,2] (and best losses [B,N]).  One rip_act call (transform + K encoders + search)."""
+    """Device-resident batched planning: lidar [B,H,W,C] (sensor layout; 200 x 200 from CARLA), vec [B,5],
+    goal [B,G,2] -> plans [B,4,2] (and best losses [B,N]).  One rip_act call (transform + K encoders + search)."""
+    self._check_batch(lidar, vec, goal)
+    if self._sync_weights():
+      self._online = {}
+    lidar, vec, goal = lidar.contiguous(), vec.contiguous(), goal.contiguous()
     b = lidar.shape[0]
-    plan = torch.empty(b, arch_T(), 2, device=self._device, dtype=torch.float32)
+    plan = torch.empty(b, arch.T, 2, device=self._device, dtype=torch.float32)
     loss = torch.empty(b, self._num_candidates, device=self._device, dtype=torch.float32) if return_loss else None
-    lib = _lib.load()
-    _lib.check(lib.rip_act(self._handle.raw, _lib.ptr(lidar), 1, _lib.ptr(vec), _lib.ptr(goal), _lib.ptr(self._x0(b)), b,
-                           self._num_candidates, goal.shape[1], _lib.ALGORITHMS[self._algorithm], self._num_steps,
-                           self._lr, self._epsilon, self._enc_dtype, _lib.ptr(plan), _lib.ptr(loss), _lib.current_stream()))
+    self._launch_act(lidar, vec, goal, plan, loss)
     return (plan, loss) if return_loss else plan
+
+  def _launch_act(self, lidar, vec, goal, plan, loss) -> None:
+    b = lidar.shape[0]
+    lib = _lib.load()
+    _lib.check(lib.rip_act(self._handle.raw, _lib.ptr(lidar), 1, lidar.shape[1], lidar.shape[2], _lib.ptr(vec),
+                           _lib.ptr(goal), _lib.ptr(self._x0(b)), b, self._num_candidates, goal.shape[1],
+                           _lib.ALGORITHMS[self._algorithm], self._num_steps, self._lr, self._epsilon, self._enc_dtype,
+                           _lib.ptr(plan), _lib.ptr(loss), self._handle.stream()))
+
+  # -- one observation per call (the reference's usage): pinned staging + one hipGraph replay ---------------
+  def _online_state(self, H: int, W: int, G: int):
+    key = (H, W, G)
+    st = self._online.get(key)
+    if st is not None:
+      return st
+    dev, C = self._device, self._in_channels
+    st = dict(
+        lidar_h=torch.empty(1, H, W, C, dtype=torch.float32).pin_memory(),
+        vec_h=torch.empty(1, 5, dtype=torch.float32).pin_memory(),
+        goal_h=torch.empty(1, G, 2, dtype=torch.float32).pin_memory(),
+        plan_h=torch.empty(1, arch.T, 2, dtype=torch.float32).pin_memory(),
+        lidar_d=torch.empty(1, H, W, C, dtype=torch.float32, device=dev),
+        vec_d=torch.empty(1, 5, dtype=torch.float32, device=dev),
+        goal_d=torch.empty(1, G, 2, dtype=torch.float32, device=dev),
+        plan_d=torch.empty(1, arch.T, 2, dtype=torch.float32, device=dev),
+        stream=torch.cuda.Stream(device=dev), graph=None)
+    st["lidar_np"], st["vec_np"], st["goal_np"] = st["lidar_h"].numpy(), st["vec_h"].numpy(), st["goal_h"].numpy()
+    st["lidar_h"].zero_(), st["vec_h"].zero_(), st["goal_h"].zero_()
+    self._x0(1)
+
+    def pipeline():
+      st["lidar_d"].copy_(st["lidar_h"], non_blocking=True)
+      st["vec_d"].copy_(st["vec_h"], non_blocking=True)
+      st["goal_d"].copy_(st["goal_h"], non_blocking=True)
+      self._launch_act(st["lidar_d"], st["vec_d"], st["goal_d"], st["plan_d"], None)
+      st["plan_h"].copy_(st["plan_d"], non_blocking=True)  # rip/agent.py:139
+
+    st["pipeline"] = pipeline
+    if self._use_graph:
+      try:
+        with torch.cuda.device(dev):
+          st["stream"].wait_stream(torch.cuda.current_stream(dev))
+          with torch.cuda.stream(st["stream"]):
+            pipeline()  # warm-up on the capture stream: one-time kernel attributes, handle stream hand-over
+          st["stream"].synchronize()
+          g = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(g, stream=st["stream"]):
+            pipeline()
+          st["graph"] = g
+      except Exception as e:  # capture unsupported in this runtime: same kernels, launched eagerly
+        import warnings
+        warnings.warn("oatomobile_amd.RIPAgent: hipGraph capture failed (%r); using eager launches" % (e,))
+        st["graph"] = None
+        torch.cuda.synchronize(dev)
+    self._online[key] = st
+    return st
 
   def __call__(self, observation: Mapping[str, np.ndarray]) -> np.ndarray:
     """Returns the imitative-prior plan [30, 3] in ego coordinates (rip/agent.py:52-151)."""
     lidar, vec, goal = _prepare_observation(observation, self._in_channels)
-    lidar_d = torch.from_numpy(lidar).to(self._device, non_blocking=True).unsqueeze(0)
-    vec_d = torch.from_numpy(vec).to(self._device, non_blocking=True).unsqueeze(0)
-    goal_d = torch.from_numpy(goal).to(self._device, non_blocking=True).unsqueeze(0)
-    plan = self.plan_batch(lidar_d, vec_d, goal_d).cpu().numpy()[0]  # rip/agent.py:139
-    return interpolate_plan(plan)
+    if self._sync_weights():
+      self._online = {}
+    st = self._online_state(lidar.shape[0], lidar.shape[1], goal.shape[0])
+    np.copyto(st["lidar_np"][0], lidar)
+    np.copyto(st["vec_np"][0], vec)
+    np.copyto(st["goal_np"][0], goal)
+    with torch.cuda.device(self._device):
+      st["stream"].wait_stream(torch.cuda.current_stream(self._device))  # earlier eager work on this handle
+      with torch.cuda.stream(st["stream"]):
+        if st["graph"] is not None:
+          st["graph"].replay()
+        else:
+          st["pipeline"]()
+      st["stream"].synchronize()
+    return interpolate_plan(st["plan_h"].numpy()[0].copy())
 
 
 class DIMAgent(SetPointAgent):
@@ -223,7 +341,3 @@ class DIMAgent(SetPointAgent):
                        visual_features=vis, velocity=vec_d[:, :3], is_at_traffic_light=vec_d[:, 3:4],
                        traffic_light_state=vec_d[:, 4:5]).cpu().numpy()[0]  # dim/agent.py:69-72
     return interpolate_plan(plan)
-
-
-def arch_T() -> int:
-  return 4

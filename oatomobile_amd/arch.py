@@ -31,6 +31,7 @@ NUM_FEATURES = 128  # classifier width == MobileNetV2(num_classes=128)
 VECTOR_INPUTS = 5  # velocity[3] + is_at_traffic_light[1] + traffic_light_state[1]
 MERGER_SIZES = (64, 64, 64)
 HIDDEN_SIZE = 64
+T = 4  # trajectory steps: ImitativeModel(output_shape=(4, 2)) (dim/model.py:41)
 HEAD_HIDDEN = 32
 BN_EPS = 1e-5
 INPUT_HW = 100  # after the 200 -> 100 bilinear down-sample

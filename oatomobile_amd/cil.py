@@ -108,11 +108,12 @@ class BehaviouralModel(nn.Module):
     lib = _lib.load()
     _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec[:, :5].contiguous()), b, 0, 1,
                               _lib.ENC_DTYPES[getattr(self, "encoder_dtype", "fp32")], _lib.ptr(zdummy), _lib.ptr(feat),
-                              _lib.current_stream()))
+                              h.stream()))
     T = self._output_shape[0]
     y = torch.empty(b, T, 2, device=vis.device, dtype=torch.float32)
-    _lib.check(lib.rip_cil_decode(_lib.ptr(feat), _lib.ptr(vec), _lib.ptr(self._blob), b, T, _lib.ptr(y),
-                                  _lib.current_stream()))
+    with torch.cuda.device(vis.device):  # stateless entry point: launches on the current device
+      _lib.check(lib.rip_cil_decode(_lib.ptr(feat), _lib.ptr(vec), _lib.ptr(self._blob), b, T, _lib.ptr(y),
+                                    h.stream()))
     return y
 
   def transform(self, sample: Mapping[str, torch.Tensor]) -> Mapping[str, torch.Tensor]:

@@ -43,7 +43,26 @@ struct SearchArgs {
   float* trace_post;     // [steps][K][B][N] or nullptr
   float* trace_x;        // [steps][B][N][8] or nullptr
   float* trace_loss;     // [steps][B][N] or nullptr
+  float* trace_grad;     // [steps][B][N][8] dLoss/dx of every Adam step, or nullptr
 };
+
+// Gradient-mode model-parallel search: one Adam step split at the exchange point.
+struct MpArgs {
+  const float* flow_w;   // [K_handle][FW_SIZE]
+  int k_fwd;             // handle index of the flow that maps x -> y (global model 0)
+  int k_begin, k_count;  // handle indices of this rank's models
+  int first_is_fwd;      // local model 0 IS the forward model (rank 0): its posterior comes from the shortcut
+  const float* z_fwd;    // [B][64] z of the forward model
+  const float* z;        // [k_count][B][64]
+  const float* goal;     // [B][G][2] or nullptr
+  int B, N, G, K;        // K = models in the whole ensemble (rip_mp_update)
+  int algorithm;
+  float lr, epsilon;
+  int step;              // 0-based Adam step index (bias correction)
+};
+hipError_t launch_mp_local(const MpArgs& a, const float* x, float* out /*[k_count][B][N][9]*/, hipStream_t s);
+hipError_t launch_mp_update(const MpArgs& a, const float* gathered /*[K][B][N][9]*/, float* x, float* m, float* v,
+                            float* x_best, float* loss_best, float* grad_out, hipStream_t s);
 
 hipError_t launch_flow_forward(const float* flow_w_k, const float* x, const float* z, int N, int z_rows, float* y,
                                float* lad, hipStream_t s);

@@ -20,6 +20,10 @@
 #include "flow.h"
 #include "flow_math.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace rip {
 
 namespace {
@@ -697,6 +701,7 @@ __global__ __launch_bounds__(NW * 64) void search_kernel(SearchArgs a) {
         x = x - step_size * (am / denom);
         if (loss < loss_best) xbest = x;                 // post-step x vs pre-step loss (rip/agent.py:131-135)
         if (a.trace_x != nullptr) a.trace_x[((size_t)step * a.B * a.N + bn) * 8 + lane] = x;
+        if (a.trace_grad != nullptr) a.trace_grad[((size_t)step * a.B * a.N + bn) * 8 + lane] = g;
       }
       if (loss < loss_best) loss_best = loss;
       if (a.trace_loss != nullptr && lane == 0) a.trace_loss[(size_t)step * a.B * a.N + bn] = loss;
@@ -984,6 +989,7 @@ __global__ __launch_bounds__(NW * 64) void search_pipe_kernel(SearchArgs a) {
         x = x - step_size * (am / (sqrtf(av) / bc2s + 1e-8f));
         if (loss < loss_best) xbest = x;  // post-step x vs pre-step loss (rip/agent.py:131-135)
         if (a.trace_x != nullptr) a.trace_x[((size_t)step * a.B * a.N + bn) * 8 + lane] = x;
+        if (a.trace_grad != nullptr) a.trace_grad[((size_t)step * a.B * a.N + bn) * 8 + lane] = g;
       }
       if (loss < loss_best) loss_best = loss;
       if (a.trace_loss != nullptr && lane == 0) a.trace_loss[(size_t)step * a.B * a.N + bn] = loss;
@@ -1097,11 +1103,162 @@ __global__ __launch_bounds__(64) void dim_select_kernel(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Gradient-mode model-parallel search (BASELINE config 4: K = 8 models over 8 GPUs).
+// One Adam step of rip/agent.py:102-135 is cut at the point where the ensemble is reduced:
+//   mp_local_kernel   (rank r, its models k): y = F_0(x; z_0) redundantly, then inverse_k(y) and its adjoint ->
+//                     out[k][b][n] = (q_k, dq_k/dy[8]).  The rank that owns model 0 reports q_0 through the
+//                     self-inverse shortcut (inverse_0(F_0(x)) == x) with a zero gradient row: that gradient is
+//                     folded into the F_0 adjoint (chain_backward's w0 terms), as in search_kernel.
+//   -- ONE all-gather of the [K_local,B,N,9] blocks (torch.distributed / RCCL) --
+//   mp_update_kernel  (every rank, redundantly): aggregate over K (rip/agent.py:121-127), dLoss/dy, F_0 adjoint,
+//                     Adam and the loss/x_best bookkeeping on rank-replicated state.  Same device functions and the
+//                     same operation order as search_kernel, so one rank with all K models reproduces it.
+// One wave per (observation, candidate[, local model]); this mode is bound by the collective's latency.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mp_local_kernel(MpArgs a, const float* __restrict__ x, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1f = smem;                 // W1 of the forward model
+  float* w1l = w1f + W1_LDS;         // W1 of the local model
+  float* tape = w1l + W1_LDS;        // TAPE
+  float* io = tape + TAPE;           // x[8], y[8], g[8]
+  const int lane = threadIdx.x;
+  const int bn = blockIdx.x, b = bn / a.N;
+  const int kl = blockIdx.y;
+  const float* blob_f = a.flow_w + (size_t)a.k_fwd * FW_SIZE;
+  const float* blob_l = a.flow_w + (size_t)(a.k_begin + kl) * FW_SIZE;
+  stage_w1(w1f, blob_f, lane, 64);
+  stage_w1(w1l, blob_l, lane, 64);
+  if (lane < 8) io[lane] = x[(size_t)bn * 8 + lane];
+  FlowRegs W;
+  load_flow_regs(W, blob_f, lane);
+  __syncthreads();
+  const float* w1row_f = w1f + (lane & 31) * W1_STRIDE;
+  const Prefix pre_f = chain_prefix(W, w1row_f, a.z_fwd[(size_t)b * 64 + lane]);
+  const ChainOut of = chain_forward<false>(MODE_FWD, W, w1row_f, pre_f, io, io + 8, nullptr, lane);
+  __builtin_amdgcn_wave_barrier();
+  float* o9 = out + (((size_t)kl * a.B + b) * a.N + (bn - b * a.N)) * 9;
+  if (a.first_is_fwd && kl == 0) {
+    if (lane == 0) o9[0] = (-0.5f * of.sq - 4.0f * LOG_2PI) - of.lad;
+    if (lane >= 1 && lane < 9) o9[lane] = 0.f;
+    return;
+  }
+  load_flow_regs(W, blob_l, lane);
+  const float* w1row_l = w1l + (lane & 31) * W1_STRIDE;
+  const Prefix pre = chain_prefix(W, w1row_l, a.z[((size_t)kl * a.B + b) * 64 + lane]);
+  const ChainOut oi = chain_forward<true>(MODE_INV, W, w1row_l, pre, io + 8, nullptr, tape, lane);
+  __builtin_amdgcn_wave_barrier();
+  chain_backward(MODE_INV, W, w1row_l, tape, nullptr, io + 16, lane);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) o9[0] = (-0.5f * oi.sq - 4.0f * LOG_2PI) - oi.lad;  // rip/agent.py:111-112
+  if (lane >= 1 && lane < 9) o9[lane] = io[16 + lane - 1];
+}
+
+__global__ __launch_bounds__(64) void mp_update_kernel(MpArgs a, const float* __restrict__ gathered,
+                                                        float* __restrict__ x, float* __restrict__ am_,
+                                                        float* __restrict__ av_, float* __restrict__ x_best,
+                                                        float* __restrict__ loss_best, float* __restrict__ grad_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1f = smem;
+  float* tape = w1f + W1_LDS;
+  float* io = tape + TAPE;  // x[8], y[8], gsum[8], dx[8]
+  const int lane = threadIdx.x;
+  const int bn = blockIdx.x, b = bn / a.N, n = bn - b * a.N;
+  const float* blob_f = a.flow_w + (size_t)a.k_fwd * FW_SIZE;
+  stage_w1(w1f, blob_f, lane, 64);
+  float xv = 0.f;
+  if (lane < 8) {
+    xv = x[(size_t)bn * 8 + lane];
+    io[lane] = xv;
+  }
+  FlowRegs W;
+  load_flow_regs(W, blob_f, lane);
+  __syncthreads();
+  const float* w1row = w1f + (lane & 31) * W1_STRIDE;
+  const Prefix pre = chain_prefix(W, w1row, a.z_fwd[(size_t)b * 64 + lane]);
+  chain_forward<true>(MODE_FWD, W, w1row, pre, io, io + 8, tape, lane);
+  __builtin_amdgcn_wave_barrier();
+  float gl = 0.f, gg0 = 0.f, gg1 = 0.f;
+  if (a.goal != nullptr) gl = goal_ll(a.goal + (size_t)b * a.G * 2, a.G, a.epsilon, io[8 + 6], io[8 + 7], &gg0, &gg1);
+  // ---- aggregate over the K models (rip/agent.py:121-127, as coded) ----
+  const size_t kstride = (size_t)a.B * a.N * 9;
+  const float* g9 = gathered + ((size_t)b * a.N + n) * 9;
+  int ksel = 0;
+  float qsel = g9[0], qmean = g9[0];
+  for (int k = 1; k < a.K; ++k) {
+    const float qk = g9[k * kstride];
+    qmean += qk;
+    const bool take = a.algorithm == ALGO_WCM ? (qk > qsel) : (qk < qsel);
+    if (take) {
+      qsel = qk;
+      ksel = k;
+    }
+  }
+  qmean /= (float)a.K;
+  const bool mean_mode = a.algorithm == ALGO_MA;
+  const float loss = -((mean_mode ? qmean : qsel) + gl);
+  if (lane < 8) {
+    float g = 0.f;
+    if (mean_mode) {
+      for (int k = 1; k < a.K; ++k) g += g9[k * kstride + 1 + lane];
+      g /= (float)a.K;
+    } else if (ksel != 0) {
+      g = g9[ksel * kstride + 1 + lane];
+    }
+    if (lane == 6) g += gg0;
+    if (lane == 7) g += gg1;
+    io[16 + lane] = -g;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float w0 = mean_mode ? 1.0f / (float)a.K : (ksel == 0 ? 1.0f : 0.0f);
+  chain_backward(MODE_FWD, W, w1row, tape, io + 16, io + 24, lane, w0);
+  __builtin_amdgcn_wave_barrier();
+  // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
+  double b1p = 1.0, b2p = 1.0;
+  for (int i = 0; i <= a.step; ++i) {
+    b1p *= 0.9;
+    b2p *= 0.999;
+  }
+  const float lb = loss_best[bn];
+  if (lane < 8) {
+    const float g = io[24 + lane];
+    float am = am_[(size_t)bn * 8 + lane], av = av_[(size_t)bn * 8 + lane];
+    am = am + (g - am) * 0.1f;
+    av = av * 0.999f + 0.001f * g * g;
+    const float step_size = (float)((double)a.lr / (1.0 - b1p));
+    const float bc2s = (float)sqrt(1.0 - b2p);
+    xv = xv - step_size * (am / (sqrtf(av) / bc2s + 1e-8f));
+    am_[(size_t)bn * 8 + lane] = am;
+    av_[(size_t)bn * 8 + lane] = av;
+    x[(size_t)bn * 8 + lane] = xv;
+    if (loss < lb) x_best[(size_t)bn * 8 + lane] = xv;  // post-step x vs pre-step loss (rip/agent.py:131-135)
+    if (grad_out != nullptr) grad_out[(size_t)bn * 8 + lane] = g;
+  }
+  if (lane == 0 && loss < lb) loss_best[bn] = loss;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+
+// The search kernels need more dynamic LDS than the default limit: raise it ONCE per (kernel, device) to the CU's
+// 160 KiB, so that later launches are pure enqueues (no attribute call between the kernels of a captured graph).
+static hipError_t allow_lds(const void* fn) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({fn, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done.insert({fn, dev});
+  return e;
+}
+
 static int rows_grid(int rows) {
   int g = (rows + 3) / 4;
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -1144,8 +1301,7 @@ size_t search_lds_bytes(int K) {
 template <int NW>
 static hipError_t launch_pipe(const SearchArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(NW * W1_LDS + NW * TAPE) * sizeof(float) + sizeof(SearchShared);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_pipe_kernel<NW>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = allow_lds(reinterpret_cast<const void*>(search_pipe_kernel<NW>));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(search_pipe_kernel<NW>, dim3(a.B * a.N), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
@@ -1161,26 +1317,22 @@ hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
   hipError_t e = hipSuccess;
   switch (nw) {
     case 1:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = allow_lds(reinterpret_cast<const void*>(search_kernel<1>));
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(search_kernel<1>, grid, dim3(64), lds, s, a);
       break;
     case 2:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = allow_lds(reinterpret_cast<const void*>(search_kernel<2>));
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(search_kernel<2>, grid, dim3(128), lds, s, a);
       break;
     case 3:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = allow_lds(reinterpret_cast<const void*>(search_kernel<3>));
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(search_kernel<3>, grid, dim3(192), lds, s, a);
       break;
     default:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = allow_lds(reinterpret_cast<const void*>(search_kernel<4>));
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(search_kernel<4>, grid, dim3(256), lds, s, a);
       break;
@@ -1206,6 +1358,20 @@ hipError_t launch_dim_select(const float* blob, const float* z, const float* x0,
   int g = B < 256 ? B : 256;
   hipLaunchKernelGGL(dim_select_kernel, dim3(g), dim3(64), lds, s, blob, z, x0, trace_loss, trace_x, B, num_steps, y,
                      trace_mean);
+  return hipGetLastError();
+}
+
+hipError_t launch_mp_local(const MpArgs& a, const float* x, float* out, hipStream_t s) {
+  const size_t lds = (size_t)(2 * W1_LDS + TAPE + 32) * sizeof(float);
+  hipLaunchKernelGGL(mp_local_kernel, dim3(a.B * a.N, a.k_count), dim3(64), lds, s, a, x, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_mp_update(const MpArgs& a, const float* gathered, float* x, float* m, float* v, float* x_best,
+                            float* loss_best, float* grad_out, hipStream_t s) {
+  const size_t lds = (size_t)(W1_LDS + TAPE + 32) * sizeof(float);
+  hipLaunchKernelGGL(mp_update_kernel, dim3(a.B * a.N), dim3(64), lds, s, a, gathered, x, m, v, x_best, loss_best,
+                     grad_out);
   return hipGetLastError();
 }
 

@@ -738,7 +738,10 @@ __device__ __forceinline__ Agg aggregate(const float (*qb)[CB], const float (*gl
   return g;
 }
 
-template <int NW>
+// TRACE: per-step posteriors / losses / gradients / post-step latents to the SearchArgs trace pointers (debug and
+// parity path: golden G6 and the teacher-forced per-step checks run on THIS kernel); the production instantiation
+// (TRACE = false) carries none of it.
+template <int NW, bool TRACE>
 __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, const float* __restrict__ mw_all,
                                                                float4* __restrict__ tape_all) {
   __shared__ MShared2 sh;
@@ -912,6 +915,21 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
                 xb[bb][1] = xv[bb][1];
                 lbest[bb] = ag.loss;
               }
+              if (TRACE) {
+                const size_t n = (size_t)n0 + bb * CB + c, row = (size_t)b * a.N + n;
+                const size_t srow = (size_t)j * a.B * a.N + row;
+                if (a.trace_grad != nullptr) {
+                  a.trace_grad[srow * 8 + 2 * q] = g0;
+                  a.trace_grad[srow * 8 + 2 * q + 1] = g1;
+                }
+                if (a.trace_x != nullptr) {
+                  a.trace_x[srow * 8 + 2 * q] = xv[bb][0];
+                  a.trace_x[srow * 8 + 2 * q + 1] = xv[bb][1];
+                }
+                if (a.trace_loss != nullptr && q == 0) a.trace_loss[srow] = ag.loss;
+                if (a.trace_post != nullptr && q < K)  // lane (c, q) reports model q: posterior + goal term
+                  a.trace_post[(((size_t)j * K + q) * a.B + b) * a.N + n] = sh.q[bb][q][c] + sh.gl[bb][0][c];
+              }
             }
           }
         }
@@ -983,33 +1001,47 @@ __global__ __launch_bounds__(NW * 64) void search_mfma2_kernel(SearchArgs a, con
 
 }  // namespace
 
+// 0 when the kernel can never run for this (K, N): rip_create sizes the handle's tape with (max_batch, max_candidates)
 size_t search_mfma_tape_bytes(int B, int N, int K) {
+  if (K > 4 || N < CB) return 0;
   return (size_t)B * (N / CB) * (K + 1) * TAPE_SLOT_F4 * sizeof(float4);
 }
 
+static bool wants_trace(const SearchArgs& a) {
+  return a.trace_post != nullptr || a.trace_x != nullptr || a.trace_loss != nullptr || a.trace_grad != nullptr;
+}
+
+// K <= 4 (wave k = model k), N a multiple of 16; the trace outputs exist on the pipelined dual-block kernel only
+// (N a multiple of 32).
 bool search_mfma_supported(const SearchArgs& a) {
-  return a.K >= 1 && a.K <= 4 && a.N % CB == 0 && a.trace_post == nullptr && a.trace_x == nullptr &&
-         a.trace_loss == nullptr;
+  return a.K >= 1 && a.K <= 4 && a.N % CB == 0 && (!wants_trace(a) || a.N % (2 * CB) == 0);
 }
 
 hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s) {
   float4* tp = reinterpret_cast<float4*>(tape);
   if (a.N % (2 * CB) == 0) {  // pipelined dual-block kernel
     const dim3 grid2(a.B * (a.N / (2 * CB)));
+    const bool tr = wants_trace(a);
+#define LAUNCH2(NW_)                                                                                        \
+  if (tr)                                                                                                   \
+    hipLaunchKernelGGL((search_mfma2_kernel<NW_, true>), grid2, dim3(NW_ * 64), 0, s, a, mw_all, tp);       \
+  else                                                                                                      \
+    hipLaunchKernelGGL((search_mfma2_kernel<NW_, false>), grid2, dim3(NW_ * 64), 0, s, a, mw_all, tp)
     switch (a.K) {
       case 1:
-        hipLaunchKernelGGL(search_mfma2_kernel<1>, grid2, dim3(64), 0, s, a, mw_all, tp);
+        LAUNCH2(1);
         break;
       case 2:
-        hipLaunchKernelGGL(search_mfma2_kernel<2>, grid2, dim3(128), 0, s, a, mw_all, tp);
+        LAUNCH2(2);
         break;
       case 3:
-        hipLaunchKernelGGL(search_mfma2_kernel<3>, grid2, dim3(192), 0, s, a, mw_all, tp);
+        LAUNCH2(3);
         break;
       default:
-        hipLaunchKernelGGL(search_mfma2_kernel<4>, grid2, dim3(256), 0, s, a, mw_all, tp);
+        LAUNCH2(4);
         break;
     }
+#undef LAUNCH2
     return hipGetLastError();
   }
   const dim3 grid(a.B * (a.N / CB));

@@ -19,7 +19,10 @@ static_assert(RIP_MAX_MODELS == rip::MAX_MODELS, "header / kernel constant misma
 static_assert(RIP_ALGO_WCM == rip::ALGO_WCM && RIP_ALGO_MA == rip::ALGO_MA && RIP_ALGO_BCM == rip::ALGO_BCM, "algo ids");
 
 struct rip_handle {
-  int K = 0, C = 0, max_batch = 0, device = 0;
+  int K = 0, C = 0, max_batch = 0, max_candidates = 0, device = 0;
+  hipStream_t last_stream = nullptr;  // the stream of the previous call: the scratch below is shared by all calls
+  bool used = false;
+  hipEvent_t order = nullptr;
   EncoderPlan plan;
   float* enc_w = nullptr;   // [K][plan.blob_floats]
   unsigned short* enc_wh = nullptr;  // [K][plan.blob_floats] bf16 copy of the folded blob (bf16 encoder)
@@ -35,12 +38,47 @@ struct rip_handle {
   // scratch for the fused entry points
   float* visual = nullptr;     // [max_batch][C][100][100]
   float* z = nullptr;          // [K][max_batch][64]
-  float* plans = nullptr;      // grown on demand: [B][N][8]
-  float* loss_best = nullptr;  // [B][N]
-  float* trace_loss = nullptr; // [steps][B]
-  float* trace_x = nullptr;    // [steps][B][8]
-  size_t plans_cap = 0, trace_cap = 0;
+  float* plans = nullptr;      // [max_batch][max_candidates][8]
+  float* loss_best = nullptr;  // [max_batch][max_candidates]
+  float* trace_loss = nullptr; // [RIP_MAX_STEPS][max_batch]   (ImitativeModel.forward)
+  float* trace_x = nullptr;    // [RIP_MAX_STEPS][max_batch][8]
 };
+
+// Makes the handle's device current for one entry point and restores the caller's on exit.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// A handle is single-stream (its scratch is shared): a call on another stream first waits for the previous one.
+static hipError_t enter_stream(rip_handle* h, hipStream_t s) {
+  if (h->used && h->last_stream != s) {
+    hipError_t e = hipEventRecord(h->order, h->last_stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamWaitEvent(s, h->order, 0);
+    if (e != hipSuccess) return e;
+  }
+  h->last_stream = s;
+  h->used = true;
+  return hipSuccess;
+}
+
+#define ENTER(h_, stream_)                                                                  \
+  DeviceScope scope_((h_)->device);                                                         \
+  if (scope_.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", (h_)->device, hipGetErrorString(scope_.err)); \
+  HIP_TRY(enter_stream((h_), (hipStream_t)(stream_)))
+
 
 static thread_local char g_err[512] = "";
 
@@ -73,24 +111,34 @@ static int check_models(const rip_handle* h, int k0, int kc) {
 
 extern "C" {
 
-int rip_abi_version(void) { return 1; }
+int rip_abi_version(void) { return 2; }
 const char* rip_last_error(void) { return g_err; }
 
-int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int device) {
+int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_candidates, int device) {
   REQUIRE(out != nullptr, "out is NULL");
   REQUIRE(K >= 1 && K <= RIP_MAX_MODELS, "K=%d outside [1,%d]", K, RIP_MAX_MODELS);
   REQUIRE(in_channels >= 1 && in_channels <= 16, "in_channels=%d outside [1,16]", in_channels);
   REQUIRE(max_batch >= 1, "max_batch=%d must be >= 1", max_batch);
+  REQUIRE(max_candidates >= 1, "max_candidates=%d must be >= 1", max_candidates);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   REQUIRE(device >= 0 && device < ndev, "device %d not in [0,%d)", device, ndev);
-  HIP_TRY(hipSetDevice(device));
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(scope.err));
   rip_handle* h = new (std::nothrow) rip_handle();
   if (h == nullptr) return fail(RIP_ESTATE, "out of host memory");
   h->K = K;
   h->C = in_channels;
   h->max_batch = max_batch;
+  h->max_candidates = max_candidates;
   h->device = device;
+  {
+    hipError_t e_ = hipEventCreateWithFlags(&h->order, hipEventDisableTiming);
+    if (e_ != hipSuccess) {
+      delete h;
+      return fail(RIP_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e_));
+    }
+  }
   h->plan = build_encoder_plan(in_channels);
   h->buf_floats = (size_t)K * max_batch * h->plan.max_act_floats;
 #define ALLOC(ptr, n)                                                             \
@@ -112,6 +160,17 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int devi
   for (int i = 0; i < 4; ++i) ALLOC(h->bufs[i], h->buf_floats);
   ALLOC(h->visual, (size_t)max_batch * in_channels * 100 * 100);
   ALLOC(h->z, (size_t)K * max_batch * 64);
+  // plan-search scratch: nothing is (re)allocated after this point (include/rip_hip.h: calls never synchronise)
+  ALLOC(h->plans, (size_t)max_batch * max_candidates * 8);
+  ALLOC(h->loss_best, (size_t)max_batch * max_candidates);
+  ALLOC(h->trace_loss, (size_t)RIP_MAX_STEPS * max_batch);
+  ALLOC(h->trace_x, (size_t)RIP_MAX_STEPS * max_batch * 8);
+  h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);  // 0 when the MFMA kernel can never run
+  if (h->tape_bytes > 0) {
+    float* tmp = nullptr;
+    ALLOC(tmp, (h->tape_bytes + 3) / 4);
+    h->tape = tmp;
+  }
 #undef ALLOC
   *out = h;
   return RIP_OK;
@@ -119,7 +178,8 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int devi
 
 int rip_destroy(rip_handle* h) {
   if (h == nullptr) return RIP_OK;
-  (void)hipSetDevice(h->device);
+  DeviceScope scope(h->device);
+  if (h->order != nullptr) (void)hipEventDestroy(h->order);
   if (h->tape != nullptr) (void)hipFree(h->tape);
   float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x};
@@ -148,6 +208,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
 int rip_num_models(const rip_handle* h) { return h ? h->K : RIP_EINVAL; }
 int rip_in_channels(const rip_handle* h) { return h ? h->C : RIP_EINVAL; }
 int rip_max_batch(const rip_handle* h) { return h ? h->max_batch : RIP_EINVAL; }
+int rip_max_candidates(const rip_handle* h) { return h ? h->max_candidates : RIP_EINVAL; }
 
 int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel) {
   REQUIRE(h != nullptr && packed_host != nullptr, "NULL argument");
@@ -155,7 +216,10 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
   std::vector<float> enc, flow, mw;
   const char* err = "";
   if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope scope(h->device);
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(scope.err));
+  // setup call: synchronous copies; make sure no kernel of an earlier call still reads the old weights
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h->enc_w + (size_t)k * h->plan.blob_floats, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice));
   {
     std::vector<unsigned short> wh(enc.size());
@@ -187,6 +251,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   REQUIRE(visual_dev != nullptr && vec_dev != nullptr && z_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
   REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
+  ENTER(h, stream);
   if (enc_dtype == RIP_ENC_BF16) {
     HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
                                 feat_dev, h->encoder_fused, (hipStream_t)stream));
@@ -197,13 +262,17 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   return RIP_OK;
 }
 
-int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, int B, int k_begin,
-                   int k_count, int enc_dtype, float* z_dev, rip_stream_t stream) {
+int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev, int B,
+                   int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream) {
   int rc = check_models(h, k_begin, k_count);
   if (rc != RIP_OK) return rc;
   REQUIRE(lidar_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
-  HIP_TRY(launch_transform(lidar_dev, B, h->C, 200, 200, channels_last, 100, h->visual, (hipStream_t)stream));
+  REQUIRE(H >= 1 && W >= 1, "bad BEV size H=%d W=%d", H, W);
+  {
+    ENTER(h, stream);
+    HIP_TRY(launch_transform(lidar_dev, B, h->C, H, W, channels_last, 100, h->visual, (hipStream_t)stream));
+  }
   return rip_encode(h, h->visual, vec_dev, B, k_begin, k_count, enc_dtype, z_dev, nullptr, stream);
 }
 
@@ -214,6 +283,7 @@ int rip_flow_forward(rip_handle* h, int k, const float* x_dev, const float* z_de
   REQUIRE(x_dev != nullptr && z_dev != nullptr && y_dev != nullptr, "NULL argument");
   REQUIRE(N >= 0 && (z_rows == N || z_rows == 1), "z_rows=%d must be N=%d or 1", z_rows, N);
   if (N == 0) return RIP_OK;
+  ENTER(h, stream);
   HIP_TRY(launch_flow_forward(h->flow_w + (size_t)k * FW_SIZE, x_dev, z_dev, N, z_rows, y_dev, logabsdet_dev,
                               (hipStream_t)stream));
   return RIP_OK;
@@ -226,6 +296,7 @@ int rip_flow_inverse(rip_handle* h, int k, const float* y_dev, const float* z_de
   REQUIRE(y_dev != nullptr && z_dev != nullptr, "NULL argument");
   REQUIRE(N >= 0 && (z_rows == N || z_rows == 1), "z_rows=%d must be N=%d or 1", z_rows, N);
   if (N == 0) return RIP_OK;
+  ENTER(h, stream);
   HIP_TRY(launch_flow_inverse(h->flow_w + (size_t)k * FW_SIZE, y_dev, z_dev, N, z_rows, x_dev, log_prob_dev,
                               logabsdet_dev, (hipStream_t)stream));
   return RIP_OK;
@@ -248,6 +319,7 @@ int rip_score(rip_handle* h, int k_begin, int k_count, const float* z_dev, const
   REQUIRE(z_dev != nullptr && y_dev != nullptr && S_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1 && N >= 1, "bad shape B=%d N=%d", B, N);
   REQUIRE(goal_dev == nullptr || (G >= 1 && epsilon > 0.f), "bad goal arguments G=%d eps=%g", G, epsilon);
+  ENTER(h, stream);
   HIP_TRY(launch_score(h->flow_w, k_begin, k_count, z_dev, y_dev, goal_dev, B, N, G, epsilon, S_dev, (hipStream_t)stream));
   return RIP_OK;
 }
@@ -279,22 +351,10 @@ int rip_cil_decode(const float* feat_dev, const float* vec_dev, const float* wei
 
 int rip_cil_blob_floats(void) { return cil_blob_floats(); }
 
-static int ensure_plans(rip_handle* h, size_t rows) {
-  if (rows <= h->plans_cap) return RIP_OK;
-  if (h->plans) (void)hipFree(h->plans);
-  if (h->loss_best) (void)hipFree(h->loss_best);
-  h->plans = h->loss_best = nullptr;
-  h->plans_cap = 0;
-  HIP_TRY(hipMalloc((void**)&h->plans, rows * 8 * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&h->loss_best, rows * sizeof(float)));
-  h->plans_cap = rows;
-  return RIP_OK;
-}
-
 int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
                int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
                float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
-               rip_stream_t stream) {
+               float* trace_grad_dev, rip_stream_t stream) {
   int rc = check_models(h, 0, h ? h->K : 1);
   if (rc != RIP_OK) return rc;
   REQUIRE(z_dev != nullptr && x0_dev != nullptr, "NULL argument");
@@ -303,16 +363,17 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   REQUIRE(algorithm == RIP_ALGO_WCM || algorithm == RIP_ALGO_MA || algorithm == RIP_ALGO_BCM, "unknown algorithm %d", algorithm);
   REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
   REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
-  HIP_TRY(hipSetDevice(h->device));
   const bool need_select = plan_dev != nullptr || best_index_dev != nullptr;
   float* plans = plans_dev;
   float* lbest = loss_best_dev;
   if (need_select && (plans == nullptr || lbest == nullptr)) {
-    rc = ensure_plans(h, (size_t)B * N);
-    if (rc != RIP_OK) return rc;
+    if ((size_t)B * N > (size_t)h->max_batch * h->max_candidates)
+      return fail(RIP_ESTATE, "B*N=%d*%d exceeds the scratch rip_create sized (max_batch=%d x max_candidates=%d)", B, N,
+                  h->max_batch, h->max_candidates);
     if (plans == nullptr) plans = h->plans;
     if (lbest == nullptr) lbest = h->loss_best;
   }
+  ENTER(h, stream);
   SearchArgs a;
   a.flow_w = h->flow_w;
   a.k0 = 0;
@@ -333,20 +394,17 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   a.trace_post = trace_post_dev;
   a.trace_x = trace_x_dev;
   a.trace_loss = nullptr;
+  a.trace_grad = trace_grad_dev;
   // kernel choice: the MFMA-batched kernel wins once there are enough 16-candidate blocks to fill the chip;
   // the wave-per-chain kernel has the lower latency for a single observation.
   bool use_mfma = search_mfma_supported(a) && h->search_mode != 1 && (h->search_mode == 2 || (size_t)B * N >= 2048);
   if (h->search_mode == 2 && !search_mfma_supported(a))
-    return fail(RIP_EINVAL, "MFMA search kernel needs K<=4, N%%16==0 and no trace outputs (K=%d N=%d)", h->K, N);
+    return fail(RIP_EINVAL, "MFMA search kernel needs K<=4 and N%%16==0 (N%%32==0 with trace outputs) (K=%d N=%d)", h->K, N);
   if (use_mfma) {
     const size_t need = search_mfma_tape_bytes(B, N, h->K);
-    if (need > h->tape_bytes) {
-      if (h->tape != nullptr) (void)hipFree(h->tape);
-      h->tape = nullptr;
-      h->tape_bytes = 0;
-      HIP_TRY(hipMalloc(&h->tape, need));
-      h->tape_bytes = need;
-    }
+    if (need > h->tape_bytes)
+      return fail(RIP_ESTATE, "MFMA search tape for B=%d N=%d needs %zu B, rip_create sized %zu B (max_batch=%d x "
+                  "max_candidates=%d)", B, N, need, h->tape_bytes, h->max_batch, h->max_candidates);
     HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));
   } else {
     HIP_TRY(launch_search(a, (hipStream_t)stream));
@@ -364,17 +422,8 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
   REQUIRE(goal_dev == nullptr || (G >= 1 && G <= rip::MAX_GOALS), "G=%d must be in [1,%d] with a goal", G, rip::MAX_GOALS);
   REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
   REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
-  HIP_TRY(hipSetDevice(h->device));
-  const size_t need = (size_t)(num_steps > 0 ? num_steps : 1) * B;
-  if (need > h->trace_cap) {
-    if (h->trace_loss) (void)hipFree(h->trace_loss);
-    if (h->trace_x) (void)hipFree(h->trace_x);
-    h->trace_loss = h->trace_x = nullptr;
-    h->trace_cap = 0;
-    HIP_TRY(hipMalloc((void**)&h->trace_loss, need * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&h->trace_x, need * 8 * sizeof(float)));
-    h->trace_cap = need;
-  }
+  REQUIRE(B <= h->max_batch, "B=%d exceeds max_batch=%d (trace scratch)", B, h->max_batch);
+  ENTER(h, stream);
   SearchArgs a;
   a.flow_w = h->flow_w;
   a.k0 = k;
@@ -395,22 +444,80 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
   a.trace_post = nullptr;
   a.trace_x = h->trace_x;
   a.trace_loss = h->trace_loss;
+  a.trace_grad = nullptr;
   HIP_TRY(launch_search(a, (hipStream_t)stream));
   HIP_TRY(launch_dim_select(h->flow_w + (size_t)k * FW_SIZE, z_dev, x0_dev, h->trace_loss, h->trace_x, B, num_steps,
                             y_dev, trace_loss_dev, (hipStream_t)stream));
   return RIP_OK;
 }
 
-int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, const float* vec_dev, const float* goal_dev,
-            const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr, float epsilon,
-            int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream) {
+int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
+            const float* goal_dev, const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr,
+            float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream) {
   REQUIRE(h != nullptr, "handle is NULL");
   REQUIRE(plan_dev != nullptr, "plan_dev is NULL");
-  int rc = rip_encode_raw(h, lidar_dev, channels_last, vec_dev, B, 0, h->K, enc_dtype, h->z, stream);
+  int rc = rip_encode_raw(h, lidar_dev, channels_last, H, W, vec_dev, B, 0, h->K, enc_dtype, h->z, stream);
   if (rc != RIP_OK) return rc;
   // h->z is [K][B][64] because rip_encode packs by the B it was given
   return rip_search(h, h->z, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, nullptr,
-                    loss_best_dev, nullptr, nullptr, nullptr, stream);
+                    loss_best_dev, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+static int fill_mp(rip_handle* h, MpArgs& a, int k_fwd, int k_begin, int k_count, int first_is_fwd, const float* z_fwd,
+                   const float* z, const float* goal, int B, int N, int G, int K, int algorithm, float lr, float eps,
+                   int step) {
+  a.flow_w = h->flow_w;
+  a.k_fwd = k_fwd;
+  a.k_begin = k_begin;
+  a.k_count = k_count;
+  a.first_is_fwd = first_is_fwd;
+  a.z_fwd = z_fwd;
+  a.z = z;
+  a.goal = goal;
+  a.B = B;
+  a.N = N;
+  a.G = G;
+  a.K = K;
+  a.algorithm = algorithm;
+  a.lr = lr;
+  a.epsilon = eps;
+  a.step = step;
+  return RIP_OK;
+}
+
+int rip_mp_local(rip_handle* h, int k_fwd, int k_begin, int k_count, int first_is_fwd, const float* z_fwd_dev,
+                 const float* z_dev, const float* x_dev, int B, int N, float* out_dev, rip_stream_t stream) {
+  int rc = check_models(h, k_begin, k_count);
+  if (rc != RIP_OK) return rc;
+  rc = check_models(h, k_fwd, 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(z_fwd_dev != nullptr && z_dev != nullptr && x_dev != nullptr && out_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && N >= 1, "bad shape B=%d N=%d", B, N);
+  REQUIRE(!first_is_fwd || k_fwd == k_begin, "first_is_fwd needs k_fwd == k_begin (got %d, %d)", k_fwd, k_begin);
+  MpArgs a;
+  fill_mp(h, a, k_fwd, k_begin, k_count, first_is_fwd, z_fwd_dev, z_dev, nullptr, B, N, 0, 0, 0, 0.f, 1.f, 0);
+  ENTER(h, stream);
+  HIP_TRY(launch_mp_local(a, x_dev, out_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_mp_update(rip_handle* h, int k_fwd, const float* z_fwd_dev, const float* gathered_dev, int K,
+                  const float* goal_dev, int B, int N, int G, int algorithm, int step, float lr, float epsilon,
+                  float* x_dev, float* m_dev, float* v_dev, float* x_best_dev, float* loss_best_dev, float* grad_dev,
+                  rip_stream_t stream) {
+  int rc = check_models(h, k_fwd, 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(z_fwd_dev != nullptr && gathered_dev != nullptr && x_dev != nullptr && m_dev != nullptr && v_dev != nullptr &&
+              x_best_dev != nullptr && loss_best_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && N >= 1 && K >= 1 && K <= 64, "bad shape B=%d N=%d K=%d", B, N, K);
+  REQUIRE(goal_dev == nullptr || (G >= 1 && G <= rip::MAX_GOALS), "G=%d must be in [1,%d] with a goal", G, rip::MAX_GOALS);
+  REQUIRE(algorithm == RIP_ALGO_WCM || algorithm == RIP_ALGO_MA || algorithm == RIP_ALGO_BCM, "unknown algorithm %d", algorithm);
+  REQUIRE(step >= 0 && step < 100000 && epsilon > 0.f && lr > 0.f, "bad step / lr / epsilon");
+  MpArgs a;
+  fill_mp(h, a, k_fwd, 0, 0, 0, z_fwd_dev, nullptr, goal_dev, B, N, G, K, algorithm, lr, epsilon, step);
+  ENTER(h, stream);
+  HIP_TRY(launch_mp_update(a, gathered_dev, x_dev, m_dev, v_dev, x_best_dev, loss_best_dev, grad_dev, (hipStream_t)stream));
+  return RIP_OK;
 }
 
 }  // extern "C"

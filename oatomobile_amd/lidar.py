@@ -49,5 +49,6 @@ def lidar_to_bev(points: Union[np.ndarray, torch.Tensor, Sequence[Union[np.ndarr
   if B:
     with torch.cuda.device(device):
       lib = _lib.load()
-      _lib.check(lib.rip_lidar_bev(_lib.ptr(pts), _lib.ptr(offsets), B, _lib.ptr(bev), _lib.current_stream()))
+      _lib.check(lib.rip_lidar_bev(_lib.ptr(pts), _lib.ptr(offsets, torch.int32), B, _lib.ptr(bev),
+                                   _lib.current_stream(device)))
   return bev[0] if single else bev

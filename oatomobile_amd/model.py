@@ -91,7 +91,7 @@ class AutoregressiveFlow(_Tree):
     lad = torch.empty(n, device=x.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.rip_flow_forward(h.raw, 0, _lib.ptr(x), _lib.ptr(z), n, z.shape[0], _lib.ptr(y), _lib.ptr(lad),
-                                    _lib.current_stream()))
+                                    h.stream()))
     return y, lad
 
   def _inverse(self, y: torch.Tensor, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -105,7 +105,7 @@ class AutoregressiveFlow(_Tree):
     lad = torch.empty(n, device=y.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.rip_flow_inverse(h.raw, 0, _lib.ptr(y), _lib.ptr(z), n, z.shape[0], _lib.ptr(x), _lib.ptr(lp),
-                                    _lib.ptr(lad), _lib.current_stream()))
+                                    _lib.ptr(lad), h.stream()))
     return x, lp, lad
 
 
@@ -119,7 +119,7 @@ class ImitativeModel(nn.Module):
       max_batch: largest observation batch one call may carry (sizes the encoder workspace).
     """
     super().__init__()
-    if tuple(output_shape) != (arch_T(), 2):
+    if tuple(output_shape) != (arch.T, 2):
       raise ValueError("only output_shape=(4, 2) is implemented (got %r)" % (tuple(output_shape),))
     self._output_shape = tuple(output_shape)
     self._in_channels = int(in_channels)
@@ -133,13 +133,19 @@ class ImitativeModel(nn.Module):
       roots[head].add(rest, shape)
     self._hip = None  # (handle, device_index)
     self._dirty = True
+    self._version = 0  # bumped whenever the weights may have changed (agents re-upload their snapshot on a mismatch)
+    self._options_applied = None
     self.eval()
 
   # -- weights -------------------------------------------------------------------------------
   def load_state_dict(self, state_dict, strict: bool = True, **kw):
     out = super().load_state_dict(state_dict, strict=strict, **kw)
-    self._dirty = True
+    self._touch()
     return out
+
+  def _touch(self) -> None:
+    self._dirty = True
+    self._version += 1
 
   def load_numpy_state_dict(self, sd: Mapping[str, np.ndarray]) -> "ImitativeModel":
     self.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
@@ -154,14 +160,14 @@ class ImitativeModel(nn.Module):
     return _weights.pack_state_dict(self.state_dict(), self._in_channels)
 
   def refresh(self) -> None:
-    """Re-upload weights after in-place parameter edits."""
-    self._dirty = True
+    """Re-upload weights after in-place parameter edits (also seen by every agent that holds this model)."""
+    self._touch()
 
   def to(self, *args, **kwargs):
     """dim/model.py:70-74: also rebuilds the decoder's base distribution on the device."""
     self = super().to(*args, **kwargs)
     self._decoder = self._decoder.to(*args, **kwargs)
-    self._dirty = True
+    self._dirty = True  # same values: the agents' snapshots stay valid (no version bump)
     return self
 
   @property
@@ -182,8 +188,10 @@ class ImitativeModel(nn.Module):
     if self._dirty:
       self._hip[0].load_model(0, self.packed_weights())
       self._dirty = False
-    if getattr(self, "fused_encoder", None) is not None:
-      self._hip[0].set_option(_lib.OPT_ENCODER_FUSED, int(self.fused_encoder))
+    fused = getattr(self, "fused_encoder", None)
+    if fused is not None and self._options_applied != (id(self._hip[0]), int(fused)):
+      self._hip[0].set_option(_lib.OPT_ENCODER_FUSED, int(fused))
+      self._options_applied = (id(self._hip[0]), int(fused))
     return self._hip[0]
 
   # -- reference API -------------------------------------------------------------------------
@@ -211,9 +219,9 @@ class ImitativeModel(nn.Module):
       G = g.shape[1]
     y = torch.empty(batch_size, *self._output_shape, device=z.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.rip_dim_forward(self._handle().raw, 0, _lib.ptr(z), _lib.ptr(g), _lib.ptr(x0), batch_size, G,
-                                   int(num_steps), float(lr), float(epsilon), _lib.ptr(y), None,
-                                   _lib.current_stream()))
+    h = self._handle()
+    _lib.check(lib.rip_dim_forward(h.raw, 0, _lib.ptr(z), _lib.ptr(g), _lib.ptr(x0), batch_size, G,
+                                   int(num_steps), float(lr), float(epsilon), _lib.ptr(y), None, h.stream()))
     return y
 
   def _goal_likelihood(self, y: torch.Tensor, goal: torch.Tensor, **hyperparams) -> torch.Tensor:
@@ -226,9 +234,12 @@ class ImitativeModel(nn.Module):
     y, goal = _f32c(y), _f32c(goal.to(y.device))
     n = y.shape[0]
     rows = torch.empty(n, device=y.device, dtype=torch.float32)
+    _lib.expect_shape(y, (None, arch.T, 2), "y")
+    _lib.expect_shape(goal, (None, None, 2), "goal")
     lib = _lib.load()
-    _lib.check(lib.rip_goal_likelihood(_lib.ptr(y), _lib.ptr(goal), n, goal.shape[0], goal.shape[1], epsilon,
-                                       _lib.ptr(rows), _lib.current_stream()))
+    with torch.cuda.device(y.device):  # stateless entry point: launches on the current device
+      _lib.check(lib.rip_goal_likelihood(_lib.ptr(y), _lib.ptr(goal), n, goal.shape[0], goal.shape[1], epsilon,
+                                         _lib.ptr(rows), _lib.current_stream(y.device)))
     return rows
 
   def _params(self, **context: torch.Tensor) -> torch.Tensor:
@@ -250,9 +261,9 @@ class ImitativeModel(nn.Module):
     ], dim=-1).contiguous()  # dim/model.py:206-214 (the cat is 5 floats per row: plumbing)
     z = torch.empty(b, arch.HIDDEN_SIZE, device=vis.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.rip_encode(self._handle().raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, 1,
-                              _lib.ENC_DTYPES[getattr(self, "encoder_dtype", "fp32")], _lib.ptr(z), None,
-                              _lib.current_stream()))
+    h = self._handle()
+    _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, 1,
+                              _lib.ENC_DTYPES[getattr(self, "encoder_dtype", "fp32")], _lib.ptr(z), None, h.stream()))
     return z
 
   def encoder_features(self, visual_features: torch.Tensor) -> torch.Tensor:
@@ -263,8 +274,9 @@ class ImitativeModel(nn.Module):
     vec = torch.zeros(b, 5, device=vis.device)
     z = torch.empty(b, 64, device=vis.device)
     feat = torch.empty(b, arch.NUM_FEATURES, device=vis.device)
-    _lib.check(_lib.load().rip_encode(self._handle().raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, 1, 0, _lib.ptr(z),
-                                      _lib.ptr(feat), _lib.current_stream()))
+    h = self._handle()
+    _lib.check(_lib.load().rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, 1, 0, _lib.ptr(z), _lib.ptr(feat),
+                                      h.stream()))
     return feat
 
   def transform(self, sample: Mapping[str, torch.Tensor]) -> Mapping[str, torch.Tensor]:
@@ -287,21 +299,20 @@ class ImitativeModel(nn.Module):
     return self._decoder._inverse(y=y, z=z)
 
 
-def arch_T() -> int:
-  return 4
-
-
 def transform_visual(visual_features: torch.Tensor, output_hw: int = arch.INPUT_HW,
                      channels_last: bool = False) -> torch.Tensor:
   """torch/transforms.py:34-49 (bilinear, align_corners=True, then H/W swap) -> rip_transform.
   in: [B,C,H,W] (or [B,H,W,C] with channels_last=True); out: [B,C,output_hw,output_hw]."""
   _require_device(visual_features, "visual_features")
   v = _f32c(visual_features)
+  if v.dim() != 4:
+    raise ValueError("visual_features must be 4-D, got shape %s" % (tuple(v.shape),))
   if channels_last:
     b, h, w, c = v.shape
   else:
     b, c, h, w = v.shape
   out = torch.empty(b, c, output_hw, output_hw, device=v.device, dtype=torch.float32)
-  _lib.check(_lib.load().rip_transform(_lib.ptr(v), b, c, h, w, int(channels_last), output_hw, _lib.ptr(out),
-                                       _lib.current_stream()))
+  with torch.cuda.device(v.device):  # stateless entry point: launches on the current device
+    _lib.check(_lib.load().rip_transform(_lib.ptr(v), b, c, h, w, int(channels_last), output_hw, _lib.ptr(out),
+                                         _lib.current_stream(v.device)))
   return out

@@ -14,6 +14,7 @@ from the recorded future: every `stride`-th waypoint of `player_future`, first `
 """
 
 import os
+import uuid
 from typing import Iterable, List, Mapping, Optional, Sequence
 
 import numpy as np
@@ -48,14 +49,27 @@ class Episode:
   """core/dataset.py:32-109: a directory of `.npz` samples + `metadata` token list."""
 
   def __init__(self, parent_dir: str, token: str) -> None:
+    self._parent_dir, self._token = parent_dir, token
     self._episode_dir = os.path.join(parent_dir, token)
+    os.makedirs(self._episode_dir, exist_ok=True)  # core/dataset.py:46-48
     self._metadata_fname = os.path.join(self._episode_dir, "metadata")
 
-  def append(self, sample_token: str, **observations: np.ndarray) -> None:
-    os.makedirs(self._episode_dir, exist_ok=True)
-    np.savez_compressed(os.path.join(self._episode_dir, "%s.npz" % sample_token), **observations)
+  def append(self, *sample_token: str, **observations: np.ndarray) -> None:
+    """core/dataset.py:53-70: one compressed `.npz` per sample under a fresh random token (uuid4 hex, like
+    utils/uuid.py); an explicit token may be passed positionally (deterministic tests)."""
+    if len(sample_token) > 1:
+      raise TypeError("append() takes at most one positional argument (the sample token)")
+    token = sample_token[0] if sample_token else uuid.uuid4().hex
+    np.savez_compressed(os.path.join(self._episode_dir, "%s.npz" % token), **observations)
     with open(self._metadata_fname, "a") as f:
-      f.write("%s\n" % sample_token)
+      f.write("%s\n" % token)
+
+  def read_sample(self, sample_token: str, attr: Optional[str] = None):
+    """core/dataset.py:79-109: the whole observation of a sample, or one attribute of it."""
+    with np.load(self.sample_path(sample_token), allow_pickle=True) as npz_file:
+      if attr is not None:
+        return npz_file[attr]
+      return {k: npz_file[k] for k in npz_file}
 
   def fetch(self) -> List[str]:
     with open(self._metadata_fname) as f:
@@ -82,7 +96,10 @@ def replay(agent, files: Sequence[str], batch_size: int, num_goals: int = 10, go
   dev = agent._device
   out = np.empty((len(files), 4, 2), np.float32)
   C = agent._in_channels
-  lidar_h = torch.empty(batch_size, 200, 200, C).pin_memory()
+  if len(files) == 0:
+    return out
+  H, W = load_datum(files[0], modalities=("lidar",))["lidar"].shape[:2]
+  lidar_h = torch.empty(batch_size, H, W, C).pin_memory()
   vec_h = torch.empty(batch_size, 5).pin_memory()
   goal_h = torch.empty(batch_size, num_goals, 2).pin_memory()
   for i0 in range(0, len(files), batch_size):

@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == bound, declared ^ bound
   for name in declared:
     assert hasattr(lib, name)
-  assert lib.rip_abi_version() == 1
+  assert lib.rip_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_no_cpu_fallback():
@@ -153,6 +153,10 @@ def test_replay_datum_and_episode_format(tmp_path):
     frames.append(fr)
     ep.append("tok%d" % i, **fr)
   assert ep.fetch() == ["tok0", "tok1", "tok2"]
+  ep.append(**frames[0])  # the reference's own call form: a random token (core/dataset.py:53-70)
+  assert len(ep.fetch()) == 4 and len(ep.fetch()[3]) == 32
+  np.testing.assert_array_equal(ep.read_sample(ep.fetch()[3], attr="velocity"), frames[0]["velocity"])
+  assert set(ep.read_sample("tok1")) == set(frames[1])
   d = replay.load_datum(ep.files()[1], mode=True)
   assert d["lidar"].dtype == np.float32 and d["lidar"].shape == (200, 200, 2)
   assert d["is_at_traffic_light"].shape == (1,) and d["is_at_traffic_light"][0] == 1.0
@@ -182,3 +186,98 @@ def test_cil_model_state_dict_and_command_logic():
   import pytest
   with pytest.raises(ValueError, match="Missing `mode`"):
     m(visual_features=None, velocity=None, is_at_traffic_light=None, traffic_light_state=None)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host rows pinned to the reference (fixtures from tools/make_golden_host.py, which runs the reference's code)
+# ---------------------------------------------------------------------------------------------------------
+def test_g11_frame_transforms_vs_reference(golden):
+  """utils/carla.py:642-700 (`rot2mat`, `world2local`, `local2world`) incl. pitch / roll and the squeeze of a
+  single point."""
+  from oatomobile_amd.agents import local2world, rot2mat, world2local
+  g = golden("g11_frames.npz")
+  for i in range(int(g["num_cases"])):
+    loc, rot, pts = g["loc%d" % i], g["rot%d" % i], g["pts%d" % i]
+    np.testing.assert_allclose(rot2mat(rot), g["R%d" % i], atol=1e-14)
+    w2l = world2local(current_location=loc, current_rotation=rot, world_locations=pts)
+    l2w = local2world(current_location=loc, current_rotation=rot, local_locations=pts)
+    np.testing.assert_allclose(w2l, g["w2l%d" % i], rtol=1e-13, atol=1e-11)
+    np.testing.assert_allclose(l2w, g["l2w%d" % i], rtol=1e-13, atol=1e-11)
+    one_w = world2local(current_location=loc, current_rotation=rot, world_locations=pts[0])
+    one_l = local2world(current_location=loc, current_rotation=rot, local_locations=pts[0])
+    assert one_w.shape == g["w2l_single%d" % i].shape == (3,)      # squeezed (utils/carla.py:674)
+    assert one_l.shape == g["l2w_single%d" % i].shape == (1, 3)    # not squeezed (:700)
+    np.testing.assert_allclose(one_w, g["w2l_single%d" % i], rtol=1e-13, atol=1e-11)
+    np.testing.assert_allclose(one_l, g["l2w_single%d" % i], rtol=1e-13, atol=1e-11)
+
+
+def test_g12_setpoint_agent_act_vs_reference(golden):
+  """base.py:116-176: replan cadence, buffer pop, ego->world transform, rendered predictions, target speed and the
+  spawn window — against what the reference's `act` handed its PID controller on the same 20-tick episodes."""
+  from oatomobile_amd.agents import SetPointAgent
+  g = golden("g12_setpoint.npz")
+  for case in range(int(g["num_cases"])):
+    plans = list(g["plans%d" % case])
+    calls = []
+
+    class Fixed(SetPointAgent):
+
+      def __call__(self, observation, *a, **k):
+        calls.append(1)
+        return plans[len(calls) - 1]
+
+    agent = Fixed(None, replan_every_steps=int(g["replan%d" % case]), setpoint_index=int(g["setpoint_index%d" % case]))
+    for t in range(len(g["locs%d" % case])):
+      if t == 12:
+        agent._steps_counter = 150
+      out = agent.act(dict(location=g["locs%d" % case][t], rotation=g["rots%d" % case][t]))
+      np.testing.assert_allclose(out["target_speed"] * 3.6, g["target_kmh%d" % case][t], rtol=1e-12)
+      np.testing.assert_allclose(out["setpoint"], g["waypoint%d" % case][t], rtol=1e-12, atol=1e-10)
+      np.testing.assert_allclose(np.atleast_2d(out["predictions"])[0], g["pred0_%d" % case][t], rtol=1e-10, atol=1e-9)
+    assert len(calls) == len(plans)  # same number of model calls as the reference made
+
+
+def test_g13_episode_written_by_reference(golden, tmp_path):
+  """An episode written by the reference's `Episode.append` (its file bytes are the fixture) read with
+  `replay.Episode` / `replay.load_datum`: token order, every modality, dtype / shape rules, the `mode` ladder
+  (datasets/carla.py:107-164) and `read_sample` (core/dataset.py:79-109)."""
+  from oatomobile_amd import replay
+  g = golden("g13_episode.npz")
+  d = tmp_path / "ep0"
+  d.mkdir()
+  (d / "metadata").write_bytes(g["metadata"].tobytes())
+  tokens = [str(t) for t in g["tokens"]]
+  for i, tok in enumerate(tokens):
+    (d / (tok + ".npz")).write_bytes(g["file%d" % i].tobytes())
+  ep = replay.Episode(str(tmp_path), "ep0")
+  assert ep.fetch() == tokens
+  modes = []
+  for i, f in enumerate(ep.files()):
+    datum = replay.load_datum(f, mode=True)
+    for k in replay.MODALITIES + ("mode",):
+      ref = g["datum%d_%s" % (i, k)]
+      assert datum[k].dtype == ref.dtype == np.float32 and datum[k].shape == ref.shape, k
+      np.testing.assert_array_equal(datum[k], ref)
+    assert datum["name"] == f
+    modes.append(int(datum["mode"][0]))
+    chw = replay.load_datum(f, modalities=("lidar",), dataformat="CHW")["lidar"]
+    assert tuple(chw.shape) == tuple(g["datum%d_lidar_chw_shape" % i])
+    assert float(chw.astype(np.float64).sum()) == float(g["datum%d_lidar_chw_sum" % i])
+    np.testing.assert_array_equal(ep.read_sample(tokens[i], attr="control"), g["sample%d_control" % i])
+  assert modes == [1, 2, 0, 2]  # STOP, LEFT, FORWARD, and theta = arccos(.) >= 0 never reaches RIGHT (:152, as coded)
+  # and the other direction: what replay.Episode writes, np.load (the reference's reader) reads back
+  ep2 = replay.Episode(str(tmp_path), "ep1")
+  ep2.append(lidar=g["datum0_lidar"], velocity=g["datum0_velocity"])
+  with np.load(ep2.files()[0]) as z:
+    np.testing.assert_array_equal(z["lidar"], g["datum0_lidar"])
+
+
+def test_validation_of_raw_pointer_inputs():
+  """dtype / contiguity / residency are enforced before a raw pointer crosses the C ABI."""
+  from oatomobile_amd import _lib
+  with pytest.raises(RuntimeError, match="no CPU path"):
+    _lib.ptr(torch.zeros(3))
+  with pytest.raises(ValueError, match="shape"):
+    _lib.expect_shape(torch.zeros(2, 3), (2, 4), "t")
+  _lib.expect_shape(torch.zeros(2, 3), (None, 3), "t")
+  assert _lib.ptr(None).value in (None, 0)
