@@ -216,12 +216,18 @@ class CandidateParallelRIP:
     plan_l, idx_l = select_best_plan(loss, plans)
     B = loss.shape[0]
     rec = torch.cat([loss.gather(1, idx_l[:, None]), plan_l.reshape(B, 8), (idx_l + self._begin).float()[:, None]], dim=1)
-    if self._world > 1 and dist.is_available() and dist.is_initialized():
-      allrec = rec.new_empty((self._world,) + tuple(rec.shape))
-      dist.all_gather_into_tensor(allrec.view(self._world * B, 10), rec.contiguous(), group=self._group)
-    else:
-      allrec = rec[None]
-    return reduce_rank_winners(allrec)
+    return reduce_rank_winners(gather_rank_winners(rec, self._group) if self._world > 1 else rec[None])
+
+
+def gather_rank_winners(rec: torch.Tensor, group=None) -> torch.Tensor:
+  """The candidate-parallel exchange: every rank's `[B, 10]` winner records -> `[world, B, 10]` on every rank (ONE
+  all-gather, 40 bytes per observation and rank)."""
+  rank, world = _world(group)
+  if world == 1:
+    return rec[None]
+  allrec = rec.new_empty((world,) + tuple(rec.shape))
+  dist.all_gather_into_tensor(allrec.view(world * rec.shape[0], rec.shape[1]), rec.contiguous(), group=group)
+  return allrec
 
 
 def reduce_rank_winners(allrec: torch.Tensor):

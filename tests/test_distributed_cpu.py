@@ -52,6 +52,20 @@ def _worker(rank, world, port, K, B, N, rows, out_dir):
     assert torch.equal(got, allrows)
     with pytest.raises(ValueError):
       D.all_gather_scores(full[:K].clone(), K)  # wrong share size
+    # gradient-mode model-parallel block exchange: [K_local, B, N, 9] per rank -> [K, B, N, 9] (uneven shares too)
+    blk = torch.from_numpy(np.random.default_rng(1).normal(size=(K, B, N, 9)).astype(np.float32))
+    assert torch.equal(D.all_gather_blocks(blk[b:e].clone(), K), blk)
+    # candidate-parallel winner exchange: lowest loss wins, ties go to the lower rank (= lower global index)
+    rec = torch.zeros(B, 10)
+    rec[:, 0] = torch.tensor([1.0 if rank == 0 else 0.5] + [2.0] * (B - 1))[:B]  # obs 0: rank 1 wins; others tie
+    rec[:, 1:9] = float(rank + 1)
+    rec[:, 9] = float(100 * rank + 7)
+    allrec = D.gather_rank_winners(rec)
+    assert allrec.shape == (world, B, 10)
+    plan, idx, best = D.reduce_rank_winners(allrec)
+    assert float(plan[0, 0, 0]) == 2.0 and int(idx[0]) == 107 and float(best[0]) == 0.5
+    if B > 1:
+      assert float(plan[1, 0, 0]) == 1.0 and int(idx[1]) == 7  # tie -> rank 0
     # barrier + max-over-ranks timing pattern used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

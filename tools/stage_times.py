@@ -30,10 +30,10 @@ def main():
   def run(e=None):
     s = _lib.current_stream()
     if e: e[0].record(st)
-    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, _lib.ptr(vec), B, 0, K, _lib.ENC_DTYPES[args.enc], _lib.ptr(z), s))
+    _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, 200, 200, _lib.ptr(vec), B, 0, K, _lib.ENC_DTYPES[args.enc], _lib.ptr(z), s))
     if e: e[1].record(st)
     _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x0), B, N, goal.shape[1], _lib.ALGORITHMS[args.algorithm],
-                              10, 0.1, 1.0, _lib.ptr(plan), None, _lib.ptr(loss), None, None, None, s))
+                              10, 0.1, 1.0, _lib.ptr(plan), None, _lib.ptr(loss), None, None, None, None, s))
     if e: e[2].record(st)
   for _ in range(10): run()
   torch.cuda.synchronize(); t0 = time.perf_counter()
