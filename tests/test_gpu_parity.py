@@ -830,8 +830,8 @@ def test_agent_sees_weight_updates_and_graph_equals_eager(dev):
   from oatomobile_amd import RIPAgent
   from oatomobile_amd.agents import interpolate_plan
   models = [hip_model(810 + k, dev) for k in range(2)]
-  g_agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, seed=2, graph=True)
-  e_agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, seed=2, graph=False)
+  g_agent = RIPAgent(None, algorithm="MA", models=models, num_candidates=16, seed=2, graph=True)
+  e_agent = RIPAgent(None, algorithm="MA", models=models, num_candidates=16, seed=2, graph=False)
   for i in range(4):
     ob = synth_observation(np.random.default_rng(30 + i))
     a, b = g_agent(dict(ob)), e_agent(dict(ob))
@@ -848,7 +848,7 @@ def test_agent_sees_weight_updates_and_graph_equals_eager(dev):
   after_g, after_e = g_agent(dict(ob)), e_agent(dict(ob))
   np.testing.assert_array_equal(after_g, after_e)
   assert np.abs(after_g - before).max() > 1e-6
-  fresh = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, seed=2, graph=False)
+  fresh = RIPAgent(None, algorithm="MA", models=models, num_candidates=16, seed=2, graph=False)
   np.testing.assert_array_equal(fresh(dict(ob)), after_g)
 
 
