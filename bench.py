@@ -52,8 +52,8 @@ ENC_ACT_ELEMS = 1466229 + 1465488  # layer-wise activation elements read + writt
 ENC_WEIGHT_ELEMS = 2370336 + 17056
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
-# MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 flop each) of the passes of search_mfma2_kernel, per 16-candidate
-# block (flow_mfma.hip: fwd_step = 251; adjoint step = 274, 82 at t = T-1)
+# MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 flop each) of the passes of search_phase_kernel, per 16-candidate
+# block (flow_phase.hip: fwd_step_lds = 251; adjoint step = 274, 82 at t = T-1)
 MFMA_FWD_PASS = 3 * 251
 MFMA_ADJ_PASS = 2 * 274 + 82
 MFMA_PREFIX = 251
@@ -281,25 +281,27 @@ def main():
   value = calls / elapsed
 
   extras = {}
-  use_mfma = (B * N >= 2048 and N % 16 == 0 and K <= 4)
+  use_mfma = (B * N >= 2048 and N % 16 == 0)  # rip_search auto: the phase-sequential MFMA kernel (flow_phase.hip)
   exec_flops = None
-  if rank == 0 and use_mfma and N % 32 == 0:
-    # exact executed-MFMA count of this launch: the inverse adjoint of model k runs for a 16-candidate block and step
-    # iff some candidate of the block selects k (WCM / BCM) — read from the kernel's own per-step posterior trace
+  if rank == 0 and use_mfma:
+    # exact executed-MFMA count of this launch: per 16-candidate block and Adam step the kernel runs F_0, K-1 inverses,
+    # the adjoint of F_0, and the adjoint of inverse k iff model k is the running arg-best (WCM / BCM) of some candidate
+    # of the block when it is reached — read from the kernel's own per-step posterior trace
     tp = torch.empty(S, K, B, N, device=dev)
     lidar, vec, goal = batches[0]
     _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x0), B, N, G, algo, S, 0.1, 1.0, None, None,
                               _lib.ptr(loss), None, _lib.ptr(tp), None, None, _lib.current_stream(dev)))
     torch.cuda.synchronize()
-    if args.algorithm == "MA":
-      adj_passes = float(S * (K - 1) * B * N // 16)
-    else:
-      sel = tp.argmax(dim=1) if args.algorithm == "WCM" else tp.argmin(dim=1)  # [S,B,N] (first index on ties)
-      onehot = torch.stack([(sel == k) for k in range(1, K)], 0) if K > 1 else torch.zeros(0, S, B, N, dtype=torch.bool, device=dev)
-      adj_passes = float(onehot.view(max(K - 1, 0), S, B, N // 16, 16).any(-1).sum().item())
     blocks16 = B * N / 16.0
+    if args.algorithm == "MA" or K == 1:
+      adj_passes = float(S * (K - 1) * blocks16)
+    else:
+      sign = 1.0 if args.algorithm == "WCM" else -1.0
+      run = (sign * tp).cummax(dim=1).values  # running best over models 0..k
+      take = (sign * tp[:, 1:]) > run[:, :-1]  # [S,K-1,B,N]: strictly better than every earlier model
+      adj_passes = float(take.view(S, K - 1, B, N // 16, 16).any(-1).sum().item())
     mfma = blocks16 * ((S + 1) * MFMA_FWD_PASS + S * MFMA_ADJ_PASS + S * (K - 1) * MFMA_FWD_PASS) + \
-        adj_passes * MFMA_ADJ_PASS + (B * N / 32.0) * K * MFMA_PREFIX
+        adj_passes * MFMA_ADJ_PASS + B * K * MFMA_PREFIX
     exec_flops = mfma * 2048.0
     extras["adjoint_inverse_passes_executed"] = adj_passes
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
@@ -329,18 +331,18 @@ def main():
     blocks16 = B * N / 16.0
     exec_tf = exec_flops / (search_ms * 1e-3) / 1e12 if exec_flops else None
     roof = {
-        "kernel": ("search_mfma2_kernel<%d> (pipelined MFMA plan search: F_0 + %d inverses + adjoints + Adam, %d steps in one launch)"
-                   % (min(K, 4), K - 1, S)) if use_mfma else
+        "kernel": ("search_phase_kernel (phase-sequential MFMA plan search: per 16-candidate wave F_0 + %d inverses + adjoints "
+                   "+ Adam, operands in LDS, %d steps in one launch)" % (K - 1, S)) if use_mfma else
                   ("search_kernel<%d> (wave-per-chain plan search, %d steps in one launch)" % (min(K, 4), S)),
         "bound": "mfma",
         "achieved": exec_tf,
         "peak": PEAK_FP32_TFLOPS,
         "unit": "TFLOP/s",
         "frac": exec_tf / PEAK_FP32_TFLOPS if exec_tf else None,
-        # HBM-side bytes per launch: the adjoint tape (K passes x 3 steps x 22 KiB written per 16-candidate block and
-        # Adam step, read back once); rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE in separate passes
-        # (profiles/) match this figure
-        "traffic": (2.0 * blocks16 * S * K * 3 * 22 * 1024) if use_mfma else None,
+        # L2 <-> fabric bytes per launch: the adjoint tape, written once and read back once per 16-candidate block,
+        # model and Adam step (F_0: 3 steps, inverses: 2 steps, the third stays in registers; a step is 16 or 20 rows
+        # of 1 KiB + 256 B of ReLU mask); rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE (profiles/)
+        "traffic": (2.0 * blocks16 * S * ((16 + 20 + 20) * 1024 + 3 * 256 + (K - 1) * ((16 + 20) * 1024 + 2 * 256))) if use_mfma else None,
         "ms_per_launch": search_ms,
         "contract_tflops": flow_flops / (search_ms * 1e-3) / 1e12,
         "contract_over_peak": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,

@@ -216,10 +216,13 @@ int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int
             float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
- *   RIP_OPT_SEARCH_KERNEL: 0 = auto (MFMA-batched when B*N >= 2048, N % 16 == 0, K <= 4),
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (phase-sequential MFMA kernel when B*N >= 2048 and N % 16 == 0, else
+ *     wave-per-chain),
  *     1 = wave-per-chain kernel (lowest latency, any K/N),
- *     2 = MFMA-batched kernel (16 candidates per wave; N % 16 == 0, K <= 4; N % 32 == 0 selects its pipelined
- *     dual-block form, the only one with trace outputs).  Both implement rip/agent.py:78-137.
+ *     2 = MFMA wave-per-model pipeline (16 candidates per wave, wave k = model k; N % 16 == 0, K <= 4; N % 32 == 0
+ *         selects its dual-block form, the only one with trace outputs),
+ *     3 = MFMA phase-sequential kernel (one wave per 16-candidate block runs all K models, operands in LDS, two
+ *         waves per SIMD; N % 16 == 0, any K <= 8, trace outputs).  All implement rip/agent.py:78-137.
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.

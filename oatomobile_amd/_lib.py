@@ -61,7 +61,7 @@ ABI_VERSION = 2
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
 OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED = 0, 1
-SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2}
+SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2, "phase": 3}
 
 _lib = None
 

@@ -87,5 +87,10 @@ size_t search_lds_bytes(int K);
 bool search_mfma_supported(const SearchArgs& a);
 size_t search_mfma_tape_bytes(int B, int N, int K);
 hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s);
+// phase-sequential variant (flow_phase.hip): one wave per 16-candidate block runs all K models, operands in LDS;
+// N % 16 == 0, any K <= MAX_MODELS, traces supported
+bool search_phase_supported(const SearchArgs& a);
+size_t search_phase_scratch_bytes(int B, int N, int K);
+hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* scratch, hipStream_t s);
 
 }  // namespace rip

@@ -30,7 +30,7 @@ struct rip_handle {
   float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the MFMA search kernel
   void* tape = nullptr;     // scratch of the MFMA search kernel
   size_t tape_bytes = 0;
-  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA-batched
+  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA wave-per-model pipeline, 3 MFMA phase-sequential
   int encoder_fused = -1;   // leading inverted-residual blocks run fused (0 = none, 17 = all); -1 = auto by batch
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
@@ -165,7 +165,10 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
   ALLOC(h->loss_best, (size_t)max_batch * max_candidates);
   ALLOC(h->trace_loss, (size_t)RIP_MAX_STEPS * max_batch);
   ALLOC(h->trace_x, (size_t)RIP_MAX_STEPS * max_batch * 8);
-  h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);  // 0 when the MFMA kernel can never run
+  // scratch of the MFMA search kernels (adjoint tape, prefix table): 0 when neither can ever run for this handle
+  h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
+  if (search_phase_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
+    h->tape_bytes = search_phase_scratch_bytes(max_batch, max_candidates, K);
   if (h->tape_bytes > 0) {
     float* tmp = nullptr;
     ALLOC(tmp, (h->tape_bytes + 3) / 4);
@@ -193,7 +196,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
   REQUIRE(h != nullptr, "handle is NULL");
   switch (option) {
     case RIP_OPT_SEARCH_KERNEL:
-      REQUIRE(value >= 0 && value <= 2, "search kernel %d not in {0 auto, 1 wave-per-chain, 2 mfma}", value);
+      REQUIRE(value >= 0 && value <= 3, "search kernel %d not in {0 auto, 1 wave-per-chain, 2 mfma, 3 phase}", value);
       h->search_mode = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_FUSED:
@@ -395,17 +398,26 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   a.trace_x = trace_x_dev;
   a.trace_loss = nullptr;
   a.trace_grad = trace_grad_dev;
-  // kernel choice: the MFMA-batched kernel wins once there are enough 16-candidate blocks to fill the chip;
-  // the wave-per-chain kernel has the lower latency for a single observation.
-  bool use_mfma = search_mfma_supported(a) && h->search_mode != 1 && (h->search_mode == 2 || (size_t)B * N >= 2048);
-  if (h->search_mode == 2 && !search_mfma_supported(a))
+  // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
+  // wave-per-chain kernel has the lower latency for a single observation.  Among the MFMA kernels the phase-sequential
+  // one (operands in LDS, two waves per SIMD, any K) is the default; mode 2 keeps the wave-per-model pipeline.
+  const bool big = (size_t)B * N >= 2048;
+  int kernel = 1;
+  if (h->search_mode == 3 || (h->search_mode == 0 && big && search_phase_supported(a))) kernel = 3;
+  if (h->search_mode == 2) kernel = 2;
+  if (kernel == 3 && !search_phase_supported(a))
+    return fail(RIP_EINVAL, "phase-sequential MFMA search needs N%%16==0 and K<=%d (K=%d N=%d)", RIP_MAX_MODELS, h->K, N);
+  if (kernel == 2 && !search_mfma_supported(a))
     return fail(RIP_EINVAL, "MFMA search kernel needs K<=4 and N%%16==0 (N%%32==0 with trace outputs) (K=%d N=%d)", h->K, N);
-  if (use_mfma) {
-    const size_t need = search_mfma_tape_bytes(B, N, h->K);
+  if (kernel != 1) {
+    const size_t need = kernel == 3 ? search_phase_scratch_bytes(B, N, h->K) : search_mfma_tape_bytes(B, N, h->K);
     if (need > h->tape_bytes)
-      return fail(RIP_ESTATE, "MFMA search tape for B=%d N=%d needs %zu B, rip_create sized %zu B (max_batch=%d x "
+      return fail(RIP_ESTATE, "MFMA search scratch for B=%d N=%d needs %zu B, rip_create sized %zu B (max_batch=%d x "
                   "max_candidates=%d)", B, N, need, h->tape_bytes, h->max_batch, h->max_candidates);
-    HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));
+    if (kernel == 3)
+      HIP_TRY(launch_search_phase(a, h->mfma_w, h->tape, (hipStream_t)stream));
+    else
+      HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));
   } else {
     HIP_TRY(launch_search(a, (hipStream_t)stream));
   }

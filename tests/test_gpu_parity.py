@@ -250,7 +250,7 @@ def test_g6_rip_reference_recipe(golden, dev, algo):
     np.testing.assert_allclose(out, g["out30_" + tag], atol=TOL)
 
 
-@pytest.mark.parametrize("kernel", ["chain", "mfma"])
+@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase"])
 @pytest.mark.parametrize("algo", ["WCM", "MA", "BCM"])
 def test_g6_search_traces(golden, dev, algo, kernel):
   """Per-step posteriors, latents, best loss and plan of BOTH search kernels vs the instrumented reference loop
@@ -285,7 +285,7 @@ def test_g6_search_traces(golden, dev, algo, kernel):
     assert torch.isfinite(tg).all()
 
 
-@pytest.mark.parametrize("kernel", ["chain", "mfma"])
+@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase"])
 @pytest.mark.parametrize("algo,K", [("WCM", 4), ("MA", 3), ("BCM", 2)])
 def test_teacher_forced_steps_vs_oracle(dev, kernel, algo, K):
   """Removes trajectory amplification from the kernel-vs-oracle comparison: every Adam step of the ORACLE's
@@ -375,7 +375,9 @@ def test_g8_scores(golden, dev):
 @pytest.mark.parametrize("kernel,algo,K,N", [("chain", "WCM", 4, 128), ("chain", "MA", 3, 16), ("chain", "BCM", 2, 5),
                                              ("chain", "WCM", 1, 7), ("chain", "WCM", 8, 8),
                                              ("mfma", "WCM", 4, 128), ("mfma", "MA", 3, 16), ("mfma", "BCM", 2, 32),
-                                             ("mfma", "WCM", 1, 16)])
+                                             ("mfma", "WCM", 1, 16),
+                                             ("phase", "WCM", 4, 128), ("phase", "MA", 3, 16), ("phase", "BCM", 2, 48),
+                                             ("phase", "WCM", 1, 16), ("phase", "WCM", 8, 32), ("phase", "MA", 5, 16)])
 def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
   """N candidates (BASELINE config 3 = K4/N128): every candidate's best loss and plan vs the oracle."""
   from oatomobile_amd import RIPAgent
@@ -408,13 +410,14 @@ def test_mfma_kernel_matches_chain_kernel(dev):
   vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
   goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
   out = {}
-  for kern in ("chain", "mfma"):
+  for kern in ("chain", "mfma", "phase"):
     agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=32, max_batch=3, seed=9, search_kernel=kern)
     plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
     out[kern] = (plan.cpu().numpy(), loss.cpu().numpy())
-  close = np.abs(out["chain"][1] - out["mfma"][1]) <= 1e-3 + 1e-4 * np.abs(out["chain"][1])
-  assert close.mean() >= 0.97
-  np.testing.assert_allclose(out["chain"][0], out["mfma"][0], atol=5e-4)
+  for kern in ("mfma", "phase"):
+    close = np.abs(out["chain"][1] - out[kern][1]) <= 1e-3 + 1e-4 * np.abs(out["chain"][1])
+    assert close.mean() >= 0.97, kern
+    np.testing.assert_allclose(out["chain"][0], out[kern][0], atol=5e-4, err_msg=kern)
   with pytest.raises(Exception):
     RIPAgent(None, algorithm="WCM", models=models, num_candidates=5, search_kernel="mfma").plan_batch(
         lidar[:1].contiguous(), vec[:1].contiguous(), goal[:1].contiguous())
