@@ -48,6 +48,18 @@ __device__ __forceinline__ f32x4 zero4() {
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return z;
 }
+// Two waves share a SIMD (waves w and w + 4 of the workgroup).  Arbitration is by age: the older wave runs at its solo
+// speed, the younger one fills its gaps and finishes alone (tools/search_ticks.py: F_0 pass 16 k vs 21 k cycles per step).
+// A wave raises its priority for its MFMA bursts and drops it for the VALU sections between them (gate math, tape
+// traffic), so that the partner's burst wins the issue port while this wave does VALU work: 4.74 -> 4.64 ms.  Measured
+// and rejected: balancing the two waves' progress tile by tile through LDS counters (both then reach the barrier
+// together, but evenly interleaved bursts cost more than the hand-over: 5.62 ms).
+#ifndef RIP_PRIO
+#define RIP_PRIO 1
+#endif
+#define PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+
 #ifndef RIP_ABL
 #define RIP_ABL 0  // development only: 1 = no tape loads, 2 = no operand reloads, 3 = no tape stores (wrong results)
 #endif
@@ -142,6 +154,7 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
 #pragma unroll
   for (int up = 0; up < 4; ++up) {
     f32x4 ar = zero4(), az = zero4(), agn = zero4(), ahn = zero4();
+    PRIO_BURST();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // 4 k-steps per operand row
       const float4 wr = wl[((0 * 4 + up) * 4 + j) * 64];
@@ -164,6 +177,7 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
     az = mfma(wxza[up], bin, az);
     agn = mfma(wxga[up], bin, agn);
     ahn = mfma(wxha[up], bin, ahn);
+    PRIO_VALU();
     float rr[4], zz[4], nn[4];
     gru_gates(ar, az, agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
     if (SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) {
@@ -190,6 +204,7 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
   // row 61 = W2 k-steps 2..5, row 62 = (W2 k-steps 6, 7, b2, -) ----
   const float bone = q == 2 ? 1.f : 0.f;
   f32x4 a0 = zero4(), a1 = zero4();
+  PRIO_BURST();
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float4 wa = wl[(52 + j) * 64];
@@ -229,6 +244,7 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
   oa = mfma(t61.y, fmaxf(a0[3], 0.f), oa);
   ob = mfma(t62.y, fmaxf(a1[3], 0.f), ob);
   oa = mfma(t62.z, bone, oa);
+  PRIO_VALU();
 #pragma unroll
   for (int r = 0; r < 4; ++r) o[r] = oa[r] + ob[r];
 }
@@ -446,6 +462,7 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
   }
   // ---- dh_t = W1^T da1_t + W_hh^T dgh_{t+1} (+ dh'_{t+1} z_{t+1} below) ----
   f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4(), acc3 = zero4();
+  PRIO_BURST();
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float4 w = tw[(1 + e) * 64];
@@ -464,6 +481,7 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
       acc3 = mfma(w.w, dgh[e], acc3);
     }
   }
+  PRIO_VALU();
   // ---- GRUCell adjoint, lane-local in the H layout (unit pairs: v_pk_mul_f32 / v_pk_fma_f32) ----
   using f2 = __attribute__((ext_vector_type(2))) float;
   const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
@@ -496,6 +514,7 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
   }
   // ---- du = W_ih^T (dpr, dpz, dpn): rows m <-> input dim m & 1 ----
   f32x4 dua = zero4(), dub = zero4();
+  PRIO_BURST();
 #pragma unroll
   for (int g = 0; g < 12; ++g) {
     const float4 wq = wq4[g * 8];
@@ -508,6 +527,7 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
     dua = mfma(wq.z, b2, dua);
     dub = mfma(wq.w, b3, dub);
   }
+  PRIO_VALU();
   carry0 = c0 + (dua[0] + dub[0]);
   carry1 = c1 + (dua[1] + dub[1]);
 }
@@ -588,6 +608,16 @@ __global__ __launch_bounds__(64) void phase_prefix_kernel(SearchArgs a, const fl
   }
 }
 
+#ifdef RIP_PROFILE_TICKS  // development (tools/search_ticks.py): where a wave's cycles go; one workgroup prints at the end
+#define TK_DECL() long long tk_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk0_ = 0
+#define TK_START() tk0_ = clock64()
+#define TK_STOP(i_) tk_[i_] += clock64() - tk0_
+#else
+#define TK_DECL()
+#define TK_START()
+#define TK_STOP(i_)
+#endif
+
 template <bool TRACE>
 __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, const float* __restrict__ mw_all,
                                                                 const float* __restrict__ pre_all,
@@ -632,19 +662,24 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
   load_tbuf(sh, K > 1 ? mw0 + MW_SIZE : mw0, wave, lane, tid);
 
   const int S = a.num_steps;
+  TK_DECL();
 #pragma unroll 1
   for (int step = 0; step <= S; ++step) {
     const bool final_pass = step == S;
     // ================= F_0: x -> y (F-buf = model 0) =================
     io[c][2 * q] = final_pass ? xb0 : xv0;
     io[c][2 * q + 1] = final_pass ? xb1 : xv1;
+    TK_START();
     __syncthreads();  // F-buf (and, at step 0, T-buf) landed; io visible within the wave
+    TK_STOP(0);
     float q_sel, gl = 0.f, gg0 = 0.f, gg1 = 0.f, w0;
     int ksel = 0;
     float gsel[8];
     {
       const Prefix16 pre = load_prefix(pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, q);
+      TK_START();
       const PassOut po = pass_forward<MODE_FWD>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
+      TK_STOP(1);
       __builtin_amdgcn_wave_barrier();
       if (final_pass) break;
       if (goal != nullptr) gl = goal_ll(goal, a.G, a.epsilon, io[c][6], io[c][7], &gg0, &gg1);
@@ -658,16 +693,22 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
     // ================= models 1..K-1: inverse, adjoint, streaming aggregation =================
 #pragma unroll 1
     for (int k = 1; k < K; ++k) {
+      TK_START();
       __syncthreads();  // every wave is done with the F-buf (F_0 or inverse_{k-1}) and the T-buf (adjoint_{k-1})
+      TK_STOP(2);
+      TK_START();
       const float* mwk = mw_all + (size_t)(a.k0 + k) * MW_SIZE;
       if (RIP_ABL != 2) {
         load_fbuf(sh, mwk, wave, lane);
         if (k > 1) load_tbuf(sh, mwk, wave, lane, tid);  // (model 1's T-buf was requested under F_0)
       }
       __syncthreads();  // operands of model k landed
+      TK_STOP(3);
+      TK_START();
       const Prefix16 pre = load_prefix(pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, q);
       StepTape last;
       const PassOut po = pass_forward<MODE_INV>(wl, pre, io, stI, tapeI, &last, c, q, (unsigned)lane);
+      TK_STOP(4);
       const float qk = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
       if (TRACE && a.trace_post != nullptr && q == 0 && active)
         a.trace_post[(((size_t)step * K + k) * a.B + b) * a.N + n0 + c] = qk + gl;
@@ -677,8 +718,10 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
       if (mean_mode || __any(take)) {
         __builtin_amdgcn_wave_barrier();
         float res[8];
+        TK_START();
         pass_backward<MODE_INV>(tw, wq4, nullptr, stI, tapeI, &last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
                                 res, 0.f);
+        TK_STOP(5);
         if (mean_mode) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) gsel[i] += inv_k * res[i];
@@ -696,7 +739,9 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
     w0 = (mean_mode ? inv_k : (ksel == 0 ? 1.0f : 0.0f)) * a.grad_scale;
     // ================= adjoint of F_0 + Adam (T-buf = model 0) =================
     if (K > 1) {
+      TK_START();
       __syncthreads();  // every wave is done with model K-1's buffers
+      TK_STOP(6);
       if (RIP_ABL != 2) {
         load_tbuf(sh, mw0, wave, lane, tid);
         load_fbuf(sh, mw0, wave, lane);  // next step's F_0
@@ -713,10 +758,14 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
       gy[c][2 * q] = -ga * a.grad_scale;
       gy[c][2 * q + 1] = -gb * a.grad_scale;
     }
+    TK_START();
     if (K > 1) __syncthreads();  // model 0's T-buf (and next step's F-buf) landed
+    TK_STOP(7);
     __builtin_amdgcn_wave_barrier();
     float res[8];
+    TK_START();
     pass_backward<MODE_FWD>(tw, wq4, gy, stF, tapeF, nullptr, pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, c, q, res, w0);
+    TK_STOP(8);
     const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
     const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
     // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
@@ -753,6 +802,12 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
       if (step + 1 < S && RIP_ABL != 2) load_tbuf(sh, mw0 + MW_SIZE, wave, lane, tid);
     }
   }
+#ifdef RIP_PROFILE_TICKS
+  if (blockIdx.x == 7 && lane == 0)
+    printf("ticks wave %d: barrier-top %lld | F %lld | barrier-done %lld barrier-dma %lld | inv %lld adj %lld | "
+           "barrier-last %lld barrier-dma0 %lld | adjF %lld\n", wave, tk_[0], tk_[1], tk_[2], tk_[3], tk_[4], tk_[5], tk_[6],
+           tk_[7], tk_[8]);
+#endif
   // plan = F_0(x_best) is in io (rip/agent.py:137)
   if (active) {
     if (a.plans != nullptr) {
