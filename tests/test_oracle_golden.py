@@ -194,3 +194,55 @@ def test_g10_cil_oracle_matches_reference(golden):
     plan = C.cil_call(m, ob)
     assert plan.shape == (39, 3)
     np.testing.assert_allclose(plan, g["agent_plan%d" % i], rtol=2e-5, atol=2e-4)
+
+
+def check_train_tensors(g, t, grads, new_params, rtol=2e-3, atol_frac=2e-4):
+  """Gradients and post-Adam parameters of one training step against the fixture `g` (step tag `t`).  Large tensors are
+  held by 1024 sampled entries + an L2 checksum.  A parameter entry is only compared where its reference gradient is
+  above rounding noise: Adam divides by sqrt(v), so a mathematically-zero gradient (1e-8 of noise, e.g. a BatchNorm
+  bias in front of another batch-statistics BatchNorm) moves its parameter by +-lr with a noise-determined sign — in
+  the reference as much as anywhere else."""
+  for k in map(str, g["keys"]):
+    if t + "grad:" + k in g.files:
+      gref, pref = g[t + "grad:" + k].reshape(-1), g[t + "param:" + k].reshape(-1)
+      gact, pact = grads[k].reshape(-1), new_params[k].reshape(-1)
+    else:
+      idx = g[t + "grad:" + k + ":idx"]
+      gref, pref = g[t + "grad:" + k + ":val"], g[t + "param:" + k + ":val"]
+      gact, pact = grads[k].reshape(-1)[idx], new_params[k].reshape(-1)[idx]
+      l2 = np.sqrt((grads[k].astype(np.float64)**2).sum())
+      np.testing.assert_allclose(l2, float(g[t + "grad:" + k + ":l2"]), rtol=rtol, atol=1e-6, err_msg="grad l2 " + k)
+    np.testing.assert_allclose(gact, gref, rtol=rtol, atol=1e-6 + atol_frac * np.abs(gref).max(), err_msg="grad:" + k)
+    solid = np.abs(gref) > 1e-5 + 1e-3 * np.abs(gref).max()
+    np.testing.assert_allclose(pact[solid], pref[solid], rtol=1e-4, atol=2e-5 if atol_frac < 1e-3 else 3e-4, err_msg="param:" + k)
+
+
+def test_g15_train_step_oracle_vs_reference(golden):
+  """oracle/train_cpu.py against the reference's own model run through dim/train.py:175-213 (two Adam steps, train
+  mode): loss, z, sampled gradients, post-step parameters and BatchNorm running statistics.  (A BatchNorm bias that
+  feeds a convolution followed by another batch-statistics BatchNorm has a mathematically zero gradient: 1e-8 of
+  rounding noise on both sides, hence the absolute floor.)"""
+  import torch
+  from oracle import train_cpu as TC
+  g = golden("g15_train_step.npz")
+  m = TC.trainable_model(W.synthetic_state_dict(int(g["weight_seed"])))
+  opt = TC.make_adam(m, lr=float(g["lr"]))
+  params = dict(m.named_parameters())
+  for step in range(2):
+    t = "s%d_" % step
+    loss, z = TC.loss_and_grads(m, torch.from_numpy(g[t + "visual_features"]), torch.from_numpy(g[t + "velocity"]),
+                                torch.from_numpy(g[t + "is_at_traffic_light"]), torch.from_numpy(g[t + "traffic_light_state"]),
+                                torch.from_numpy(g[t + "y"]), torch.from_numpy(g[t + "dropout_mask"]))
+    np.testing.assert_allclose(float(loss), float(g[t + "loss"]), rtol=1e-5)
+    # (step 1 starts from parameters that already carry step 0's noise-determined +-lr moves, see check_train_tensors)
+    np.testing.assert_allclose(z.numpy(), g[t + "z"], rtol=1e-4 if step == 0 else 1e-3, atol=1e-5 if step == 0 else 1e-4)
+    grads = {k: params[k].grad.detach().numpy().copy() for k in map(str, g["keys"])}
+    opt.step()
+    # step 1 starts from step 0's noise-determined +-lr moves of the zero-gradient parameters: the 52-layer backward
+    # amplifies them to ~0.5 % on the first conv's gradient, in ANY two runs that differ by rounding
+    check_train_tensors(g, t, grads, {k: params[k].detach().numpy() for k in map(str, g["keys"])},
+                        rtol=2e-3 if step == 0 else 3e-2, atol_frac=2e-4 if step == 0 else 2e-2)
+    sd = m.state_dict()
+    for key in g.files:
+      if key.startswith(t + "buffer:") and "num_batches" not in key:
+        np.testing.assert_allclose(sd[key[len(t + "buffer:"):]].numpy(), g[key], rtol=1e-5, atol=1e-6)
