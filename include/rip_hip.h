@@ -22,8 +22,8 @@
  *     hipFree / hipMemcpy / device synchronisation (safe under stream capture).
  *     All device scratch is allocated by rip_create from (max_batch,
  *     max_candidates); a call that exceeds it returns RIP_ESTATE.
- *     rip_create / rip_destroy / rip_load_model / rip_train_* setup calls are
- *     the only ones that allocate or copy synchronously.  NULL = the null stream.
+ *     rip_create / rip_destroy / rip_load_model / rip_train_create / _destroy
+ *     are the only ones that allocate or copy synchronously.  NULL = the null stream.
  *   - a handle is bound to one device: every entry point that takes a handle
  *     makes that device current for the duration of the call and restores the
  *     caller's current device before returning.  The stateless entry points
@@ -214,6 +214,44 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
 int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
             const float* goal_dev, const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr,
             float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
+
+/* N3 — the DIM training step, oatomobile/baselines/torch/dim/train.py:175-213:
+ *   z = model._params(...) in TRAIN mode (MobileNetV2 BatchNorm on batch statistics with the running-stat update,
+ *   Dropout before the classifier), _, log_prob, logabsdet = decoder._inverse(y, z),
+ *   loss = -mean(log_prob - logabsdet), loss.backward(), torch.optim.Adam(lr).step().
+ * Parameters, gradients and the two Adam moments are caller-owned device vectors of rip_train_numel(C) floats in the
+ * reference's state_dict order minus the int64 num_batches_tracked counters (the `packed_host` layout of
+ * rip_load_model: conv weight, BN weight, BN bias, running_mean, running_var per conv, classifier, merger, GRUCell,
+ * head), so that a data-parallel job all-reduces ONE gradient tensor between the two calls.  The trainer handle owns
+ * the activation workspace for up to max_batch observations (fp32, 3 x 11.7 MB per observation).
+ *
+ * rip_train_forward_backward: visual_dev [B,C,100,100] (rip_transform output), vec_dev [B,5], y_dev [B,4,2] (the
+ *   target, already perturbed by the caller: train.py:184-189), dropout_mask_dev [B,1280] keep/scale factors (0 or
+ *   1/(1-p); NULL = no dropout).  batch_stats != 0: BatchNorm train mode, the running statistics inside params_dev are
+ *   updated (momentum 0.1); 0: running statistics are used and left alone ("frozen" BatchNorm / evaluate_step).
+ *   Writes grads_dev (running-statistic slots: 0), *loss_dev, z_dev [B,64] (optional).
+ * rip_train_adam: torch.optim.Adam step `step` (1-based) on the entries with trainable_dev[i] != 0
+ *   (rip_train_trainable_mask: everything but the running statistics); weight_decay is added to the gradient.
+ * Both enqueue on `stream` without synchronising; rip_train_create / _destroy / _trainable_mask are setup calls. */
+typedef struct rip_trainer rip_trainer;
+size_t rip_train_numel(int in_channels);
+int rip_train_create(rip_trainer** out, int in_channels, int max_batch, int device);
+int rip_train_destroy(rip_trainer* t);
+int rip_train_trainable_mask(const rip_trainer* t, unsigned char* mask_host, size_t numel);
+int rip_train_forward_backward(rip_trainer* t, float* params_dev, float* grads_dev, const float* visual_dev,
+                               const float* vec_dev, const float* y_dev, const float* dropout_mask_dev, int B,
+                               int batch_stats, float* loss_dev, float* z_dev, rip_stream_t stream);
+int rip_train_adam(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev,
+                   const unsigned char* trainable_dev, size_t numel, int step, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, rip_stream_t stream);
+/* Inspection: copies what the last rip_train_forward_backward (batch B) saved for conv layer `layer` (0 = features.0,
+ * then the convs of features.1 .. features.18 in order; rip_train_num_layers of them) to dst_dev, NHWC [B,H,W,C]:
+ * what = 0 the pre-BatchNorm conv output, 1 the post-activation output, 2 the gradient w.r.t. that output.
+ * (A gradient through ReLU6 is only defined up to the kink decisions: two implementations whose forward values differ
+ * in the 7th digit disagree on the mask of the ~1e-7 fraction of activations that sit on a kink, and each such element
+ * moves a per-channel gradient by ~1/(B*H*W).  Tests read the masks back through this call to compare like with like.) */
+int rip_train_peek(rip_trainer* t, int layer, int what, int B, float* dst_dev, size_t dst_numel, rip_stream_t stream);
+int rip_train_num_layers(const rip_trainer* t);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
  *   RIP_OPT_SEARCH_KERNEL: 0 = auto (phase-sequential MFMA kernel when B*N >= 2048 and N % 16 == 0, else

@@ -13,6 +13,7 @@ from oatomobile_amd.model import transform_visual
 from oatomobile_amd.cil import BehaviouralModel
 from oatomobile_amd.cil import CILAgent
 from oatomobile_amd.lidar import lidar_to_bev
+from oatomobile_amd.train import DIMTrainer
 
 __all__ = ["ImitativeModel", "RIPAgent", "DIMAgent", "SetPointAgent", "transform_visual", "lidar_to_bev",
-           "BehaviouralModel", "CILAgent"]
+           "BehaviouralModel", "CILAgent", "DIMTrainer"]

@@ -55,6 +55,17 @@ SIGNATURES = [
     ("rip_in_channels", c_int, [c_void_p]),
     ("rip_max_batch", c_int, [c_void_p]),
     ("rip_max_candidates", c_int, [c_void_p]),
+    ("rip_train_numel", c_size_t, [c_int]),
+    ("rip_train_create", c_int, [POINTER(c_void_p), c_int, c_int, c_int]),
+    ("rip_train_destroy", c_int, [c_void_p]),
+    ("rip_train_trainable_mask", c_int, [c_void_p, c_void_p, c_size_t]),
+    ("rip_train_forward_backward", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("rip_train_peek", c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    ("rip_train_num_layers", c_int, [c_void_p]),
+    ("rip_train_adam", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float,
+      c_void_p]),
 ]
 ABI_VERSION = 2
 

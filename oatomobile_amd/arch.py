@@ -72,6 +72,29 @@ def blocks(input_hw: int = INPUT_HW) -> List[Block]:
   return out
 
 
+class ConvLayer(NamedTuple):
+  """One conv + BatchNorm of the MobileNetV2 stack, in network order (what rip_train_peek indexes)."""
+  name: str    # state_dict prefix of the conv weight's module, e.g. "_encoder._model.features.2.conv.0.0"
+  cout: int
+  h_out: int
+  relu6: bool  # followed by ReLU6 (every conv but the linear-bottleneck projections)
+
+
+def conv_layers(in_channels: int = 2, input_hw: int = INPUT_HW) -> List[ConvLayer]:
+  f = "_encoder._model.features."
+  out = [ConvLayer(f + "0.0", STEM_CHANNELS, conv_out(input_hw, 2), True)]
+  for b in blocks(input_hw):
+    p = f + "%d.conv." % b.index
+    j = 0
+    if b.expand:
+      out.append(ConvLayer(p + "0.0", b.hidden, b.h_in, True))
+      j = 1
+    out.append(ConvLayer(p + "%d.0" % j, b.hidden, b.h_out, True))
+    out.append(ConvLayer(p + "%d" % (j + 1), b.oup, b.h_out, False))
+  out.append(ConvLayer(f + "18.0", LAST_CHANNELS, out[-1].h_out, True))
+  return out
+
+
 def _bn(prefix: str, c: int):
   return [
       (prefix + ".weight", (c,)),

@@ -19,6 +19,7 @@
 //   adam                torch.optim.Adam defaults     rip/agent.py:96,131
 #include "flow.h"
 #include "flow_math.h"
+#include "train.h"
 
 #include <mutex>
 #include <set>
@@ -1238,6 +1239,157 @@ __global__ __launch_bounds__(64) void mp_update_kernel(MpArgs a, const float* __
   if (lane == 0 && loss < lb) loss_best[bn] = loss;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// DIM training step, flow part (dim/train.py:198-204): teacher-forced inverse of one (y, z) row per
+// wave (sequence.py:153-216) with ALL four steps taped (h_0 = z is a function of the encoder here), its adjoint with
+// cotangent `cot` (= -1/B: loss = -mean(log_prob - logabsdet)) into dz, and per (row, step) the vectors whose outer
+// products are the weight gradients:  dW_ih = dgi^T u,  dW_hh = dgh^T hprev,  dW1 = da1^T h,  dW2 = do^T relu(a1)
+// (formed afterwards as GEMMs over the B*T records; the bias gradients are their column sums).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_train_kernel(const float* __restrict__ blob, const float* __restrict__ z,
+                                                          const float* __restrict__ y, int B, float cot,
+                                                          float* __restrict__ q_rows, float* __restrict__ dz,
+                                                          float* __restrict__ rec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w1 = smem;                                    // W1_LDS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  float* tp = smem + W1_LDS + wave * (T * 7 * 64 + T * 8);  // per wave: [t][7][64] lane tape + [t][8] uniforms
+  float* tu = tp + T * 7 * 64;
+  stage_w1(w1, blob, tid, blockDim.x);
+  FlowRegs W;
+  load_flow_regs(W, blob, lane);
+  __syncthreads();
+  const float* w1row = w1 + (lane & 31) * W1_STRIDE;
+  const bool upper = lane >= 32;
+  for (int row = blockIdx.x * nw + wave; row < B; row += gridDim.x * nw) {
+    const float* yr = y + (size_t)row * 8;
+    float h = z[(size_t)row * 64 + lane];
+    float u0 = 0.f, u1 = 0.f, sq = 0.f, lad = 0.f;
+    // ---------------- forward ----------------
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+      float gh[3], a1 = 0.f;
+      matvec<true, false>(W, w1row, h, gh, a1);
+      const float gir = fmaf(W.wih[0][1], u1, fmaf(W.wih[0][0], u0, W.bih[0]));
+      const float giz = fmaf(W.wih[1][1], u1, fmaf(W.wih[1][0], u0, W.bih[1]));
+      const float gin = fmaf(W.wih[2][1], u1, fmaf(W.wih[2][0], u0, W.bih[2]));
+      const float r = sigmoidf_(gir + gh[0]);
+      const float zg = sigmoidf_(giz + gh[1]);
+      const float n = tanhf_(fmaf(r, gh[2], gin));
+      const float hn = fmaf(zg, h - n, n);
+      float* tl = tp + t * 7 * 64 + lane;
+      tl[0 * 64] = h;
+      tl[1 * 64] = r;
+      tl[2 * 64] = zg;
+      tl[3 * 64] = n;
+      tl[4 * 64] = gh[2];
+      h = hn;
+      float ghx[3];
+      matvec<false, true>(W, w1row, h, ghx, a1);
+      tl[5 * 64] = a1;
+      tl[6 * 64] = h;
+      float o0, o1, o2, o3;
+      head_finish(W, a1, o0, o1, o2, o3);
+      const float s0 = softplusf_(o2) + 1e-3f, s1 = softplusf_(o3) + 1e-3f;  // sequence.py:193
+      const float y0 = yr[2 * t], y1 = yr[2 * t + 1];
+      const float x0 = (y0 - (u0 + o0)) * rcpf_(s0), x1 = (y1 - (u1 + o1)) * rcpf_(s1);  // :196
+      sq = fmaf(x0, x0, fmaf(x1, x1, sq));
+      lad += __logf(s0 * s1);
+      if (lane == 0) {
+        float* q8 = tu + t * 8;
+        q8[0] = x0;
+        q8[1] = x1;
+        q8[2] = s0;
+        q8[3] = s1;
+        q8[4] = softplus_gradf_(o2);
+        q8[5] = softplus_gradf_(o3);
+        q8[6] = u0;
+        q8[7] = u1;
+      }
+      u0 = y0;  // teacher forcing, :201
+      u1 = y1;
+    }
+    if (lane == 0) q_rows[row] = (-0.5f * sq - 4.0f * LOG_2PI) - lad;
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- adjoint ----------------
+    float dhdir = 0.f, dpr = 0.f, dpz = 0.f, dghn = 0.f;
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+      const float* q8 = tu + t * 8;
+      const float x0 = q8[0], x1 = q8[1], s0 = q8[2], s1 = q8[3], sg0 = q8[4], sg1 = q8[5];
+      const float i0 = rcpf_(s0), i1 = rcpf_(s1);
+      // q = -0.5 |x|^2 - sum log s:  dq/ddloc = x / s,  dq/ds = (x^2 - 1) / s  (then through softplus)
+      const float dd0 = cot * x0 * i0, dd1 = cot * x1 * i1;
+      const float dos0 = cot * (x0 * x0 - 1.0f) * i0 * sg0, dos1 = cot * (x1 * x1 - 1.0f) * i1 * sg1;
+      const float* tl = tp + t * 7 * 64 + lane;
+      const float a1 = tl[5 * 64];
+      const float part = W.w2a * (upper ? dos0 : dd0) + W.w2b * (upper ? dos1 : dd1);
+      float da1 = xor32_sum(part);
+      da1 = a1 > 0.f ? da1 : 0.f;
+      const float da1h = upper ? 0.f : da1;  // rows of W1 are duplicated in both halves
+      const float dh = transposed_matvec(W, w1row, da1h, dpr, dpz, dghn, lane) + dhdir;
+      const float hprev = tl[0 * 64], r = tl[1 * 64], zg = tl[2 * 64], n = tl[3 * 64], ghn = tl[4 * 64];
+      const float dn = dh * (1.0f - zg);
+      const float dzg = dh * (hprev - n);
+      dhdir = dh * zg;
+      const float dpn = dn * (1.0f - n * n);
+      const float dr = dpn * ghn;
+      dghn = dpn * r;
+      dpr = dr * r * (1.0f - r);
+      dpz = dzg * zg * (1.0f - zg);
+      float* rc = rec + ((size_t)row * T + t) * FLOW_TRAIN_REC;
+      rc[0 * 64 + lane] = dpr;   // dgi = (d pre_r, d pre_z, d pre_n)
+      rc[1 * 64 + lane] = dpz;
+      rc[2 * 64 + lane] = dpn;
+      rc[192 + 0 * 64 + lane] = dpr;  // dgh = (d pre_r, d pre_z, d gh_n)
+      rc[192 + 1 * 64 + lane] = dpz;
+      rc[192 + 2 * 64 + lane] = dghn;
+      rc[384 + lane] = hprev;
+      if (lane < 2) rc[448 + lane] = q8[6 + lane];
+      if (lane < 32) {
+        rc[450 + lane] = da1;
+        rc[550 + lane] = fmaxf(a1, 0.f);
+      }
+      rc[482 + lane] = tl[6 * 64];
+      if (lane < 4) rc[546 + lane] = lane == 0 ? dd0 : (lane == 1 ? dd1 : (lane == 2 ? dos0 : dos1));
+    }
+    dz[(size_t)row * 64 + lane] = transposed_matvec(W, w1row, 0.f, dpr, dpz, dghn, lane) + dhdir;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// reference tensor layout -> the lane-major FW_* blob of flow.h (what fold_and_pack does on the host for inference)
+__global__ void flow_relayout_kernel(const float* __restrict__ wih, const float* __restrict__ whh,
+                                     const float* __restrict__ bih, const float* __restrict__ bhh,
+                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ blob) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= FW_SIZE) return;
+  float v = 0.f;
+  if (i < FW_WIH) {  // [(g*16+i4)][64 lanes][4]
+    const int q = i & 3, j = (i >> 2) & 63, c = i >> 8, g = c / 16, i4 = c % 16;
+    v = whh[(size_t)(g * 64 + j) * 64 + 4 * i4 + q];
+  } else if (i < FW_BIH) {
+    const int e = i - FW_WIH, j = e & 63, gd = e >> 6, g = gd >> 1, d = gd & 1;
+    v = wih[(g * 64 + j) * 2 + d];
+  } else if (i < FW_BHH) {
+    v = bih[i - FW_BIH];
+  } else if (i < FW_B1) {
+    v = bhh[i - FW_BHH];
+  } else if (i < FW_W2) {
+    v = b1[(i - FW_B1) & 31];
+  } else if (i < FW_B2) {
+    const int e = i - FW_W2, j = e & 63, qq = e >> 6;
+    v = w2[(2 * (j >> 5) + qq) * 32 + (j & 31)];
+  } else if (i < FW_W1) {
+    v = b2[i - FW_B2];
+  } else {
+    v = w1[i - FW_W1];
+  }
+  blob[i] = v;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1372,6 +1524,21 @@ hipError_t launch_mp_update(const MpArgs& a, const float* gathered, float* x, fl
   const size_t lds = (size_t)(W1_LDS + TAPE + 32) * sizeof(float);
   hipLaunchKernelGGL(mp_update_kernel, dim3(a.B * a.N), dim3(64), lds, s, a, gathered, x, m, v, x_best, loss_best,
                      grad_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_flow_train(const float* wih, const float* whh, const float* bih, const float* bhh, const float* w1,
+                             const float* b1, const float* w2, const float* b2, const float* z, const float* y, int B,
+                             float* q_rows, float* dz, float* records, hipStream_t s) {
+  // the lane-major blob lives in the first FW_SIZE floats after the records of the LAST row (the caller sizes the
+  // record buffer for max_batch rows + this blob: see trainer_create)
+  float* blob = records + (size_t)B * FLOW_TRAIN_ROW_FLOATS;
+  hipLaunchKernelGGL(flow_relayout_kernel, dim3((FW_SIZE + 255) / 256), dim3(256), 0, s, wih, whh, bih, bhh, w1, b1, w2, b2,
+                     blob);
+  const size_t lds = (size_t)(W1_LDS + 4 * (T * 7 * 64 + T * 8)) * sizeof(float);
+  int g = (B + 3) / 4;
+  g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+  hipLaunchKernelGGL(flow_train_kernel, dim3(g), dim3(256), lds, s, blob, z, y, B, -1.0f / (float)B, q_rows, dz, records);
   return hipGetLastError();
 }
 

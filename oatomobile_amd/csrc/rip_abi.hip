@@ -12,6 +12,7 @@
 
 #include "encoder.h"
 #include "flow.h"
+#include "train.h"
 
 using namespace rip;
 
@@ -529,6 +530,85 @@ int rip_mp_update(rip_handle* h, int k_fwd, const float* z_fwd_dev, const float*
   fill_mp(h, a, k_fwd, 0, 0, 0, z_fwd_dev, nullptr, goal_dev, B, N, G, K, algorithm, lr, epsilon, step);
   ENTER(h, stream);
   HIP_TRY(launch_mp_update(a, gathered_dev, x_dev, m_dev, v_dev, x_best_dev, loss_best_dev, grad_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+// ---------------- N3: DIM training step (train.hip) ----------------
+size_t rip_train_numel(int in_channels) { return in_channels >= 1 && in_channels <= 16 ? train_numel(in_channels) : 0; }
+
+int rip_train_create(rip_trainer** out, int in_channels, int max_batch, int device) {
+  REQUIRE(out != nullptr, "out is NULL");
+  REQUIRE(in_channels >= 1 && in_channels <= 16, "in_channels=%d outside [1,16]", in_channels);
+  REQUIRE(max_batch >= 1, "max_batch=%d must be >= 1", max_batch);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  REQUIRE(device >= 0 && device < ndev, "device %d not in [0,%d)", device, ndev);
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(scope.err));
+  Trainer* t = nullptr;
+  hipError_t e = trainer_create(&t, in_channels, max_batch, device);
+  if (e != hipSuccess) return fail(RIP_EHIP, "trainer workspace allocation failed: %s", hipGetErrorString(e));
+  *out = reinterpret_cast<rip_trainer*>(t);
+  return RIP_OK;
+}
+
+int rip_train_destroy(rip_trainer* t) {
+  if (t == nullptr) return RIP_OK;
+  Trainer* tr = reinterpret_cast<Trainer*>(t);
+  DeviceScope scope(trainer_device(tr));
+  trainer_destroy(tr);
+  return RIP_OK;
+}
+
+int rip_train_trainable_mask(const rip_trainer* t, unsigned char* mask_host, size_t numel) {
+  REQUIRE(t != nullptr && mask_host != nullptr, "NULL argument");
+  const Trainer* tr = reinterpret_cast<const Trainer*>(t);
+  REQUIRE(numel == trainer_numel(tr), "numel=%zu, expected %zu", numel, trainer_numel(tr));
+  trainer_trainable_mask(tr, mask_host);
+  return RIP_OK;
+}
+
+int rip_train_forward_backward(rip_trainer* t, float* params_dev, float* grads_dev, const float* visual_dev,
+                               const float* vec_dev, const float* y_dev, const float* dropout_mask_dev, int B,
+                               int batch_stats, float* loss_dev, float* z_dev, rip_stream_t stream) {
+  REQUIRE(t != nullptr, "trainer is NULL");
+  Trainer* tr = reinterpret_cast<Trainer*>(t);
+  REQUIRE(params_dev != nullptr && grads_dev != nullptr && visual_dev != nullptr && vec_dev != nullptr && y_dev != nullptr &&
+              loss_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && B <= trainer_max_batch(tr), "B=%d outside [1,max_batch=%d]", B, trainer_max_batch(tr));
+  REQUIRE(B >= 2 || !batch_stats, "BatchNorm batch statistics need B >= 2 (got %d)", B);
+  DeviceScope scope(trainer_device(tr));
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice failed: %s", hipGetErrorString(scope.err));
+  HIP_TRY(trainer_step(tr, params_dev, grads_dev, visual_dev, vec_dev, y_dev, dropout_mask_dev, B, batch_stats, loss_dev,
+                       z_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_train_peek(rip_trainer* t, int layer, int what, int B, float* dst_dev, size_t dst_numel, rip_stream_t stream) {
+  REQUIRE(t != nullptr && dst_dev != nullptr, "NULL argument");
+  Trainer* tr = reinterpret_cast<Trainer*>(t);
+  REQUIRE(what >= 0 && what <= 2, "what=%d not in {0 pre-BN, 1 post-activation, 2 gradient}", what);
+  size_t n = 0;
+  float* src = trainer_debug_layer(tr, layer, what, B, &n);
+  REQUIRE(src != nullptr, "layer %d outside the conv stack", layer);
+  REQUIRE(n <= dst_numel, "dst holds %zu floats, %zu needed", dst_numel, n);
+  DeviceScope scope(trainer_device(tr));
+  HIP_TRY(hipMemcpyAsync(dst_dev, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_train_num_layers(const rip_trainer* t) {
+  return t ? trainer_num_layers(reinterpret_cast<const Trainer*>(t)) : RIP_EINVAL;
+}
+
+int rip_train_adam(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev,
+                   const unsigned char* trainable_dev, size_t numel, int step, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, rip_stream_t stream) {
+  REQUIRE(params_dev != nullptr && grads_dev != nullptr && m_dev != nullptr && v_dev != nullptr, "NULL argument");
+  REQUIRE(step >= 1 && lr > 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f,
+          "bad Adam hyper-parameters");
+  HIP_TRY(trainer_adam(params_dev, grads_dev, m_dev, v_dev, trainable_dev, numel, step, lr, beta1, beta2, eps, weight_decay,
+                       (hipStream_t)stream));
   return RIP_OK;
 }
 

@@ -1,0 +1,847 @@
+// DIM training step for gfx950: forward in train mode, backward and Adam of
+//   oatomobile/baselines/torch/dim/train.py:175-213
+//     z = model._params(...)                      dim/model.py:173-219, MobileNetV2 in TRAIN mode: BatchNorm batch
+//                                                 statistics (+ running-stat update), Dropout(0.2) before the classifier
+//     _, log_prob, logabsdet = decoder._inverse   torch/networks/sequence.py:153-216
+//     loss = -mean(log_prob - logabsdet); loss.backward(); Adam(lr).step()
+// on the reference's own parameter layout: ONE fp32 vector in state_dict order (arch.py:packed_spec — conv weight,
+// BN weight, BN bias, running_mean, running_var per conv; classifier; merger; GRUCell; head), with the gradient and the
+// two Adam moments as vectors of the same layout, all owned by the caller (torch tensors: the data-parallel all-reduce
+// of the gradients is one collective on one tensor).
+//
+// fp32 throughout, activations NHWC [B*H*W, C] (what the inference encoder uses), every conv layer keeps its pre-BN
+// output and its post-activation output for the backward pass (11.7 MB per image).  Kernels:
+//   gemm_f32_kernel     all dense contractions (pointwise convs fwd / dgrad / wgrad, classifier, merger, the flow's
+//                       weight gradients): 64x64x16 LDS tiles on v_mfma_f32_16x16x4_f32, split-K with atomics for the
+//                       wgrad reductions over B*H*W
+//   stem / depthwise    direct 3x3 kernels (fwd, dgrad, wgrad)
+//   BatchNorm           per-channel (sum, sum of squares) -> batch mean / biased variance, running-stat update with the
+//                       unbiased variance (momentum 0.1), normalise + ReLU6 (+ residual); backward as the two
+//                       per-channel reductions (sum g, sum g x^) + one elementwise pass
+//   flow_train_kernel   (flow.hip) teacher-forced inverse, its adjoint through all 4 steps into z, and the per-step gate
+//                       gradients whose outer products with the saved inputs are the GRU / head weight gradients (GEMMs)
+//   adam_kernel         torch.optim.Adam defaults, skipping the running statistics
+// This is the first correct path of the row (parity with the reference's step, tests/golden/g15): the kernels are
+// plain, not yet tuned like the inference path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "encoder.h"
+#include "flow.h"
+#include "train.h"
+
+namespace rip {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int FEAT = 128, LAST_C = 1280, VEC = 5, HID = 64;
+constexpr float BN_EPS = 1e-5f, BN_MOMENTUM = 0.1f;
+
+// ------------------------------------------------------------------------------------------------------------
+// GEMM: C[M,N] (ldc) (+)= op(A)[M,K] op(B)[K,N];  TA: A is stored [K,M]; TB: B is stored [N,K].
+// 256 threads, 64x64 tile, K chunks of 16; wave w computes the 32x32 quadrant (w >> 1, w & 1) as 2x2 MFMA tiles.
+// gridDim.z > 1: split-K, partial sums added with atomics (C zeroed by the caller); accumulate: C += (no split).
+// ------------------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                       int kchunk, int accumulate) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kb; k0 < ke; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      {  // A tile: consecutive threads follow the contiguous dimension of the stored matrix
+        const int m = TA ? (e & 63) : (e >> 4), k = TA ? (e >> 6) : (e & 15);
+        const int gm = m0 + m, gk = k0 + k;
+        float v = 0.f;
+        if (gm < M && gk < ke) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+        As[k][m] = v;
+      }
+      {
+        const int n = TB ? (e >> 4) : (e & 63), k = TB ? (e & 15) : (e >> 6);
+        const int gn = n0 + n, gk = k0 + k;
+        float v = 0.f;
+        if (gn < N && gk < ke) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+        Bs[k][n] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = kk * 4 + (lane >> 4);
+      const float a0 = As[k][wm + (lane & 15)], a1 = As[k][wm + 16 + (lane & 15)];
+      const float b0 = Bs[k][wn + (lane & 15)], b1 = Bs[k][wn + 16 + (lane & 15)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // result tile: lane (n = lane & 15, q = lane >> 4), register r <-> row 4 q + r, column n
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm + i * 16 + 4 * (lane >> 4) + r, gn = n0 + wn + j * 16 + (lane & 15);
+        if (gm < M && gn < N) {
+          float* p = C + (size_t)gm * ldc + gn;
+          if (gridDim.z > 1)
+            atomicAdd(p, acc[i][j][r]);
+          else if (accumulate)
+            *p += acc[i][j][r];
+          else
+            *p = acc[i][j][r];
+        }
+      }
+}
+
+hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                int K, int accumulate, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
+  dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
+  int kchunk = K;
+  // reductions over B*H*W with few output tiles: split K so that the chip has work (C must then be pre-zeroed or
+  // hold the value to add to: atomics add into it)
+  const long tiles = (long)grid.x * grid.y;
+  if (K >= 4096 && tiles < 512) {
+    int splits = (int)std::min<long>((512 + tiles - 1) / tiles, (K + 1023) / 1024);
+    if (splits > 1) {
+      kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+      grid.z = (K + kchunk - 1) / kchunk;
+      if (!accumulate) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+        if (e != hipSuccess) return e;
+      }
+    }
+  }
+#define GEMM_LAUNCH(TA_, TB_) \
+  hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate)
+  if (ta && tb)
+    GEMM_LAUNCH(true, true);
+  else if (ta)
+    GEMM_LAUNCH(true, false);
+  else if (tb)
+    GEMM_LAUNCH(false, true);
+  else
+    GEMM_LAUNCH(false, false);
+#undef GEMM_LAUNCH
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// direct convolutions (3x3, pad 1)
+// ------------------------------------------------------------------------------------------------------------
+// stem: in NCHW [B,C,Hin,Hin] -> out NHWC [B,Ho,Ho,Co]; w [Co][C][3][3] (reference layout)
+__global__ void stem_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                int B, int C, int Hin, int Ho, int Co) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * Ho * Ho * Co;
+  if (idx >= total) return;
+  const int oc = idx % Co;
+  const size_t p = idx / Co;
+  const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c)
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= Hin) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= Hin) continue;
+        acc = fmaf(in[(((size_t)b * C + c) * Hin + iy) * Hin + ix], w[((oc * C + c) * 3 + ky) * 3 + kx], acc);
+      }
+    }
+  out[idx] = acc;
+}
+
+// dw[oc][c][ky][kx] = sum_{b,oy,ox} dpre[b,oy,ox,oc] in[b,c,2oy-1+ky,2ox-1+kx]; one block per output channel
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dpre,
+                                                         float* __restrict__ dw, int B, int C, int Hin, int Ho, int Co) {
+  __shared__ float red[256];
+  const int oc = blockIdx.x;
+  const int taps = C * 9;  // <= 144 for C <= 16
+  for (int t0 = 0; t0 < taps; t0 += 6) {
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t npix = (size_t)B * Ho * Ho;
+    for (size_t p = threadIdx.x; p < npix; p += 256) {
+      const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
+      const float g = dpre[p * Co + oc];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int t = t0 + j;
+        if (t >= taps) break;
+        const int c = t / 9, ky = (t % 9) / 3, kx = t % 3;
+        const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin) acc[j] = fmaf(g, in[(((size_t)b * C + c) * Hin + iy) * Hin + ix], acc[j]);
+      }
+    }
+    for (int j = 0; j < 6 && t0 + j < taps; ++j) {
+      red[threadIdx.x] = acc[j];
+      __syncthreads();
+      for (int sft = 128; sft > 0; sft >>= 1) {
+        if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) dw[(size_t)oc * taps + t0 + j] = red[0];
+      __syncthreads();
+    }
+  }
+}
+
+// depthwise: x NHWC [B,Hi,Hi,C] -> out [B,Ho,Ho,C]; w [C][3][3]
+__global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int B,
+                              int C, int Hi, int Ho, int stride) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * Ho * Ho * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const size_t p = idx / C;
+  const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = stride * oy - 1 + ky;
+    if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = stride * ox - 1 + kx;
+      if (ix < 0 || ix >= Hi) continue;
+      acc = fmaf(x[(((size_t)b * Hi + iy) * Hi + ix) * C + c], w[c * 9 + ky * 3 + kx], acc);
+    }
+  }
+  out[idx] = acc;
+}
+
+// dx[b,iy,ix,c] += sum_{ky,kx} dpre[b,oy,ox,c] w[c,ky,kx] with stride*oy - 1 + ky == iy
+__global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ dx,
+                                int B, int C, int Hi, int Ho, int stride) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * Hi * Hi * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const size_t p = idx / C;
+  const int ix = p % Hi, iy = (p / Hi) % Hi, b = p / ((size_t)Hi * Hi);
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride != 0) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride != 0) continue;
+      const int ox = tx / stride;
+      if (ox >= Ho) continue;
+      acc = fmaf(dpre[(((size_t)b * Ho + oy) * Ho + ox) * C + c], w[c * 9 + ky * 3 + kx], acc);
+    }
+  }
+  dx[idx] += acc;
+}
+
+// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c]: blocks own pixel chunks, threads a channel
+// each (channel fastest: coalesced), partial sums to global with atomics (dw zeroed by the caller)
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
+                                                       float* __restrict__ dw, int B, int C, int Hi, int Ho, int stride,
+                                                       int pix_per_block) {
+  const size_t npix = (size_t)B * Ho * Ho;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t p = p0; p < p1; ++p) {
+      const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
+      const float g = dpre[p * C + c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = stride * oy - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = stride * ox - 1 + kx;
+          if (iy >= 0 && iy < Hi && ix >= 0 && ix < Hi)
+            acc[ky * 3 + kx] = fmaf(g, x[(((size_t)b * Hi + iy) * Hi + ix) * C + c], acc[ky * 3 + kx]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(&dw[c * 9 + t], acc[t]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// BatchNorm (train mode), NHWC [M, C]
+// ------------------------------------------------------------------------------------------------------------
+// per-channel reductions over the rows of an NHWC [M, C] tensor (blocks own row chunks, the channel runs fastest over
+// the threads; per-block partial sums, then one float atomic per channel and block):
+//   STAT_SUM      out[c]     += sum x
+//   STAT_CENTRED  out[C + c] += sum (x - mean[c])^2          (second pass of the variance: no E[x^2] - m^2 cancellation,
+//                                                             which costs percents of invstd for channels whose mean is
+//                                                             100 x their spread — the residual branches produce them)
+//   STAT_BWD      out[c] += sum g,  out[C + c] += sum g * xhat,  xhat = (y - mean[c]) * invstd[c]   (x = g, y = pre)
+enum { STAT_SUM = 0, STAT_CENTRED = 1, STAT_BWD = 2 };
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       float* __restrict__ out, size_t M, int C, int rows_per_block) {
+  extern __shared__ float sm[];  // [2*C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  auto accumulate = [&](int c, size_t rbeg, size_t rstep, float& s1, float& s2) {
+    const float mu = MODE != STAT_SUM ? mean[c] : 0.f;
+    const float is = MODE == STAT_BWD ? invstd[c] : 0.f;
+    for (size_t r = rbeg; r < r1; r += rstep) {
+      const float v = x[r * C + c];
+      if (MODE == STAT_SUM) {
+        s1 += v;
+      } else if (MODE == STAT_CENTRED) {
+        const float d = v - mu;
+        s2 = fmaf(d, d, s2);
+      } else {
+        s1 += v;
+        s2 = fmaf(v, (y[r * C + c] - mu) * is, s2);
+      }
+    }
+  };
+  if (C <= 256 && 256 % C == 0) {  // a thread keeps one channel, 256 / C threads share it
+    const int c = threadIdx.x % C;
+    float s1 = 0.f, s2 = 0.f;
+    accumulate(c, r0 + threadIdx.x / C, 256 / C, s1, s2);
+    if (MODE != STAT_CENTRED) atomicAdd(&sm[c], s1);
+    if (MODE != STAT_SUM) atomicAdd(&sm[C + c], s2);
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {  // this thread is the only writer of channel c
+      float s1 = 0.f, s2 = 0.f;
+      accumulate(c, r0, 1, s1, s2);
+      sm[c] += s1;
+      sm[C + c] += s2;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    if ((MODE == STAT_SUM && i >= C) || (MODE == STAT_CENTRED && i < C)) continue;
+    atomicAdd(&out[i], sm[i]);
+  }
+}
+
+// sum -> mean (first pass of the batch statistics)
+__global__ void bn_mean_kernel(const float* __restrict__ sums, float* __restrict__ mean, size_t M, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) mean[c] = (float)((double)sums[c] / (double)M);
+}
+
+// sums -> mean, invstd (saved for the backward pass); running statistics (nn.BatchNorm2d train mode: momentum 0.1,
+// running_var takes the UNBIASED batch variance)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, size_t M, int C,
+                                   int update_running) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = (double)mean[c];                    // bn_mean_kernel
+  const double var = (double)sums[C + c] / (double)M;  // centred second pass: biased batch variance
+  invstd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  if (update_running) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    run_mean[c] = (1.f - BN_MOMENTUM) * run_mean[c] + BN_MOMENTUM * (float)m;
+    run_var[c] = (1.f - BN_MOMENTUM) * run_var[c] + BN_MOMENTUM * (float)unbiased;
+  }
+}
+
+// eval-statistics variant ("frozen" BatchNorm): mean / invstd from the running buffers
+__global__ void bn_from_running_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                       float* __restrict__ mean, float* __restrict__ invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = run_mean[c];
+  invstd[c] = 1.0f / sqrtf(run_var[c] + BN_EPS);
+}
+
+// post = act(gamma * (pre - mean) * invstd + beta) (+ res)
+__global__ void bn_act_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ post,
+                                  size_t total, int C, int relu6) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = idx % C;
+  float v = fmaf((pre[idx] - mean[c]) * invstd[c], gamma[c], beta[c]);
+  if (relu6) v = fminf(fmaxf(v, 0.f), 6.f);
+  if (res != nullptr) v += res[idx];
+  post[idx] = v;
+}
+
+// g = dpost masked by the ReLU6 derivative (in place into gbuf), res_grad += dpost for residual layers
+__global__ void act_bwd_kernel(const float* __restrict__ dpost, const float* __restrict__ post, float* __restrict__ g,
+                               float* __restrict__ dres, size_t total, int relu6) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const float d = dpost[idx];
+  if (dres != nullptr) dres[idx] += d;
+  float v = d;
+  if (relu6) {
+    const float y = post[idx];
+    v = (y > 0.f && y < 6.f) ? d : 0.f;
+  }
+  g[idx] = v;
+}
+
+// sums2 = (sum g, sum g * xhat) per channel = (dbeta, dgamma) and
+// dpre = gamma invstd (g - dbeta/M - xhat dgamma/M)   (batch statistics)   |   gamma invstd g   (running statistics)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ pre,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums2,
+                                    float* __restrict__ dpre, size_t total, int C, size_t M, int batch_stats) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const float is = invstd[c];
+  const float xhat = (pre[idx] - mean[c]) * is;
+  float v = g[idx];
+  if (batch_stats) {
+    v = v - sums2[c] / (float)M - xhat * (sums2[C + c] / (float)M);  // sums2 = (sum g, sum g xhat) = (dbeta, dgamma)
+  }
+  dpre[idx] = gamma[c] * is * v;
+}
+__global__ void bn_param_grads_kernel(const float* __restrict__ sums2, const float* __restrict__ mean,
+                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = sums2[c];
+  dgamma[c] = sums2[C + c];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tail: average pool, dropout, bias / ReLU, concat
+// ------------------------------------------------------------------------------------------------------------
+__global__ void pool_drop_fwd_kernel(const float* __restrict__ post, const float* __restrict__ mask,
+                                     float* __restrict__ pooled, int B, int P, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int c = idx % C, b = idx / C;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += post[((size_t)b * P + p) * C + c];
+  s /= (float)P;
+  pooled[idx] = mask != nullptr ? s * mask[idx] : s;
+}
+__global__ void pool_drop_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ mask,
+                                     float* __restrict__ dpost, int B, int P, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * P * C) return;
+  const int c = idx % C;
+  const int b = idx / ((size_t)P * C);
+  const float d = dpooled[(size_t)b * C + c] * (mask != nullptr ? mask[(size_t)b * C + c] : 1.f);
+  dpost[idx] += d / (float)P;
+}
+// x[r, 0..n) = act(x + bias)
+__global__ void bias_act_kernel(float* __restrict__ x, int ld, const float* __restrict__ bias, int rows, int n, int relu) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * n) return;
+  const int c = idx % n, r = idx / n;
+  float v = x[(size_t)r * ld + c] + bias[c];
+  if (relu) v = fmaxf(v, 0.f);
+  x[(size_t)r * ld + c] = v;
+}
+__global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n && !(y[idx] > 0.f)) d[idx] = 0.f;
+}
+__global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows,
+                                 int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * n) return;
+  const int c = idx % n, r = idx / n;
+  dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
+}
+// out[c] = sum_r x[r, c]
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int rows, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += x[(size_t)r * ld + c];
+  out[c] = s;
+}
+__global__ void mean_loss_kernel(const float* __restrict__ q, float* __restrict__ loss, int B) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += q[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = -red[0] / (float)B;  // dim/train.py:201
+}
+
+// torch.optim.Adam (defaults: betas (0.9, 0.999), eps 1e-8, amsgrad False), L2 weight decay added to the gradient;
+// entries with trainable == 0 (BatchNorm running statistics) are left alone
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, const unsigned char* __restrict__ trainable, size_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (trainable != nullptr && !trainable[i])) return;
+  float grad = g[i];
+  if (weight_decay != 0.f) grad = fmaf(weight_decay, p[i], grad);
+  const float mi = m[i] + (grad - m[i]) * (1.f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = v[i] * beta2 + (1.f - beta2) * grad * grad;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// host side: parameter layout + workspace + the step
+// ------------------------------------------------------------------------------------------------------------
+struct TrainLayer {
+  size_t w, gamma, beta, rmean, rvar;  // offsets into the packed vector
+  size_t wn;
+  size_t act_off;  // offset of this layer's [M, cout] activation in the per-kind activation arenas (floats per image)
+  int block_in;    // layer whose post-activation is this layer's residual input, or -1
+};
+
+struct Trainer {
+  EncoderPlan plan;
+  std::vector<TrainLayer> tl;
+  size_t cls_w, cls_b, mrg_w[3], mrg_b[3];
+  size_t f_wih, f_whh, f_bih, f_bhh, f_w1, f_b1, f_w2, f_b2;
+  size_t numel = 0;
+  size_t act_per_image = 0;  // floats per image over all conv layers
+  int C = 0, max_batch = 0, device = 0;
+  // workspaces
+  float *pre = nullptr, *post = nullptr, *dpost = nullptr;  // [max_batch * act_per_image]
+  float *gbuf = nullptr, *dpre = nullptr;                    // [max_batch * max layer activation]
+  float *stats = nullptr;                                    // per layer: mean, invstd [2 * sum cout]; sums scratch
+  float *sums = nullptr;
+  float* tail = nullptr;  // pooled, feat/merged, h1, h2, z and their gradients
+  float* flowbuf = nullptr;
+  size_t max_act = 0, stats_floats = 0;
+};
+
+static size_t round4(size_t n) { return n; }
+
+size_t train_numel(int in_channels) {
+  const EncoderPlan plan = build_encoder_plan(in_channels);
+  size_t pos = 0;
+  for (const Layer& l : plan.layers) {
+    const size_t per_out = l.kind == L_STEM ? (size_t)l.cin * 9 : (l.kind == L_DW ? 9 : (size_t)l.cin);
+    pos += per_out * l.cout + 4 * (size_t)l.cout;
+  }
+  pos += (size_t)FEAT * LAST_C + FEAT;
+  const int sizes[4] = {FEAT + VEC, HID, HID, HID};
+  for (int i = 0; i < 3; ++i) pos += (size_t)sizes[i + 1] * sizes[i] + sizes[i + 1];
+  pos += 192 * 2 + 192 * 64 + 192 + 192 + 32 * 64 + 32 + 4 * 32 + 4;
+  return round4(pos);
+}
+
+hipError_t trainer_create(Trainer** out, int in_channels, int max_batch, int device) {
+  Trainer* t = new Trainer();
+  t->plan = build_encoder_plan(in_channels);
+  t->C = in_channels;
+  t->max_batch = max_batch;
+  t->device = device;
+  size_t pos = 0, act = 0, chans = 0;
+  const int nl = (int)t->plan.layers.size();
+  t->tl.resize(nl);
+  for (int i = 0; i < nl; ++i) {
+    const Layer& l = t->plan.layers[i];
+    TrainLayer& q = t->tl[i];
+    const size_t per_out = l.kind == L_STEM ? (size_t)l.cin * 9 : (l.kind == L_DW ? 9 : (size_t)l.cin);
+    q.wn = per_out * l.cout;
+    q.w = pos;
+    q.gamma = q.w + q.wn;
+    q.beta = q.gamma + l.cout;
+    q.rmean = q.beta + l.cout;
+    q.rvar = q.rmean + l.cout;
+    pos = q.rvar + l.cout;
+    q.act_off = act;
+    const size_t a = (size_t)l.h_out * l.h_out * l.cout;
+    act += a;
+    if (a > t->max_act) t->max_act = a;
+    chans += l.cout;
+    q.block_in = -1;
+  }
+  for (const FusedBlock& fb : t->plan.blocks) {
+    const Layer& lp = t->plan.layers[fb.project];
+    if (lp.residual) t->tl[fb.project].block_in = (fb.expand >= 0 ? fb.expand : fb.dw) - 1;
+  }
+  t->act_per_image = act;
+  t->cls_w = pos;
+  pos += (size_t)FEAT * LAST_C;
+  t->cls_b = pos;
+  pos += FEAT;
+  const int sizes[4] = {FEAT + VEC, HID, HID, HID};
+  for (int i = 0; i < 3; ++i) {
+    t->mrg_w[i] = pos;
+    pos += (size_t)sizes[i + 1] * sizes[i];
+    t->mrg_b[i] = pos;
+    pos += sizes[i + 1];
+  }
+  t->f_wih = pos;
+  pos += 192 * 2;
+  t->f_whh = pos;
+  pos += 192 * 64;
+  t->f_bih = pos;
+  pos += 192;
+  t->f_bhh = pos;
+  pos += 192;
+  t->f_w1 = pos;
+  pos += 32 * 64;
+  t->f_b1 = pos;
+  pos += 32;
+  t->f_w2 = pos;
+  pos += 4 * 32;
+  t->f_b2 = pos;
+  pos += 4;
+  t->numel = pos;
+  t->stats_floats = 2 * chans;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](float** p, size_t n) {
+    if (e == hipSuccess) e = hipMalloc((void**)p, n * sizeof(float));
+  };
+  const size_t B = (size_t)max_batch;
+  alloc(&t->pre, B * act);
+  alloc(&t->post, B * act);
+  alloc(&t->dpost, B * act);
+  alloc(&t->gbuf, B * t->max_act);
+  alloc(&t->dpre, B * t->max_act);
+  alloc(&t->stats, t->stats_floats);
+  alloc(&t->sums, 2 * 1280 * 2);
+  alloc(&t->tail, B * (size_t)TRAIN_TAIL_FLOATS);
+  alloc(&t->flowbuf, B * (size_t)FLOW_TRAIN_ROW_FLOATS + FW_SIZE);
+  if (e != hipSuccess) {
+    trainer_destroy(t);
+    return e;
+  }
+  *out = t;
+  return hipSuccess;
+}
+
+void trainer_destroy(Trainer* t) {
+  if (t == nullptr) return;
+  float* ptrs[] = {t->pre, t->post, t->dpost, t->gbuf, t->dpre, t->stats, t->sums, t->tail, t->flowbuf};
+  for (float* p : ptrs)
+    if (p != nullptr) (void)hipFree(p);
+  delete t;
+}
+
+size_t trainer_numel(const Trainer* t) { return t->numel; }
+int trainer_max_batch(const Trainer* t) { return t->max_batch; }
+int trainer_device(const Trainer* t) { return t->device; }
+
+// marks the trainable entries of the packed vector (everything but the BatchNorm running statistics)
+void trainer_trainable_mask(const Trainer* t, unsigned char* mask) {
+  for (size_t i = 0; i < t->numel; ++i) mask[i] = 1;
+  for (size_t i = 0; i < t->tl.size(); ++i) {
+    const int c = t->plan.layers[i].cout;
+    for (int j = 0; j < 2 * c; ++j) mask[t->tl[i].rmean + j] = 0;
+  }
+}
+
+#define TRY(expr)                   \
+  do {                              \
+    hipError_t e_ = (expr);         \
+    if (e_ != hipSuccess) return e_; \
+  } while (0)
+
+hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* visual, const float* vec, const float* y,
+                        const float* dropout_mask, int B, int batch_stats, float* loss, float* z_out, hipStream_t s) {
+  const int nl = (int)t->plan.layers.size();
+  const size_t Bz = (size_t)B;
+  // activation arenas are laid out layer-major: layer i occupies [B * act_off_i, B * act_off_i + B * a_i)
+  auto A = [&](float* base, int i) { return base + Bz * t->tl[i].act_off; };
+  TRY(hipMemsetAsync(grads, 0, t->numel * sizeof(float), s));
+  TRY(hipMemsetAsync(t->dpost, 0, Bz * t->act_per_image * sizeof(float), s));
+  // ================================== forward ==================================
+  size_t st_off = 0;
+  std::vector<size_t> stat_off(nl);
+  for (int i = 0; i < nl; ++i) {
+    const Layer& l = t->plan.layers[i];
+    const TrainLayer& q = t->tl[i];
+    const size_t M = Bz * l.h_out * l.h_out;
+    const size_t total = M * l.cout;
+    float* pre = A(t->pre, i);
+    float* post = A(t->post, i);
+    const float* x = i == 0 ? visual : A(t->post, i - 1);
+    if (l.kind == L_STEM) {
+      hipLaunchKernelGGL(stem_fwd_kernel, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in, l.h_out,
+                         l.cout);
+    } else if (l.kind == L_DW) {
+      hipLaunchKernelGGL(dw_fwd_kernel, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cout, l.h_in, l.h_out,
+                         l.stride);
+    } else {
+      TRY(gemm(false, true, x, l.cin, params + q.w, l.cin, pre, l.cout, (int)M, l.cout, l.cin, 0, s));
+    }
+    float* mean = t->stats + st_off;
+    float* invstd = mean + l.cout;
+    stat_off[i] = st_off;
+    st_off += 2 * (size_t)l.cout;
+    if (batch_stats) {
+      TRY(hipMemsetAsync(t->sums, 0, 2 * (size_t)l.cout * sizeof(float), s));
+      const int rows_per_block = 256;
+      hipLaunchKernelGGL(colstats_kernel<STAT_SUM>, dim3(nblk(M, rows_per_block)), dim3(256), 2 * l.cout * sizeof(float), s,
+                         pre, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, t->sums, M, l.cout,
+                         rows_per_block);
+      hipLaunchKernelGGL(bn_mean_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, M, l.cout);
+      hipLaunchKernelGGL(colstats_kernel<STAT_CENTRED>, dim3(nblk(M, rows_per_block)), dim3(256), 2 * l.cout * sizeof(float),
+                         s, pre, (const float*)nullptr, mean, (const float*)nullptr, t->sums, M, l.cout, rows_per_block);
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, invstd, params + q.rmean,
+                         params + q.rvar, M, l.cout, 1);
+    } else {
+      hipLaunchKernelGGL(bn_from_running_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, params + q.rmean, params + q.rvar, mean,
+                         invstd, l.cout);
+    }
+    const float* res = q.block_in >= 0 ? A(t->post, q.block_in) : nullptr;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(nblk(total)), dim3(256), 0, s, pre, mean, invstd, params + q.gamma,
+                       params + q.beta, res, post, total, l.cout, l.relu6);
+  }
+  // ---- tail: pool + dropout -> classifier -> cat(vec) -> merger (3 x Linear + ReLU) -> z ----
+  const Layer& ll = t->plan.layers[nl - 1];
+  const int P = ll.h_out * ll.h_out;
+  float* pooled = t->tail;                          // [B,1280]
+  float* merged = pooled + Bz * LAST_C;             // [B,133]: feat | vec
+  float* h1 = merged + Bz * (FEAT + VEC);           // [B,64]
+  float* h2 = h1 + Bz * HID;
+  float* zz = h2 + Bz * HID;
+  float* dz = zz + Bz * HID;
+  float* dh2 = dz + Bz * HID;
+  float* dh1 = dh2 + Bz * HID;
+  float* dmerged = dh1 + Bz * HID;                  // [B,133]
+  float* dpooled = dmerged + Bz * (FEAT + VEC);     // [B,1280]
+  float* qrow = dpooled + Bz * LAST_C;              // [B]
+  hipLaunchKernelGGL(pool_drop_fwd_kernel, dim3(nblk(Bz * LAST_C)), dim3(256), 0, s, A(t->post, nl - 1), dropout_mask, pooled,
+                     B, P, LAST_C);
+  TRY(gemm(false, true, pooled, LAST_C, params + t->cls_w, LAST_C, merged, FEAT + VEC, B, FEAT, LAST_C, 0, s));
+  hipLaunchKernelGGL(bias_act_kernel, dim3(nblk(Bz * FEAT)), dim3(256), 0, s, merged, FEAT + VEC, params + t->cls_b, B, FEAT, 0);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk(Bz * VEC)), dim3(256), 0, s, vec, VEC, merged + FEAT, FEAT + VEC, B, VEC);
+  TRY(gemm(false, true, merged, FEAT + VEC, params + t->mrg_w[0], FEAT + VEC, h1, HID, B, HID, FEAT + VEC, 0, s));
+  hipLaunchKernelGGL(bias_act_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, h1, HID, params + t->mrg_b[0], B, HID, 1);
+  TRY(gemm(false, true, h1, HID, params + t->mrg_w[1], HID, h2, HID, B, HID, HID, 0, s));
+  hipLaunchKernelGGL(bias_act_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, h2, HID, params + t->mrg_b[1], B, HID, 1);
+  TRY(gemm(false, true, h2, HID, params + t->mrg_w[2], HID, zz, HID, B, HID, HID, 0, s));
+  hipLaunchKernelGGL(bias_act_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, zz, HID, params + t->mrg_b[2], B, HID, 1);
+  if (z_out != nullptr) TRY(hipMemcpyAsync(z_out, zz, Bz * HID * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // ---- flow: teacher-forced inverse + adjoint (cotangent -1/B per row), per-step records for the weight gradients ----
+  TRY(launch_flow_train(params + t->f_wih, params + t->f_whh, params + t->f_bih, params + t->f_bhh, params + t->f_w1,
+                        params + t->f_b1, params + t->f_w2, params + t->f_b2, zz, y, B, qrow, dz, t->flowbuf, s));
+  hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(256), 0, s, qrow, loss, B);
+  {
+    const int R = B * 4;
+    const float* fb = t->flowbuf;  // [R][FLOW_TRAIN_REC]
+    const int ld = FLOW_TRAIN_REC;
+    // record columns: dgi 192 | dgh 192 | hprev 64 | u 2 | da1 32 | h 64 | do 4 | relu(a1) 32
+    const float *dgi = fb, *dgh = fb + 192, *hprev = fb + 384, *u = fb + 448, *da1 = fb + 450, *hh = fb + 482,
+                *dout = fb + 546, *ra1 = fb + 550;
+    TRY(gemm(true, false, dgi, ld, u, ld, grads + t->f_wih, 2, 192, 2, R, 0, s));
+    TRY(gemm(true, false, dgh, ld, hprev, ld, grads + t->f_whh, 64, 192, 64, R, 0, s));
+    TRY(gemm(true, false, da1, ld, hh, ld, grads + t->f_w1, 64, 32, 64, R, 0, s));
+    TRY(gemm(true, false, dout, ld, ra1, ld, grads + t->f_w2, 32, 4, 32, R, 0, s));
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dgi, ld, grads + t->f_bih, R, 192);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dgh, ld, grads + t->f_bhh, R, 192);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, da1, ld, grads + t->f_b1, R, 32);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dout, ld, grads + t->f_b2, R, 4);
+  }
+  // ================================== backward ==================================
+  // ---- merger / classifier ----
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dz, zz, B * HID);
+  TRY(gemm(true, false, dz, HID, h2, HID, grads + t->mrg_w[2], HID, HID, HID, B, 0, s));
+  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dz, HID, grads + t->mrg_b[2], B, HID);
+  TRY(gemm(false, false, dz, HID, params + t->mrg_w[2], HID, dh2, HID, B, HID, HID, 0, s));
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dh2, h2, B * HID);
+  TRY(gemm(true, false, dh2, HID, h1, HID, grads + t->mrg_w[1], HID, HID, HID, B, 0, s));
+  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dh2, HID, grads + t->mrg_b[1], B, HID);
+  TRY(gemm(false, false, dh2, HID, params + t->mrg_w[1], HID, dh1, HID, B, HID, HID, 0, s));
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dh1, h1, B * HID);
+  TRY(gemm(true, false, dh1, HID, merged, FEAT + VEC, grads + t->mrg_w[0], FEAT + VEC, HID, FEAT + VEC, B, 0, s));
+  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dh1, HID, grads + t->mrg_b[0], B, HID);
+  TRY(gemm(false, false, dh1, HID, params + t->mrg_w[0], FEAT + VEC, dmerged, FEAT + VEC, B, FEAT + VEC, HID, 0, s));
+  TRY(gemm(true, false, dmerged, FEAT + VEC, pooled, LAST_C, grads + t->cls_w, LAST_C, FEAT, LAST_C, B, 0, s));
+  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dmerged, FEAT + VEC, grads + t->cls_b, B, FEAT);
+  TRY(gemm(false, false, dmerged, FEAT + VEC, params + t->cls_w, LAST_C, dpooled, LAST_C, B, LAST_C, FEAT, 0, s));
+  hipLaunchKernelGGL(pool_drop_bwd_kernel, dim3(nblk(Bz * P * LAST_C)), dim3(256), 0, s, dpooled, dropout_mask,
+                     A(t->dpost, nl - 1), B, P, LAST_C);
+  // ---- conv stack, last layer first ----
+  for (int i = nl - 1; i >= 0; --i) {
+    const Layer& l = t->plan.layers[i];
+    const TrainLayer& q = t->tl[i];
+    const size_t M = Bz * l.h_out * l.h_out;
+    const size_t total = M * l.cout;
+    const float* mean = t->stats + stat_off[i];
+    const float* invstd = mean + l.cout;
+    float* dres = q.block_in >= 0 ? A(t->dpost, q.block_in) : nullptr;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, A(t->dpost, i), A(t->post, i), t->gbuf, dres, total,
+                       l.relu6);
+    // NOTE: for residual layers `post` holds bn + res; they carry no ReLU6, so the mask is not needed there
+    TRY(hipMemsetAsync(t->sums, 0, 2 * (size_t)l.cout * sizeof(float), s));
+    hipLaunchKernelGGL(colstats_kernel<STAT_BWD>, dim3(nblk(M, 256)), dim3(256), 2 * l.cout * sizeof(float), s, t->gbuf,
+                       A(t->pre, i), mean, invstd, t->sums, M, l.cout, 256);
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, invstd, grads + q.gamma,
+                       grads + q.beta, l.cout);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(total)), dim3(256), 0, s, t->gbuf, A(t->pre, i), mean, invstd,
+                       params + q.gamma, t->sums, t->dpre, total, l.cout, M, batch_stats);
+    const float* x = i == 0 ? visual : A(t->post, i - 1);
+    if (l.kind == L_STEM) {
+      hipLaunchKernelGGL(stem_wgrad_kernel, dim3(l.cout), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cin, l.h_in, l.h_out,
+                         l.cout);
+    } else if (l.kind == L_DW) {
+      const int ppb = 128;
+      hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nblk(M, ppb)), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in,
+                         l.h_out, l.stride, ppb);
+      const size_t tin = Bz * l.h_in * l.h_in * l.cout;
+      hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nblk(tin)), dim3(256), 0, s, t->dpre, params + q.w, A(t->dpost, i - 1), B, l.cout,
+                         l.h_in, l.h_out, l.stride);
+    } else {
+      TRY(gemm(true, false, t->dpre, l.cout, x, l.cin, grads + q.w, l.cin, l.cout, l.cin, (int)M, 0, s));
+      TRY(gemm(false, false, t->dpre, l.cout, params + q.w, l.cin, A(t->dpost, i - 1), l.cin, (int)M, l.cin, l.cout, 1, s));
+    }
+  }
+  return hipGetLastError();
+}
+
+int trainer_num_layers(const Trainer* t) { return (int)t->plan.layers.size(); }
+
+// device pointer of conv layer `i`'s saved NHWC activation of the last step (what: 0 pre-BN, 1 post-activation, 2 its
+// gradient) and its element count for batch B (rip_train_peek)
+float* trainer_debug_layer(Trainer* t, int i, int what, int B, size_t* numel) {
+  if (i < 0 || i >= (int)t->plan.layers.size()) return nullptr;
+  const Layer& l = t->plan.layers[i];
+  *numel = (size_t)B * l.h_out * l.h_out * l.cout;
+  float* base = what == 0 ? t->pre : (what == 1 ? t->post : t->dpost);
+  return base + (size_t)B * t->tl[i].act_off;
+}
+
+hipError_t trainer_adam(float* params, const float* grads, float* m, float* v, const unsigned char* trainable, size_t n,
+                        int step, float lr, float beta1, float beta2, float eps, float weight_decay, hipStream_t s) {
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, s, params, grads, m, v, trainable, n, lr, beta1, beta2, eps,
+                     weight_decay, (float)bc1, (float)std::sqrt(bc2));
+  return hipGetLastError();
+}
+
+}  // namespace rip
