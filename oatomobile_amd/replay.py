@@ -92,7 +92,12 @@ def goal_from_future(player_future: np.ndarray, num_goals: int = 10, stride: int
 
 def replay(agent, files: Sequence[str], batch_size: int, num_goals: int = 10, goal_stride: int = 8) -> np.ndarray:
   """Plans for every datum in `files` -> [len(files), 4, 2] (host).  `agent` is a `RIPAgent` built with
-  `max_batch >= batch_size`.  Decode (np.load) runs on the host; upload is one pinned copy per batch."""
+  `max_batch >= batch_size`.  Decode (np.load) runs on the host; upload is one pinned copy per batch.
+
+  The decode is what bounds this loop (measured: 1.4 k observations/s for compressed 200x200x2 datums against
+  70 k/s of act() on the device): ~0.7 ms of zipfile + zlib + dtype conversion per frame, mostly under the GIL — a
+  16-thread pool was SLOWER (0.8 k/s).  The reference spreads it over 50 DataLoader worker processes
+  (dim/train.py:150-155); sharding `files` over ranks / processes (`distributed.shard_range`) is the same lever here."""
   dev = agent._device
   out = np.empty((len(files), 4, 2), np.float32)
   C = agent._in_channels

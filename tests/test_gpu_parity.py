@@ -1043,3 +1043,70 @@ def test_train_step_hand_back_to_inference(dev):
   tr.sync_to_model()
   z_inf = m._params(**ctx).cpu().numpy()
   np.testing.assert_allclose(z_inf, zo.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_config4_k8_n512_on_the_mfma_kernel(dev):
+  """BASELINE configs[3] on ONE GPU: K = 8 models, N = 512 candidates through the phase-sequential MFMA kernel (the
+  wave-per-model pipeline stops at K = 4): candidates vs the oracle, scoring mode vs the search's own posteriors."""
+  from oatomobile_amd import RIPAgent
+  from oracle import reference_cpu as O
+  K, N, B = 8, 512, 4
+  models = [hip_model(500 + k, dev) for k in range(K)]
+  refs = [oracle_model(500 + k) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=3, search_kernel="phase")
+  obs = [synth_observation(np.random.default_rng(120 + i)) for i in range(B)]
+  lidar = torch.stack([torch.from_numpy(o["lidar"]) for o in obs]).to(dev)
+  vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
+  goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
+  plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
+  assert torch.isfinite(plan).all() and float(loss.max()) < 1000.0
+  for b in (0, 3):
+    ob = obs[b]
+    _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"], ob["goal"],
+                        x0=agent._x0_rows.cpu()[:96], algorithm="WCM")
+    lo, lh = res["loss_best"].numpy(), loss.cpu().numpy()[b, :96]
+    assert (np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.97
+  # the same launch through the wave-per-chain kernel (any K): per-candidate best losses agree
+  chain = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=3, search_kernel="chain")
+  plan_c, loss_c = chain.plan_batch(lidar, vec, goal, return_loss=True)
+  close = np.abs(loss.cpu().numpy() - loss_c.cpu().numpy()) <= 1e-3 + 1e-4 * np.abs(loss_c.cpu().numpy())
+  assert close.mean() >= 0.97
+
+
+def test_replay_512_cached_observations(dev, tmp_path):
+  """BASELINE configs[4] at a size that still runs in seconds: 512 cached `.npz` datums (the reference's on-disk
+  schema, datasets/carla.py:107-164) replayed in batches of 256 through the bench configuration (K = 4, N = 128, MFMA
+  search), sampled observations against the oracle, batch-order independence, and the decode-inclusive rate."""
+  import time
+  from oatomobile_amd import RIPAgent, replay
+  from oracle import reference_cpu as O
+  K, N, F = 4, 128, 512
+  models = [hip_model(100 + k, dev) for k in range(K)]
+  refs = [oracle_model(100 + k) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=256, seed=0)
+  ep = replay.Episode(str(tmp_path), "ep")
+  rng = np.random.default_rng(44)
+  futures = []
+  for i in range(F):
+    o = synth_observation(np.random.default_rng(4400 + i))
+    fut = np.cumsum(np.abs(rng.normal(size=(80, 3))) * 0.4, axis=0).astype(np.float32)
+    ep.append(lidar=o["lidar"], velocity=o["velocity"], is_at_traffic_light=o["is_at_traffic_light"],
+              traffic_light_state=o["traffic_light_state"], player_future=fut)
+    futures.append((o, fut))
+  files = ep.files()
+  t0 = time.perf_counter()
+  plans = replay.replay(agent, files, batch_size=256)
+  dt = time.perf_counter() - t0
+  print("replay of %d cached datums: %.0f observations/s including np.load decode (batch 256)" % (F, F / dt))
+  assert plans.shape == (F, 4, 2) and np.isfinite(plans).all()
+  for i in (0, 255, 256, 511):
+    o, fut = futures[i]
+    goal = np.c_[replay.goal_from_future(fut), np.zeros((10, 1), np.float32)]
+    _, res = O.rip_call(refs, o["lidar"], o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"], goal,
+                        x0=agent._x0_rows.cpu(), algorithm="WCM")
+    srt = np.sort(res["loss_best"].numpy())
+    if srt[1] - srt[0] > 1e-3:
+      np.testing.assert_allclose(plans[i], res["plan"].numpy(), atol=5e-4)
+  # another batching of the same files gives the same plans (observations are independent)
+  plans2 = replay.replay(agent, files[::-1], batch_size=128)[::-1]
+  np.testing.assert_allclose(plans2, plans, atol=1e-5)
