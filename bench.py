@@ -307,7 +307,7 @@ def main():
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
 
   # ---------------- secondary lines (rank 0, N = 1 only; untimed by the driver's contract) ----------------
-  online = pcie = scoring = fp32_line = c4_line = None
+  online = pcie = scoring = fp32_line = c4_line = train_line = None
   if rank == 0 and world == 1 and not args.no_extras:
     online = _bench_online(args, models, dev, host_batches[0])
     pcie = _bench_pcie(args, encode_search, host_batches, dev, B, C, G, timed)
@@ -322,6 +322,7 @@ def main():
                            "plan-level effect)"}
     if C == 2:
       c4_line = _bench_c4(args, dev, timed, seeds)
+    train_line = _bench_train(args, dev, timed)
 
   if rank == 0:
     flow_flops = 2.0 * 3.0 * (1 + K) * 4 * FLOW_MAC_PER_STEP * N * S * B  # SURVEY §8(d) flops_flow(grad)
@@ -388,6 +389,7 @@ def main():
         "scoring_only": scoring,
         "fp32_parity": fp32_line,
         "bev_c4": c4_line,
+        "train_step": train_line,
     }
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(args)
@@ -506,6 +508,31 @@ def _bench_c4(args, dev, timed, seeds):
 
   el = timed(step, 5, 2)
   return {"calls_per_s": B * 5 / el, "ms_per_step": 1e3 * el / 5, "obs_per_step": B, "bev_channels": 4}
+
+
+def _bench_train(args, dev, timed):
+  """the DIM training step (dim/train.py:175-213: train-mode forward, backward, Adam) on one model,
+  fp32, batch 128 — the first correct path of that row, reported so that its cost is on record."""
+  from oatomobile_amd import DIMTrainer, ImitativeModel, transform_visual
+  B = 128
+  model = ImitativeModel.synthetic(7, in_channels=args.channels, max_batch=1).to(dev)
+  tr = DIMTrainer(model, lr=1e-3, max_batch=B, device=dev)
+  lidar, vec, goal = synth_batch(np.random.default_rng(77), B, args.channels)
+  batch = dict(visual_features=transform_visual(torch.from_numpy(lidar).to(dev), channels_last=True),
+               velocity=torch.from_numpy(vec[:, :3].copy()).to(dev), is_at_traffic_light=torch.from_numpy(vec[:, 3:4].copy()).to(dev),
+               traffic_light_state=torch.from_numpy(vec[:, 4:5].copy()).to(dev),
+               player_future=torch.from_numpy(np.cumsum(np.abs(np.random.default_rng(78).normal(size=(B, 4, 2))), axis=1).astype(np.float32)).to(dev))
+  losses = []
+
+  def step(i, ev):
+    losses.append(tr.train_step(batch))
+
+  el = timed(step, 6, 2)
+  l = [float(x) for x in losses]
+  tr.close()
+  return {"observations_per_s": B * 6 / el, "ms_per_step": 1e3 * el / 6, "batch": B, "loss_first_last": [l[0], l[-1]],
+          "note": "one ImitativeModel, fp32, BatchNorm batch statistics + dropout, loss.backward, Adam(1e-3); same batch "
+                  "every step (the loss falls)"}
 
 
 def _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all):

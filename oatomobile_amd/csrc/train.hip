@@ -25,6 +25,7 @@
 // plain, not yet tuned like the inference path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -172,38 +173,51 @@ __global__ void stem_fwd_kernel(const float* __restrict__ in, const float* __res
   out[idx] = acc;
 }
 
-// dw[oc][c][ky][kx] = sum_{b,oy,ox} dpre[b,oy,ox,oc] in[b,c,2oy-1+ky,2ox-1+kx]; one block per output channel
+// dw[oc][c][ky][kx] = sum_{b,oy,ox} dpre[b,oy,ox,oc] in[b,c,2oy-1+ky,2ox-1+kx].  Blocks own chunks of output pixels;
+// thread (oc = t % Co, sub = t / Co) walks every (256 / Co)-th pixel of the chunk with its C*9 partial sums in
+// registers (the input taps of a pixel are the same for all oc: broadcast loads), then LDS and one global atomic per
+// (block, output).  C <= 4 (TAPS registers); dw zeroed by the caller.
+template <int CMAX>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dpre,
-                                                         float* __restrict__ dw, int B, int C, int Hin, int Ho, int Co) {
-  __shared__ float red[256];
-  const int oc = blockIdx.x;
-  const int taps = C * 9;  // <= 144 for C <= 16
-  for (int t0 = 0; t0 < taps; t0 += 6) {
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const size_t npix = (size_t)B * Ho * Ho;
-    for (size_t p = threadIdx.x; p < npix; p += 256) {
+                                                         float* __restrict__ dw, int B, int C, int Hin, int Ho, int Co,
+                                                         int pix_per_block) {
+  __shared__ float sm[64 * CMAX * 9];
+  const int taps = C * 9;
+  for (int i = threadIdx.x; i < Co * taps; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const size_t npix = (size_t)B * Ho * Ho;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+  const int groups = 256 / Co;
+  const int oc = threadIdx.x % Co, sub = threadIdx.x / Co;
+  if (sub < groups) {
+    float acc[CMAX * 9];
+#pragma unroll
+    for (int t = 0; t < CMAX * 9; ++t) acc[t] = 0.f;
+    for (size_t p = p0 + sub; p < p1; p += groups) {
       const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
       const float g = dpre[p * Co + oc];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int t = t0 + j;
-        if (t >= taps) break;
-        const int c = t / 9, ky = (t % 9) / 3, kx = t % 3;
-        const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin) acc[j] = fmaf(g, in[(((size_t)b * C + c) * Hin + iy) * Hin + ix], acc[j]);
+      for (int c = 0; c < CMAX; ++c) {
+        if (c >= C) break;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin)
+              acc[c * 9 + ky * 3 + kx] = fmaf(g, in[(((size_t)b * C + c) * Hin + iy) * Hin + ix], acc[c * 9 + ky * 3 + kx]);
+          }
+        }
       }
     }
-    for (int j = 0; j < 6 && t0 + j < taps; ++j) {
-      red[threadIdx.x] = acc[j];
-      __syncthreads();
-      for (int sft = 128; sft > 0; sft >>= 1) {
-        if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) dw[(size_t)oc * taps + t0 + j] = red[0];
-      __syncthreads();
-    }
+#pragma unroll
+    for (int t = 0; t < CMAX * 9; ++t)
+      if (t < taps) atomicAdd(&sm[oc * taps + t], acc[t]);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Co * taps; i += 256) atomicAdd(&dw[i], sm[i]);
 }
 
 // depthwise: x NHWC [B,Hi,Hi,C] -> out [B,Ho,Ho,C]; w [C][3][3]
@@ -258,33 +272,44 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __r
   dx[idx] += acc;
 }
 
-// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c]: blocks own pixel chunks, threads a channel
-// each (channel fastest: coalesced), partial sums to global with atomics (dw zeroed by the caller)
+// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c]: blocks own pixel chunks; thread
+// (c = t % Cb, sub = t / Cb) with Cb = min(C, 256) channels per sweep walks every (256 / Cb)-th pixel (channel fastest:
+// coalesced); partial sums meet in LDS, then one global atomic per (block, channel, tap) (dw zeroed by the caller)
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
                                                        float* __restrict__ dw, int B, int C, int Hi, int Ho, int stride,
                                                        int pix_per_block) {
+  extern __shared__ float sm[];  // [C * 9]
+  for (int i = threadIdx.x; i < C * 9; i += 256) sm[i] = 0.f;
+  __syncthreads();
   const size_t npix = (size_t)B * Ho * Ho;
   const size_t p0 = (size_t)blockIdx.x * pix_per_block;
   const size_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (size_t p = p0; p < p1; ++p) {
-      const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
-      const float g = dpre[p * C + c];
+  const int Cb = C < 256 ? C : 256;
+  const int groups = 256 / Cb;
+  const int sub = threadIdx.x / Cb;
+  if (sub < groups) {
+    for (int c = threadIdx.x % Cb; c < C; c += Cb) {
+      float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (size_t p = p0 + sub; p < p1; p += groups) {
+        const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
+        const float g = dpre[p * C + c];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = stride * oy - 1 + ky;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = stride * oy - 1 + ky;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = stride * ox - 1 + kx;
-          if (iy >= 0 && iy < Hi && ix >= 0 && ix < Hi)
-            acc[ky * 3 + kx] = fmaf(g, x[(((size_t)b * Hi + iy) * Hi + ix) * C + c], acc[ky * 3 + kx]);
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = stride * ox - 1 + kx;
+            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Hi)
+              acc[ky * 3 + kx] = fmaf(g, x[(((size_t)b * Hi + iy) * Hi + ix) * C + c], acc[ky * 3 + kx]);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) atomicAdd(&dw[c * 9 + t], acc[t]);
+      for (int t = 0; t < 9; ++t) atomicAdd(&sm[c * 9 + t], acc[t]);
+    }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(&dw[i], sm[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -292,12 +317,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------------
 // per-channel reductions over the rows of an NHWC [M, C] tensor (blocks own row chunks, the channel runs fastest over
 // the threads; per-block partial sums, then one float atomic per channel and block):
-//   STAT_SUM      out[c]     += sum x
-//   STAT_CENTRED  out[C + c] += sum (x - mean[c])^2          (second pass of the variance: no E[x^2] - m^2 cancellation,
-//                                                             which costs percents of invstd for channels whose mean is
-//                                                             100 x their spread — the residual branches produce them)
+//   STAT_SHIFTED  out[c] += sum (x - k[c]),  out[C + c] += sum (x - k[c])^2  with the shift k[c] = x[0][c] (`mean` arg):
+//                 mean = k + S1/M, var = S2/M - (S1/M)^2 in double.  One pass, and no E[x^2] - m^2 cancellation: the
+//                 shift is a sample of the channel, so |S1/M| is of the order of its spread even when the channel's mean
+//                 is 100 x that (the residual branches produce such channels)
 //   STAT_BWD      out[c] += sum g,  out[C + c] += sum g * xhat,  xhat = (y - mean[c]) * invstd[c]   (x = g, y = pre)
-enum { STAT_SUM = 0, STAT_CENTRED = 1, STAT_BWD = 2 };
+enum { STAT_SHIFTED = 0, STAT_BWD = 2 };
 template <int MODE>
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -308,14 +333,13 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   auto accumulate = [&](int c, size_t rbeg, size_t rstep, float& s1, float& s2) {
-    const float mu = MODE != STAT_SUM ? mean[c] : 0.f;
+    const float mu = mean[c];  // STAT_SHIFTED: the shift k[c]
     const float is = MODE == STAT_BWD ? invstd[c] : 0.f;
     for (size_t r = rbeg; r < r1; r += rstep) {
       const float v = x[r * C + c];
-      if (MODE == STAT_SUM) {
-        s1 += v;
-      } else if (MODE == STAT_CENTRED) {
+      if (MODE == STAT_SHIFTED) {
         const float d = v - mu;
+        s1 += d;
         s2 = fmaf(d, d, s2);
       } else {
         s1 += v;
@@ -327,8 +351,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     const int c = threadIdx.x % C;
     float s1 = 0.f, s2 = 0.f;
     accumulate(c, r0 + threadIdx.x / C, 256 / C, s1, s2);
-    if (MODE != STAT_CENTRED) atomicAdd(&sm[c], s1);
-    if (MODE != STAT_SUM) atomicAdd(&sm[C + c], s2);
+    atomicAdd(&sm[c], s1);
+    atomicAdd(&sm[C + c], s2);
   } else {
     for (int c = threadIdx.x; c < C; c += 256) {  // this thread is the only writer of channel c
       float s1 = 0.f, s2 = 0.f;
@@ -338,27 +362,21 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    if ((MODE == STAT_SUM && i >= C) || (MODE == STAT_CENTRED && i < C)) continue;
-    atomicAdd(&out[i], sm[i]);
-  }
-}
-
-// sum -> mean (first pass of the batch statistics)
-__global__ void bn_mean_kernel(const float* __restrict__ sums, float* __restrict__ mean, size_t M, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) mean[c] = (float)((double)sums[c] / (double)M);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&out[i], sm[i]);
 }
 
 // sums -> mean, invstd (saved for the backward pass); running statistics (nn.BatchNorm2d train mode: momentum 0.1,
 // running_var takes the UNBIASED batch variance)
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, size_t M, int C,
-                                   int update_running) {
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ shift,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, size_t M, int C, int update_running) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double m = (double)mean[c];                    // bn_mean_kernel
-  const double var = (double)sums[C + c] / (double)M;  // centred second pass: biased batch variance
+  const double d1 = (double)sums[c] / (double)M;
+  const double m = (double)shift[c] + d1;
+  double var = (double)sums[C + c] / (double)M - d1 * d1;  // biased batch variance
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
   if (update_running) {
     const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
@@ -703,15 +721,12 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     st_off += 2 * (size_t)l.cout;
     if (batch_stats) {
       TRY(hipMemsetAsync(t->sums, 0, 2 * (size_t)l.cout * sizeof(float), s));
-      const int rows_per_block = 256;
-      hipLaunchKernelGGL(colstats_kernel<STAT_SUM>, dim3(nblk(M, rows_per_block)), dim3(256), 2 * l.cout * sizeof(float), s,
-                         pre, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, t->sums, M, l.cout,
-                         rows_per_block);
-      hipLaunchKernelGGL(bn_mean_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, M, l.cout);
-      hipLaunchKernelGGL(colstats_kernel<STAT_CENTRED>, dim3(nblk(M, rows_per_block)), dim3(256), 2 * l.cout * sizeof(float),
-                         s, pre, (const float*)nullptr, mean, (const float*)nullptr, t->sums, M, l.cout, rows_per_block);
-      hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, invstd, params + q.rmean,
-                         params + q.rvar, M, l.cout, 1);
+      const int rows_per_block = (int)std::max<size_t>(64, (M + 2047) / 2048);
+      // shift = the channel's value in the first row of `pre` (read in place: row 0 IS a [C] vector)
+      hipLaunchKernelGGL(colstats_kernel<STAT_SHIFTED>, dim3(nblk(M, rows_per_block)), dim3(256), 2 * l.cout * sizeof(float),
+                         s, pre, (const float*)nullptr, pre, (const float*)nullptr, t->sums, M, l.cout, rows_per_block);
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, pre, mean, invstd,
+                         params + q.rmean, params + q.rvar, M, l.cout, 1);
     } else {
       hipLaunchKernelGGL(bn_from_running_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, params + q.rmean, params + q.rvar, mean,
                          invstd, l.cout);
@@ -798,20 +813,26 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
                        l.relu6);
     // NOTE: for residual layers `post` holds bn + res; they carry no ReLU6, so the mask is not needed there
     TRY(hipMemsetAsync(t->sums, 0, 2 * (size_t)l.cout * sizeof(float), s));
-    hipLaunchKernelGGL(colstats_kernel<STAT_BWD>, dim3(nblk(M, 256)), dim3(256), 2 * l.cout * sizeof(float), s, t->gbuf,
-                       A(t->pre, i), mean, invstd, t->sums, M, l.cout, 256);
+    const int rpb = (int)std::max<size_t>(64, (M + 2047) / 2048);
+    hipLaunchKernelGGL(colstats_kernel<STAT_BWD>, dim3(nblk(M, rpb)), dim3(256), 2 * l.cout * sizeof(float), s, t->gbuf,
+                       A(t->pre, i), mean, invstd, t->sums, M, l.cout, rpb);
     hipLaunchKernelGGL(bn_param_grads_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, invstd, grads + q.gamma,
                        grads + q.beta, l.cout);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(total)), dim3(256), 0, s, t->gbuf, A(t->pre, i), mean, invstd,
                        params + q.gamma, t->sums, t->dpre, total, l.cout, M, batch_stats);
     const float* x = i == 0 ? visual : A(t->post, i - 1);
     if (l.kind == L_STEM) {
-      hipLaunchKernelGGL(stem_wgrad_kernel, dim3(l.cout), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cin, l.h_in, l.h_out,
-                         l.cout);
+      const int ppb = 512;
+      if (l.cin <= 4)
+        hipLaunchKernelGGL(stem_wgrad_kernel<4>, dim3(nblk(M, ppb)), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cin, l.h_in,
+                           l.h_out, l.cout, ppb);
+      else
+        hipLaunchKernelGGL(stem_wgrad_kernel<16>, dim3(nblk(M, ppb)), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cin, l.h_in,
+                           l.h_out, l.cout, ppb);
     } else if (l.kind == L_DW) {
-      const int ppb = 128;
-      hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nblk(M, ppb)), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in,
-                         l.h_out, l.stride, ppb);
+      const int ppb = (int)std::max<size_t>(64, (M + 1023) / 1024);
+      hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nblk(M, ppb)), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
+                         grads + q.w, B, l.cout, l.h_in, l.h_out, l.stride, ppb);
       const size_t tin = Bz * l.h_in * l.h_in * l.cout;
       hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nblk(tin)), dim3(256), 0, s, t->dpre, params + q.w, A(t->dpost, i - 1), B, l.cout,
                          l.h_in, l.h_out, l.stride);
