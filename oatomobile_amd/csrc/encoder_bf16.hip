@@ -1077,15 +1077,22 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
                                float* feat, int fused_blocks, hipStream_t s) {
   const size_t ms = plan.blob_floats;
-  // leading inverted-residual blocks as one fused kernel each; auto: whenever a launch has >= 256 (model, observation)
-  // pairs to spread over the CUs (one workgroup per pair and row band)
-  if (fused_blocks < 0) fused_blocks = (long)B * kc >= 256 ? 7 : 0;
+  // inverted-residual blocks as one fused kernel each.  auto: the row-streaming blocks (features.2-7) whenever a
+  // launch has >= 256 (model, observation) pairs to spread over the CUs, the tile blocks (features.8-16) from 1024
+  // pairs (one workgroup owns up to 4-8 observations; below that the layer-wise GEMMs fill the chip better)
+  const bool auto_sel = fused_blocks < 0;
+  const bool tile_ok = !auto_sel || (long)B * kc >= 1024;
+  if (auto_sel) fused_blocks = (long)B * kc >= 256 ? 17 : 0;
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
+  std::vector<char> tiled(plan.blocks.size(), 0);
   for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
-    if (!irb_bf16_supported(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw], plan.layers[fb.project]))
-      continue;
+    const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
+    const bool rows = irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    if (!rows && !tile) continue;
+    tiled[bi] = tile;
     if (fb.expand >= 0) in_block[fb.expand] = 1;
     in_block[fb.dw] = 1;
     in_block[fb.project] = 2;  // the block is launched where its last layer sits
@@ -1096,10 +1103,10 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     if (in_block[li] == 1) continue;
     if (in_block[li] == 2) {
       const FusedBlock& fb = plan.blocks[block_of[li]];
-      hipError_t e = launch_irb_bf16(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw],
-                                     plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc, B,
-                                     reinterpret_cast<const unsigned short*>(bufs[fb.src]),
-                                     reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
+      const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
+      hipError_t e = (tiled[block_of[li]] ? launch_irb_tile_bf16 : launch_irb_bf16)(
+          le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc, B,
+          reinterpret_cast<const unsigned short*>(bufs[fb.src]), reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
       if (e != hipSuccess) return e;
       continue;
     }

@@ -1,0 +1,402 @@
+// Fused bf16 inverted-residual block for the small-image stages (features.8 .. features.17: 7x7 and 4x4 maps) on
+// gfx950: expand 1x1 (MFMA) -> depthwise 3x3 -> project 1x1 (MFMA) (+ residual) in one kernel.
+//
+// torchvision v0.6.0 `InvertedResidual` (reference call site oatomobile/torch/networks/perception.py:36-51), BN
+// folded.  Layer by layer these ten blocks are 30 launches that write and re-read the 6x expanded tensor three times
+// (features.8 at 512 observations x 4 models: 77 MB each way per layer for 13 MB of block input); they were half of
+// the bf16 encoder's time.  Here the expanded tensor only ever exists as 64-channel slices in LDS.
+//
+// Decomposition (the row-streaming kernel of encoder_bf16_irb.hip does not fit: a 7x7 map has no rows to stream):
+// a workgroup owns G whole observations of one model (G*H*H pixel rows) and walks the hidden dimension in chunks of
+// 64 channels.  Its 8 waves are SPECIALISED and pipelined over the chunks, one barrier per step:
+//   waves 0-3 (matrix waves), step s:  expand chunk s    -> E[s & 1]      project chunk s-2  <- D[s & 1]
+//   waves 4-7 (vector waves), step s:  depthwise chunk s-1: E[(s-1) & 1] -> D[(s-1) & 1]
+// so each SIMD hosts one matrix wave and one vector wave: the depthwise (the VALU-bound part: 9 fp32 FMAs per output,
+// bf16 unpacking, ReLU6, packing) runs under the other wave's MFMAs instead of in a phase of its own, and neither role
+// carries the other's registers (the matrix waves hold the block input as B operands, the projection accumulators and
+// the pointwise weights; the vector waves two sets of 72 fp32 taps, so the next chunk's taps load a whole step ahead).
+//   expand: wave w owns the 16-pixel tiles w, w+4, ...; B = block input (K = CIN), resident in registers for all
+//     chunks; A = the chunk's 64 x CIN weight rows (requested one step ahead).  bias + ReLU6 + bf16 -> E.
+//   E is stored with a zero column either side of every image row, so the depthwise has no border predicates; rows
+//     above / below the map are skipped at compile time.
+//   depthwise: thread = (observation, output column, 8-channel group) walks DOWN its column: each input row is read
+//     (3 pixels) and unpacked once and scattered into the <= 3 output rows it belongs to.  bias + ReLU6 + bf16 -> D.
+//   project: wave w owns output tiles w, w+4, ...: one B read from D feeds all COUT/16 channel tiles; accumulators
+//     persist in registers across the chunks.
+// Epilogue: bias (+ residual from the block input) -> bf16.  Arithmetic order is the layer-wise kernels': MFMA chain
+// over ascending K from zero, then bias; depthwise = bias, then taps in (ky, kx) order; RNE rounding at the same points.
+#include <stdlib.h>
+
+#include "encoder.h"
+
+namespace rip {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 u) {
+  union {
+    u32x4 u;
+    bf16x8 v;
+  } c;
+  c.u = u;
+  return c.v;
+}
+__device__ __forceinline__ f32x2 bfpair(unsigned u) {
+  f32x2 r;
+  r.x = __uint_as_float(u << 16);
+  r.y = __uint_as_float(u & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ unsigned pack_bf16(f32x2 v) {
+  union {
+    bf16x2 h;
+    unsigned u;
+  } c;
+  c.h = __builtin_convertvector(v, bf16x2);
+  return c.u;
+}
+__device__ __forceinline__ f32x2 relu6_2(f32x2 v) {
+  return __builtin_elementwise_min(__builtin_elementwise_max(v, f32x2{0.f, 0.f}), f32x2{6.f, 6.f});
+}
+
+constexpr int HC = 64;        // hidden channels per chunk
+constexpr int LD = HC + 8;    // bf16 elements per LDS pixel row (odd multiple of 16 bytes)
+
+struct TileArgs {
+  const bf16_t* x;       // [K][B][HIN][HIN][CIN]
+  bf16_t* y;             // [K][B][HOUT][HOUT][COUT]
+  const float* wbase;    // fp32 folded blobs (biases, depthwise taps)
+  const bf16_t* whbase;  // bf16 copy of the blobs (pointwise weights), same offsets
+  size_t model_stride;
+  int k0;
+  size_t we_off, be_off, wd_off, bd_off, wp_off, bp_off;
+  int B, HID, residual, G;
+  int abl;  // development: 1 = no depthwise, 2 = no matrix work, 4 = no tap loads, 8 = no weight loads
+};
+
+template <int HIN, int STRIDE, int G>
+struct TileGeom {
+  static constexpr int HOUT = STRIDE == 1 ? HIN : (HIN + 1) / 2;
+  static constexpr int HWI = HIN * HIN, HWO = HOUT * HOUT;
+  static constexpr int PW = HIN + 2;                                  // padded row: zero, HIN pixels, zero
+  static constexpr int E_ROWS = G * HIN * PW;                         // per E buffer
+  static constexpr int D_ROWS = ((G * HWO + 15) / 16) * 16;           // per D buffer
+  static constexpr int TIN = (G * HWI + 63) / 64, TOUT = (G * HWO + 63) / 64;  // 16-pixel tiles per matrix wave
+  static constexpr size_t LDS_BYTES = (size_t)2 * (E_ROWS + D_ROWS) * LD * sizeof(bf16_t);
+};
+
+// G: observations per workgroup at most (G * HOUT * 8 <= 256 depthwise threads); a.G <= G is what the host chose.
+// AEF / APF: the expansion / projection weights of the next step are requested a step ahead (register budget
+// permitting: KSX * 16 / NCT * 8 more live registers); otherwise they are requested where the phase starts and the
+// wave's stall is covered by the vector wave on the same SIMD.
+template <int HIN, int STRIDE, int CIN, int COUT, int G, bool AEF, bool APF>
+__global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
+  using Geo = TileGeom<HIN, STRIDE, G>;
+  constexpr int HOUT = Geo::HOUT, HWI = Geo::HWI, HWO = Geo::HWO, PW = Geo::PW, TIN = Geo::TIN, TOUT = Geo::TOUT;
+  constexpr int KSX = CIN / 32, NCT = COUT / 16, NHT = HC / 16, NKP = HC / 32;
+  constexpr int CTG = NCT > 10 ? 10 : NCT;  // channel tiles per projection pass (weights of one pass are live at a time)
+  static_assert(NCT % CTG == 0 && (CTG == NCT || !APF), "projection passes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* const Ebuf = reinterpret_cast<bf16_t*>(smem_raw);              // [2][E_ROWS][LD]
+  bf16_t* const Dbuf = Ebuf + (size_t)2 * Geo::E_ROWS * LD;              // [2][D_ROWS][LD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = blockIdx.z;
+  const int img0 = blockIdx.x * a.G;
+  const int n_img = min(a.G, a.B - img0);
+  const int m_in = n_img * HWI, m_out = n_img * HWO;
+  const int HID = a.HID;
+  const int nch = HID / HC;
+  const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
+  const bf16_t* Wh = a.whbase + (size_t)(a.k0 + k) * a.model_stride;
+  const bf16_t* xg = a.x + ((size_t)k * a.B + img0) * HWI * CIN;
+  bf16_t* yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // zero both E buffers once: the padding columns are never written again
+  if (!(a.abl & 8))
+    for (int e = tid; e < 2 * Geo::E_ROWS * LD / 8; e += 512) reinterpret_cast<u32x4*>(Ebuf)[e] = zero4;
+  __syncthreads();
+
+  if (w < 4) {
+    // ================= matrix waves: expand + project =================
+    const int n = lane & 15, q = lane >> 4;
+    const int npt_in = (m_in + 15) >> 4, npt_out = (m_out + 15) >> 4;
+    u32x4 xb[TIN][KSX];   // block input, B operands
+    int erow[TIN];        // padded E row of this lane's pixel per tile (-1: beyond the workgroup's pixels)
+#pragma unroll
+    for (int t = 0; t < TIN; ++t) {
+      const int px = 16 * (w + 4 * t) + n;
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks)
+        xb[t][ks] = px < m_in ? *reinterpret_cast<const u32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q) : zero4;
+      const int g = px / HWI, r = px - g * HWI, iy = r / HIN, ix = r - iy * HIN;
+      erow[t] = px < m_in ? g * HIN * PW + iy * PW + ix + 1 : -1;
+    }
+    f32x4 acc[TOUT][NCT];
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ae[NHT][KSX], ap[CTG][NKP];
+    float4 be[NHT];
+    auto load_ae = [&](int c) {  // expand weights / bias of chunk c
+#pragma unroll
+      for (int ht = 0; ht < NHT; ++ht) {
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks)
+          ae[ht][ks] = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)(c * HC + 16 * ht + n) * CIN + 32 * ks + 8 * q);
+        be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * ht + 4 * q);
+      }
+    };
+    auto load_ap = [&](int c, int ct0) {  // projection weights of chunk c, channel tiles ct0 .. ct0 + CTG - 1
+      const bf16_t* wp = Wh + a.wp_off + (size_t)(16 * ct0 + n) * HID + c * HC + 8 * q;
+#pragma unroll
+      for (int ct = 0; ct < CTG; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < NKP; ++ks) ap[ct][ks] = *reinterpret_cast<const u32x4*>(wp + (size_t)16 * ct * HID + 32 * ks);
+    };
+    if (AEF) load_ae(0);
+    if (APF) load_ap(0, 0);
+    auto expand = [&](int c) {  // chunk c -> E[c & 1]
+      bf16_t* E = Ebuf + (size_t)(c & 1) * Geo::E_ROWS * LD;
+      if (!AEF) load_ae(c);
+#pragma unroll
+      for (int t = 0; t < TIN; ++t) {
+        if (w + 4 * t >= npt_in) continue;  // wave-uniform
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks)
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ae[ht][ks]), as_bf16x8(xb[t][ks]), v, 0, 0, 0);
+          u32x2 o;
+          o.x = pack_bf16(relu6_2(f32x2{v[0] + be[ht].x, v[1] + be[ht].y}));
+          o.y = pack_bf16(relu6_2(f32x2{v[2] + be[ht].z, v[3] + be[ht].w}));
+          if (erow[t] >= 0) *reinterpret_cast<u32x2*>(E + (size_t)erow[t] * LD + 16 * ht + 4 * q) = o;
+        }
+      }
+      if (AEF && c + 1 < nch) load_ae(c + 1);  // lands during the projection and the barrier
+    };
+    auto project = [&](int c) {  // chunk c <- D[c & 1]
+      const bf16_t* D = Dbuf + (size_t)(c & 1) * Geo::D_ROWS * LD;
+#pragma unroll
+      for (int cg = 0; cg < NCT; cg += CTG) {
+        if (!APF) load_ap(c, cg);
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) {
+          if (w + 4 * t >= npt_out) continue;  // wave-uniform
+          u32x4 bv[NKP];
+#pragma unroll
+          for (int ks = 0; ks < NKP; ++ks)
+            bv[ks] = *reinterpret_cast<const u32x4*>(D + (size_t)(16 * (w + 4 * t) + n) * LD + 32 * ks + 8 * q);
+#pragma unroll
+          for (int ct = 0; ct < CTG; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < NKP; ++ks)
+              acc[t][cg + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ap[ct][ks]), as_bf16x8(bv[ks]), acc[t][cg + ct], 0, 0, 0);
+        }
+      }
+      if (APF && c + 1 < nch) load_ap(c + 1, 0);  // projected in the next step
+    };
+    const bool mx_on = !(a.abl & 2);
+#pragma unroll 1
+    for (int s = 0; s < nch; ++s) {  // steps with an expansion
+      if (mx_on) expand(s);
+      if (s >= 2 && mx_on) project(s - 2);
+      __syncthreads();
+    }
+    // drain: the last two projections; the epilogue's operands (bias, residual = block input) are requested first
+    float4 bpj[NCT];
+    u32x2 rres[TOUT][NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bpj[ct] = *reinterpret_cast<const float4*>(W + a.bp_off + 16 * ct + 4 * q);
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t) {
+      const int p = 16 * (w + 4 * t) + n;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        rres[t][ct] = (a.residual && p < m_out) ? *reinterpret_cast<const u32x2*>(xg + (size_t)p * CIN + 16 * ct + 4 * q)
+                                                : u32x2{0u, 0u};
+    }
+    if (nch >= 2 && mx_on) project(nch - 2);
+    __syncthreads();
+    if (mx_on) project(nch - 1);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t) {
+      const int p = 16 * (w + 4 * t) + n;
+      if (p >= m_out || (a.abl & 16)) continue;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        f32x2 v0 = {acc[t][ct][0] + bpj[ct].x, acc[t][ct][1] + bpj[ct].y};
+        f32x2 v1 = {acc[t][ct][2] + bpj[ct].z, acc[t][ct][3] + bpj[ct].w};
+        v0 += bfpair(rres[t][ct].x);  // zeros when the block has no residual (as the layer-wise kernels: + 0 is exact)
+        v1 += bfpair(rres[t][ct].y);
+        u32x2 o;
+        o.x = pack_bf16(v0);
+        o.y = pack_bf16(v1);
+        *reinterpret_cast<u32x2*>(yg + (size_t)p * COUT + 16 * ct + 4 * q) = o;
+      }
+    }
+  } else {
+    // ================= vector waves: depthwise 3x3 =================
+    const int vt = tid - 256;
+    const int c8 = vt & 7, dcol = (vt >> 3) % HOUT, dimg = (vt >> 3) / HOUT;
+    const bool dw_on = dimg < n_img;
+    // first of the three padded columns this thread reads (input column dcol*S - 1 -> padded index dcol*S)
+    const int e_off = ((dw_on ? dimg : 0) * HIN * PW + dcol * STRIDE) * LD + 8 * c8;
+    const int d_off = ((dw_on ? dimg : 0) * HWO + dcol) * LD + 8 * c8;
+    f32x2 wt[2][9][4], bd[2][4];
+    auto load_taps = [&](int c, f32x2(&wt_)[9][4], f32x2(&bd_)[4]) {
+      const float* wd = W + a.wd_off + c * HC + 8 * c8;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wd + (size_t)t * HID);
+        const float4 w1 = *reinterpret_cast<const float4*>(wd + (size_t)t * HID + 4);
+        wt_[t][0] = f32x2{w0.x, w0.y};
+        wt_[t][1] = f32x2{w0.z, w0.w};
+        wt_[t][2] = f32x2{w1.x, w1.y};
+        wt_[t][3] = f32x2{w1.z, w1.w};
+      }
+      const float4 b0 = *reinterpret_cast<const float4*>(W + a.bd_off + c * HC + 8 * c8);
+      const float4 b1 = *reinterpret_cast<const float4*>(W + a.bd_off + c * HC + 8 * c8 + 4);
+      bd_[0] = f32x2{b0.x, b0.y};
+      bd_[1] = f32x2{b0.z, b0.w};
+      bd_[2] = f32x2{b1.x, b1.y};
+      bd_[3] = f32x2{b1.z, b1.w};
+    };
+    auto depthwise = [&](const bf16_t* E, bf16_t* D, const f32x2(&wt_)[9][4], const f32x2(&bd_)[4]) {
+      f32x2 sacc[HOUT][4];
+#pragma unroll
+      for (int iy = 0; iy < HIN; ++iy) {
+        const bf16_t* r = E + e_off + iy * PW * LD;
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(r);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(r + LD);
+        const u32x4 v2 = *reinterpret_cast<const u32x4*>(r + 2 * LD);
+        const f32x2 f[3][4] = {{bfpair(v0.x), bfpair(v0.y), bfpair(v0.z), bfpair(v0.w)},
+                               {bfpair(v1.x), bfpair(v1.y), bfpair(v1.z), bfpair(v1.w)},
+                               {bfpair(v2.x), bfpair(v2.y), bfpair(v2.z), bfpair(v2.w)}};
+#pragma unroll
+        for (int oy = 0; oy < HOUT; ++oy) {
+          const int ky = iy - oy * STRIDE + 1;  // compile-time after unrolling
+          if (ky < 0 || ky > 2) continue;
+          if (ky == 0 || (ky == 1 && oy * STRIDE - 1 < 0)) {  // first row of this output that lies inside the map
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc[oy][e] = bd_[e];
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc[oy][e] = __builtin_elementwise_fma(f[kx][e], wt_[ky * 3 + kx][e], sacc[oy][e]);
+          if (ky == 2 || iy == HIN - 1) {  // last row of this output inside the map: finish it
+            u32x4 o;
+            o.x = pack_bf16(relu6_2(sacc[oy][0]));
+            o.y = pack_bf16(relu6_2(sacc[oy][1]));
+            o.z = pack_bf16(relu6_2(sacc[oy][2]));
+            o.w = pack_bf16(relu6_2(sacc[oy][3]));
+            *reinterpret_cast<u32x4*>(D + d_off + oy * HOUT * LD) = o;
+          }
+        }
+      }
+    };
+    load_taps(0, wt[0], bd[0]);
+#pragma unroll 1
+    for (int s = 0; s < nch + 2; s += 2) {
+      // even step s: depthwise of chunk s-1 (odd buffers), taps of chunk s arrive in set 0
+      if (s >= 1 && s <= nch && dw_on && !(a.abl & 1))
+        depthwise(Ebuf + (size_t)Geo::E_ROWS * LD, Dbuf + (size_t)Geo::D_ROWS * LD, wt[1], bd[1]);
+      if (s + 1 < nch && !(a.abl & 4)) load_taps(s + 1, wt[1], bd[1]);
+      __syncthreads();
+      if (s + 1 >= nch + 2) break;
+      // odd step s+1: depthwise of chunk s (even buffers)
+      if (s + 1 <= nch && dw_on && !(a.abl & 1)) depthwise(Ebuf, Dbuf, wt[0], bd[0]);
+      if (s + 2 < nch && !(a.abl & 4)) load_taps(s + 2, wt[0], bd[0]);
+      __syncthreads();
+    }
+  }
+}
+
+template <int HIN, int STRIDE, int CIN, int COUT, int GMAX, bool AEF, bool APF>
+hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
+  using Geo = TileGeom<HIN, STRIDE, GMAX>;
+  static_assert(GMAX * Geo::HOUT * 8 <= 256, "one depthwise thread per (observation, column, 8 channels)");
+  // observations per workgroup: one workgroup per CU when the launch is large enough, never more than GMAX
+  int G = (int)(((long)a.B * kc + 255) / 256);
+  if (G > GMAX) G = GMAX;
+  if (G < 1) G = 1;
+  a.G = G;
+  static bool attr_set[64] = {};  // per device: > 64 KB of dynamic LDS needs the opt-in
+  auto kern = irb_tile_bf16_kernel<HIN, STRIDE, CIN, COUT, GMAX, AEF, APF>;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Geo::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G, 1, kc), dim3(512), Geo::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp) {
+  if (le == nullptr) return false;
+  const int cin = le->cin, hid = ld.cout, cout = lp.cout;
+  if (hid != 6 * cin || hid % HC != 0) return false;
+  if (ld.h_in == 7 && ld.stride == 1) return (cin == 64 && (cout == 64 || cout == 96)) || (cin == 96 && cout == 96);
+  if (ld.h_in == 7 && ld.stride == 2) return cin == 96 && cout == 160;
+  // features.17 (160 -> 960 -> 320 at 4x4) stays layer-wise: with 320 output channels a wave's accumulators leave
+  // room for one 16-pixel tile only, every weight tile would feed a single MFMA (measured 424 us vs ~150 us)
+  if (ld.h_in == 4 && ld.stride == 1) return cin == 160 && cout == 160;
+  return false;
+}
+
+hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
+                                const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
+                                const unsigned short* x, unsigned short* y, hipStream_t s) {
+  TileArgs a;
+  a.x = x;
+  a.y = y;
+  a.wbase = enc_w;
+  a.whbase = enc_wh;
+  a.model_stride = model_stride;
+  a.k0 = k0;
+  a.we_off = le->w_off;
+  a.be_off = le->b_off;
+  a.wd_off = ld.w_off;
+  a.bd_off = ld.b_off;
+  a.wp_off = lp.w_off;
+  a.bp_off = lp.b_off;
+  a.B = B;
+  a.HID = ld.cout;
+  a.residual = lp.residual;
+  a.G = 1;
+  a.abl = 0;
+  if (const char* e = getenv("RIP_TILE_ABL")) a.abl = atoi(e);
+  const int cin = le->cin, cout = lp.cout;
+  //                                          HIN S CIN COUT GMAX AEF APF
+  if (ld.h_in == 7 && ld.stride == 1) {
+    if (cin == 64 && cout == 64) return launch_tile<7, 1, 64, 64, 4, true, true>(a, kc, s);    // features.8-10
+    if (cin == 64 && cout == 96) return launch_tile<7, 1, 64, 96, 4, true, false>(a, kc, s);    // features.11
+    if (cin == 96 && cout == 96) return launch_tile<7, 1, 96, 96, 4, false, false>(a, kc, s);    // features.12, 13
+  }
+  if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_tile<7, 2, 96, 160, 4, true, true>(a, kc, s);  // 14
+  if (ld.h_in == 4 && ld.stride == 1 && cin == 160) {
+    if (cout == 160) return launch_tile<4, 1, 160, 160, 8, false, false>(a, kc, s);              // features.15, 16
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace rip

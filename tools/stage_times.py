@@ -15,6 +15,7 @@ def main():
   ap.add_argument("--candidates", type=int, default=128)
   ap.add_argument("--algorithm", default="WCM")
   ap.add_argument("--enc", default="fp32")
+  ap.add_argument("--fused", type=int, default=-1, help="RIP_OPT_ENCODER_FUSED (-1 = auto)")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
   dev = torch.device("cuda", 0)
@@ -22,6 +23,7 @@ def main():
   models = [ImitativeModel.synthetic(100 + k, max_batch=1) for k in range(K)]
   agent = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, max_batch=B, device=dev)
   lib, h = _lib.load(), agent._handle.raw
+  _lib.check(lib.rip_set_option(h, 1, args.fused))
   lidar, vec, goal = (torch.from_numpy(a).to(dev) for a in synth_batch(np.random.default_rng(0), B, 2))
   x0 = agent._x0(B)
   z = torch.empty(K, B, 64, device=dev); plan = torch.empty(B, 4, 2, device=dev); loss = torch.empty(B, N, device=dev)
