@@ -74,6 +74,12 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
                            const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
                            const unsigned short* x, unsigned short* y, hipStream_t s);
 
+// stem + features.1 in one kernel (encoder_bf16_front.hip)
+bool front_bf16_supported(const Layer& ls, const Layer& ld, const Layer& lp);
+hipError_t launch_front_bf16(const Layer& ls, const Layer& ld, const Layer& lp, const float* enc_w,
+                             const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B, const float* visual,
+                             unsigned short* y, hipStream_t s);
+
 // small-image stages (7x7 / 4x4 maps, features.8 .. features.17): encoder_bf16_tile.hip
 bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
 hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,

@@ -1098,6 +1098,19 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     in_block[fb.project] = 2;  // the block is launched where its last layer sits
     block_of[fb.project] = (int)bi;
   }
+  // stem + features.1 (block 0, t = 1) as one kernel
+  bool front = false;
+  if (fused_blocks >= 1 && !plan.blocks.empty() && plan.blocks[0].expand < 0 && plan.layers[0].kind == L_STEM &&
+      plan.blocks[0].dw == 1 && plan.layers[1].src == plan.layers[0].dst &&
+      front_bf16_supported(plan.layers[0], plan.layers[plan.blocks[0].dw], plan.layers[plan.blocks[0].project])) {
+    const FusedBlock& fb = plan.blocks[0];
+    front = true;
+    in_block[0] = in_block[fb.dw] = in_block[fb.project] = 1;
+    hipError_t e = launch_front_bf16(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc,
+                                     B, visual, reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
+    if (e != hipSuccess) return e;
+  }
+  (void)front;
   for (size_t li = 0; li < plan.layers.size(); ++li) {
     const Layer& l = plan.layers[li];
     if (in_block[li] == 1) continue;
