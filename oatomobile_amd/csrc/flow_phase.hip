@@ -60,6 +60,9 @@ __device__ __forceinline__ f32x4 zero4() {
 #define PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 
+#ifndef RIP_PREFETCH
+#define RIP_PREFETCH 1  // operand rows requested one MFMA group ahead (development switch)
+#endif
 #ifndef RIP_ABL
 #define RIP_ABL 0  // development only: 1 = no tape loads, 2 = no operand reloads, 3 = no tape stores (wrong results)
 #endif
@@ -151,15 +154,28 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
   const float4 wxr = wl[48 * 64], wxz = wl[49 * 64], wxg = wl[50 * 64], wxh = wl[51 * 64];
   const float wxra[4] = {wxr.x, wxr.y, wxr.z, wxr.w}, wxza[4] = {wxz.x, wxz.y, wxz.z, wxz.w};
   const float wxga[4] = {wxg.x, wxg.y, wxg.z, wxg.w}, wxha[4] = {wxh.x, wxh.y, wxh.z, wxh.w};
+  // operand rows one group (12 MFMAs = 384 cycles) ahead of their use: the LDS latency of a group's three reads is
+  // covered by the previous group's MFMAs instead of by its last two (what the scheduler does on its own)
+  float4 cr = wl[((0 * 4 + 0) * 4 + 0) * 64], cz = wl[((1 * 4 + 0) * 4 + 0) * 64], ch = wl[((2 * 4 + 0) * 4 + 0) * 64];
 #pragma unroll
   for (int up = 0; up < 4; ++up) {
     f32x4 ar = zero4(), az = zero4(), agn = zero4(), ahn = zero4();
     PRIO_BURST();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // 4 k-steps per operand row
-      const float4 wr = wl[((0 * 4 + up) * 4 + j) * 64];
-      const float4 wz = wl[((1 * 4 + up) * 4 + j) * 64];
-      const float4 wh = wl[((2 * 4 + up) * 4 + j) * 64];
+      const float4 wr = cr, wz = cz, wh = ch;
+      if (RIP_PREFETCH) {
+        const int nj = (j + 1) & 3, nup = up + (j == 3 ? 1 : 0);
+        if (nup < 4) {
+          cr = wl[((0 * 4 + nup) * 4 + nj) * 64];
+          cz = wl[((1 * 4 + nup) * 4 + nj) * 64];
+          ch = wl[((2 * 4 + nup) * 4 + nj) * 64];
+        } else {  // the head's first rows
+          cr = wl[52 * 64];
+          cz = wl[56 * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       ar = mfma(wr.x, H[4 * j + 0], ar);
       az = mfma(wz.x, H[4 * j + 0], az);
       ahn = mfma(wh.x, H[4 * j + 0], ahn);
@@ -172,6 +188,12 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
       ar = mfma(wr.w, H[4 * j + 3], ar);
       az = mfma(wz.w, H[4 * j + 3], az);
       ahn = mfma(wh.w, H[4 * j + 3], ahn);
+      if (!RIP_PREFETCH && !(up == 3 && j == 3)) {
+        const int nj = (j + 1) & 3, nup = up + (j == 3 ? 1 : 0);
+        cr = wl[((0 * 4 + nup) * 4 + nj) * 64];
+        cz = wl[((1 * 4 + nup) * 4 + nj) * 64];
+        ch = wl[((2 * 4 + nup) * 4 + nj) * 64];
+      }
     }
     ar = mfma(wxra[up], bin, ar);
     az = mfma(wxza[up], bin, az);
@@ -205,10 +227,15 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
   const float bone = q == 2 ? 1.f : 0.f;
   f32x4 a0 = zero4(), a1 = zero4();
   PRIO_BURST();
+  float4 ca = RIP_PREFETCH ? cr : wl[52 * 64], cb = RIP_PREFETCH ? cz : wl[56 * 64];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float4 wa = wl[(52 + j) * 64];
-    const float4 wb = wl[(56 + j) * 64];
+    const float4 wa = ca, wb = cb;
+    if (j < 3) {
+      ca = wl[(52 + j + 1) * 64];
+      cb = wl[(56 + j + 1) * 64];
+      if (RIP_PREFETCH) __builtin_amdgcn_sched_barrier(0);
+    }
     a0 = mfma(wa.x, H[4 * j + 0], a0);
     a1 = mfma(wb.x, H[4 * j + 0], a1);
     a0 = mfma(wa.y, H[4 * j + 1], a0);
@@ -463,22 +490,27 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
   // ---- dh_t = W1^T da1_t + W_hh^T dgh_{t+1} (+ dh'_{t+1} z_{t+1} below) ----
   f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4(), acc3 = zero4();
   PRIO_BURST();
+  {
+    // rows 1..8 (W1^T, B = da1) then 9..56 (W_hh^T, B = dgh), each feeding 4 MFMAs; requested PF rows (PF * 128
+    // cycles of MFMAs) ahead of their use
+    constexpr int NROW = FIRST ? 8 : 56;
+    constexpr int PF = 3;
+    float4 ring[PF];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float4 w = tw[(1 + e) * 64];
-    acc0 = mfma(w.x, da1r[e], acc0);
-    acc1 = mfma(w.y, da1r[e], acc1);
-    acc2 = mfma(w.z, da1r[e], acc2);
-    acc3 = mfma(w.w, da1r[e], acc3);
-  }
-  if (!FIRST) {
+    for (int e = 0; e < PF; ++e) ring[e] = tw[(1 + e) * 64];
 #pragma unroll
-    for (int e = 0; e < 48; ++e) {
-      const float4 w = tw[(9 + e) * 64];
-      acc0 = mfma(w.x, dgh[e], acc0);
-      acc1 = mfma(w.y, dgh[e], acc1);
-      acc2 = mfma(w.z, dgh[e], acc2);
-      acc3 = mfma(w.w, dgh[e], acc3);
+    for (int e = 0; e < NROW; ++e) {
+      const float4 w = ring[e % PF];
+      if (RIP_PREFETCH) {
+        if (e + PF < NROW) ring[e % PF] = tw[(1 + e + PF) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const float bop = e < 8 ? da1r[e < 8 ? e : 0] : dgh[e < 8 ? 0 : e - 8];
+      acc0 = mfma(w.x, bop, acc0);
+      acc1 = mfma(w.y, bop, acc1);
+      acc2 = mfma(w.z, bop, acc2);
+      acc3 = mfma(w.w, bop, acc3);
+      if (!RIP_PREFETCH && e + PF < NROW) ring[e % PF] = tw[(1 + e + PF) * 64];
     }
   }
   PRIO_VALU();
