@@ -52,6 +52,8 @@ ENC_ACT_ELEMS = 1466229 + 1465488  # layer-wise activation elements read + writt
 ENC_WEIGHT_ELEMS = 2370336 + 17056
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA (MI355X_MICROARCH.md; the headline 5 PF includes 2:1 sparsity)
+PEAK_FP32_VECTOR_TFLOPS = 157.3  # packed fp32 FMA on the vector ALUs
 # MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 flop each) of the passes of search_phase_kernel, per 16-candidate
 # block (flow_phase.hip: fwd_step_lds = 251; adjoint step = 274, 82 at t = T-1)
 MFMA_FWD_PASS = 3 * 251
@@ -64,6 +66,30 @@ def synth_batch(rng, B, C, G=10):
   vec = np.c_[rng.normal(0, 3.0, size=(B, 3)), (rng.random((B, 1)) < 0.2), rng.integers(0, 4, size=(B, 1))]
   goal = np.cumsum(np.abs(rng.normal(size=(B, G, 2))) * 2.0, axis=1)
   return lidar.astype(np.float32), vec.astype(np.float32), goal.astype(np.float32)
+
+
+def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype):
+  """The encoder stage against its three ceilings.  Work per (model, observation) from the architecture (arch.py):
+  pointwise convs 68.63 M MAC on the matrix cores, depthwise + stem (4.64 + 0.72 C) M fp32 FMA on the vector ALUs;
+  HBM bytes MEASURED at the bench configuration (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all encoder kernels of one
+  512-observation x 4-model step, profiles/r2/pmc_summary_v3.csv: 2.370 GB) scaled by (B K) / 2048."""
+  t = enc_ms * 1e-3
+  pw_flops = 2.0 * 68.627e6 * B * K
+  valu_fma = (4.641e6 + 0.720e6 * C) * B * K
+  line = {"ms_per_step": enc_ms,
+          "mfma_TFLOPs": pw_flops / t / 1e12, "mfma_frac": pw_flops / t / 1e12 / (PEAK_BF16_TFLOPS if enc_dtype == "bf16" else PEAK_FP32_TFLOPS),
+          "valu_TFMAs": valu_fma / t / 1e12, "valu_frac": 2.0 * valu_fma / t / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+          "layerwise_GBps": layerwise_bytes / t / 1e9,
+          "note": "transform + stem + MobileNetV2 features (%s) + classifier + merger.  `layerwise_GBps` = SURVEY §8d "
+                  "bytes_pre + bytes_enc (every layer's input and output through HBM) / time: what the UNFUSED network "
+                  "would have to move, not what the fused kernels move." % enc_dtype}
+  if enc_dtype == "bf16" and C == 2:
+    meas = 2.370e9 * (B * K) / 2048.0
+    line.update({"measured_hbm_bytes": meas, "measured_GBps": meas / t / 1e9, "frac_hbm": meas / t / 1e9 / PEAK_HBM_GBS})
+    line["note"] += ("  `measured_*`: HBM bytes from the PMC passes in profiles/r2 (fused blocks keep the expanded tensors "
+                     "in LDS: 2.37 GB per step instead of the layer-wise 12.2 GB).  The stage sits far below all three "
+                     "ceilings: 25 dependent launches of small-tile work (16-96 channel GEMMs, 9-tap depthwise).")
+  return line
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -358,12 +384,7 @@ def main():
                 "(inverse_0(F_0(x)) == x) and K adjoints per candidate, none of which the algorithm needs, so it can "
                 "exceed the peak.  `whole_act_*`: §8(d) algorithmic bytes per act (weights amortised over the batch) x "
                 "calls/s vs 8 TB/s.  `traffic`: the adjoint tape.",
-        "encoder": {"ms_per_step": enc_ms, "algorithmic_GBps": enc_bytes / (enc_ms * 1e-3) / 1e9,
-                    "frac_hbm": enc_bytes / (enc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                    "note": "transform + stem + MobileNetV2 features (%s) + classifier + merger; LAYER-WISE compulsory "
-                            "bytes (SURVEY §8d bytes_pre+bytes_enc) / encoder time vs 8 TB/s -- an upper bound on "
-                            "the achieved HBM rate: the fused blocks keep the expanded tensors on chip (measured "
-                            "FETCH_SIZE x2 + WRITE_SIZE of the encoder kernels: profiles/)" % args.encoder_dtype},
+        "encoder": _encoder_roofline(enc_ms, enc_bytes, B, K, C, args.encoder_dtype),
     }
     roof.update(extras)
     out = {
