@@ -182,7 +182,7 @@ def _free_port():
 def _self_spawn(args):
   """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
   n = torch.cuda.device_count()
-  if n < args.gpus:
+  if n < args.gpus and os.environ.get("RIP_BENCH_SHARE_GPU") != "1":
     raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, n))
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -220,13 +220,21 @@ def main():
   if world != args.gpus:
     raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
   assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the product has no CPU path)"
-  torch.cuda.set_device(local_rank)
-  dev = torch.device("cuda", local_rank)
+  # development / test hook: RIP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and RIP_BENCH_BACKEND=gloo replaces RCCL
+  # (which refuses two ranks on one device), so the world > 1 code path can be exercised on a one-GPU box
+  # (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu); the numbers of such a run mean nothing.
+  dev_index = 0 if os.environ.get("RIP_BENCH_SHARE_GPU") == "1" else local_rank
+  backend = os.environ.get("RIP_BENCH_BACKEND", "nccl")
+  torch.cuda.set_device(dev_index)
+  dev = torch.device("cuda", dev_index)
   dist = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+      dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+      dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
   import __graft_entry__ as entry
   if rank == 0:

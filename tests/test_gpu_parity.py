@@ -1133,3 +1133,25 @@ def test_replay_512_cached_observations(dev, tmp_path):
   # another batching of the same files gives the same plans (observations are independent)
   plans2 = replay.replay(agent, files[::-1], batch_size=128)[::-1]
   np.testing.assert_allclose(plans2, plans, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+  """`python bench.py --gpus 2` (self-spawn under torch.distributed.run, barrier + max-over-ranks timing, rank 0
+  prints the line) on a ONE-GPU box: both ranks on cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one
+  device).  Checks the world > 1 code path and the JSON contract, not the numbers."""
+  import json, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, RIP_BENCH_SHARE_GPU="1", RIP_BENCH_BACKEND="gloo")
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--obs-batch", "32", "--no-cpu-baseline", "--no-extras"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
+  rec = json.loads(lines[0])
+  assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+  assert rec["value"] > 0 and abs(rec["value"] - 2 * 32 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
+  assert rec["roofline"]["frac"] is None or 0 < rec["roofline"]["frac"] < 1
