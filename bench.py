@@ -598,9 +598,28 @@ def _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all):
     par = "model-parallel (gradient mode): K = %d models over %d ranks, one all-gather of the [K_local,B,N,9] block per Adam step" % (K, world)
     scaling, n_total = "strong", N
   elapsed = timed(step, args.steps, args.warmup)
+  # the distributed result against the world-1 composition of the same search on rank 0 (same candidate stream)
+  if args.mode == "candidates":
+    plan_d = cp(lidar, vec, goal)[0]
+  else:
+    plan_d = mp(lidar, vec, goal)[0]
+  check = None
+  if rank == 0:
+    if args.mode == "candidates":
+      one = D.CandidateParallelRIP(models, N * world, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B, device=dev,
+                                   encoder_dtype=args.encoder_dtype, rank=0, world=1)
+      plan_1 = one(lidar, vec, goal)[0]
+    else:
+      full = [ImitativeModel.synthetic(100 + k, in_channels=C, max_batch=1) for k in range(K)]
+      one = D.ModelParallelRIP(full, K, num_candidates=N, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B,
+                               device=dev, rank=0, world=1)
+      plan_1 = one(lidar, vec, goal)[0]
+    check = {"max_abs_plan_diff_vs_single_gpu": float((plan_d - plan_1).abs().max().item()),
+             "note": "plans of the %d-rank run vs ONE rank holding everything, same observations and latent starts" % world}
   if rank == 0:
     calls = B * args.steps
     print(json.dumps({
+        "check": check,
         "metric": "RIPAgent.act() calls/sec (K=%d, %d plans, 200x200 BEV)" % (K, n_total),
         "value": calls / elapsed, "unit": "calls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,

@@ -38,6 +38,18 @@ def _world(group=None) -> Tuple[int, int]:
   return dist.get_rank(group), dist.get_world_size(group)
 
 
+
+def _all_gather_into(flat: torch.Tensor, block: torch.Tensor, group=None) -> None:
+  """`dist.all_gather_into_tensor`; on the gloo backend device tensors are staged through the host (gloo has no
+  device all-gather) — that combination only occurs in the one-GPU tests of the multi-rank paths, RCCL takes the
+  device tensors as they are."""
+  if block.is_cuda and dist.get_backend(group) == "gloo":
+    host = torch.empty(flat.shape, dtype=flat.dtype)
+    dist.all_gather_into_tensor(host, block.detach().cpu().contiguous(), group=group)
+    flat.copy_(host)
+    return
+  dist.all_gather_into_tensor(flat, block.contiguous(), group=group)
+
 def all_gather_scores(local_scores: torch.Tensor, num_models: int, group=None) -> torch.Tensor:
   """Model-parallel exchange: `local_scores [K_local, B, N]` (this rank's models, in `shard_range` order) ->
   `[K, B, N]` on every rank.  Ranks may own different numbers of models (K % world != 0): blocks are padded to
@@ -53,7 +65,7 @@ def all_gather_scores(local_scores: torch.Tensor, num_models: int, group=None) -
   block = local_scores.new_zeros((kmax, B, N))
   block[:k_local] = local_scores
   flat = local_scores.new_empty((world * kmax, B, N))  # concatenated along dim 0 (the layout gloo and RCCL share)
-  dist.all_gather_into_tensor(flat, block.contiguous(), group=group)
+  _all_gather_into(flat, block, group)
   out = flat.view(world, kmax, B, N)
   return torch.cat([out[r, :e - b] for r, (b, e) in enumerate(shares)], dim=0).contiguous()
 
@@ -69,7 +81,7 @@ def gather_rows(local_rows: torch.Tensor, total_rows: int, group=None) -> torch.
   block = local_rows.new_zeros((rmax,) + tuple(local_rows.shape[1:]))
   block[:local_rows.shape[0]] = local_rows
   flat = local_rows.new_empty((world * rmax,) + tuple(local_rows.shape[1:]))
-  dist.all_gather_into_tensor(flat, block.contiguous(), group=group)
+  _all_gather_into(flat, block, group)
   out = flat.view((world, rmax) + tuple(local_rows.shape[1:]))
   return torch.cat([out[r, :e - b] for r, (b, e) in enumerate(shares)], dim=0).contiguous()
 
@@ -142,7 +154,7 @@ def all_gather_blocks(local: torch.Tensor, num_models: int, group=None) -> torch
   block = local.new_zeros((kmax,) + tuple(local.shape[1:]))
   block[:local.shape[0]] = local
   flat = local.new_empty((world * kmax,) + tuple(local.shape[1:]))
-  dist.all_gather_into_tensor(flat, block.contiguous(), group=group)
+  _all_gather_into(flat, block, group)
   out = flat.view((world, kmax) + tuple(local.shape[1:]))
   return torch.cat([out[r, :e - b] for r, (b, e) in enumerate(shares)], dim=0).contiguous()
 
@@ -226,7 +238,7 @@ def gather_rank_winners(rec: torch.Tensor, group=None) -> torch.Tensor:
   if world == 1:
     return rec[None]
   allrec = rec.new_empty((world,) + tuple(rec.shape))
-  dist.all_gather_into_tensor(allrec.view(world * rec.shape[0], rec.shape[1]), rec.contiguous(), group=group)
+  _all_gather_into(allrec.view(world * rec.shape[0], rec.shape[1]), rec, group)
   return allrec
 
 
@@ -315,7 +327,12 @@ class ModelParallelRIP:
   def __call__(self, lidar: torch.Tensor, vec: torch.Tensor, goal: torch.Tensor, exchange=None):
     """Returns (plan [B,4,2], best candidate index [B], loss_best [B,N]) — identical on every rank.
     `exchange(block)` replaces the all-gather (tests: concatenate the blocks of emulated ranks)."""
-    gather = exchange if exchange is not None else (lambda t: all_gather_blocks(t, self._k_total, self._group))
+    if exchange is not None:
+      gather = exchange
+    elif self._world == 1:  # one rank holds every model (also when constructed with world=1 inside a larger job)
+      gather = lambda t: t
+    else:
+      gather = lambda t: all_gather_blocks(t, self._k_total, self._group)
     goal = goal.contiguous()
     B = lidar.shape[0]
     z_local = self.encode_local(lidar, vec)

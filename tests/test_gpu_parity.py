@@ -1135,23 +1135,39 @@ def test_replay_512_cached_observations(dev, tmp_path):
   np.testing.assert_allclose(plans2, plans, atol=1e-5)
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_share_one_gpu():
-  """`python bench.py --gpus 2` (self-spawn under torch.distributed.run, barrier + max-over-ranks timing, rank 0
-  prints the line) on a ONE-GPU box: both ranks on cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one
-  device).  Checks the world > 1 code path and the JSON contract, not the numbers."""
+def _run_bench_two_ranks(extra):
   import json, subprocess, sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = dict(os.environ, RIP_BENCH_SHARE_GPU="1", RIP_BENCH_BACKEND="gloo")
   for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
     env.pop(k, None)
   out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--obs-batch", "32", "--no-cpu-baseline", "--no-extras"], cwd=root, env=env, capture_output=True,
-                       text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-extras"] + extra, cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
   assert out.returncode == 0, out.stderr[-2000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
   assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
-  rec = json.loads(lines[0])
+  return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+  """`python bench.py --gpus 2` (self-spawn under torch.distributed.run, barrier + max-over-ranks timing, rank 0
+  prints the line) on a ONE-GPU box: both ranks on cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one
+  device).  Checks the world > 1 code path and the JSON contract, not the numbers."""
+  rec = _run_bench_two_ranks(["--obs-batch", "32"])
   assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
   assert rec["value"] > 0 and abs(rec["value"] - 2 * 32 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
   assert rec["roofline"]["frac"] is None or 0 < rec["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["candidates", "models"])
+def test_bench_parallel_modes_two_ranks(mode):
+  """`bench.py --mode candidates|models --gpus 2`: CandidateParallelRIP / ModelParallelRIP across two PROCESSES
+  (one-GPU hook: shared device, gloo, device all-gathers staged through the host).  The mode's own check — the
+  plan of the distributed search against the single-GPU search of the same observations — is part of the line."""
+  rec = _run_bench_two_ranks(["--mode", mode, "--obs-batch", "8"])
+  assert rec["n_gpus"] == 2 and rec["value"] > 0
+  assert rec["config"]["mode"] == mode
+  assert rec["check"]["max_abs_plan_diff_vs_single_gpu"] <= 1e-4, rec["check"]
