@@ -341,7 +341,7 @@ def main():
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
 
   # ---------------- secondary lines (rank 0, N = 1 only; untimed by the driver's contract) ----------------
-  online = pcie = scoring = fp32_line = c4_line = train_line = None
+  online = pcie = scoring = fp32_line = c4_line = train_line = replay_line = None
   if rank == 0 and world == 1 and not args.no_extras:
     online = _bench_online(args, models, dev, host_batches[0])
     pcie = _bench_pcie(args, encode_search, host_batches, dev, B, C, G, timed)
@@ -357,6 +357,7 @@ def main():
     if C == 2:
       c4_line = _bench_c4(args, dev, timed, seeds)
     train_line = _bench_train(args, dev, timed)
+    replay_line = _bench_replay(args, agent, dev, B, C)
 
   if rank == 0:
     flow_flops = 2.0 * 3.0 * (1 + K) * 4 * FLOW_MAC_PER_STEP * N * S * B  # SURVEY §8(d) flops_flow(grad)
@@ -419,6 +420,7 @@ def main():
         "fp32_parity": fp32_line,
         "bev_c4": c4_line,
         "train_step": train_line,
+        "replay": replay_line,
     }
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(args)
@@ -496,6 +498,47 @@ def _bench_pcie(args, encode_search, host_batches, dev, B, C, G, timed):
           "note": "inputs staged in pinned host memory, H2D double-buffered on a copy stream under the previous "
                   "step's kernels (PCIe Gen5 x16: %.1f ms of transfer per step at 63 GB/s); never `value`" %
                   (nbytes / 63e9 * 1e3)}
+
+
+def _bench_replay(args, agent, dev, B, C):
+  """BASELINE configs[4] shape on one GPU: cached `.npz` datums (the reference's on-disk schema) decoded by worker
+  processes into shared-memory batches (oatomobile_amd/replay.py:DatumBatches), uploaded and planned batch by batch.
+  Steady state: the clock starts when the first batch has been planned (the workers' start-up is seconds)."""
+  import shutil, tempfile
+  from oatomobile_amd import replay
+  nfiles, repeats = 256, 16
+  workers = max(1, min(48, replay.effective_cpus() - 2))
+  tmp = tempfile.mkdtemp(prefix="rip_replay_")
+  try:
+    ep = replay.Episode(tmp, "ep")
+    rng = np.random.default_rng(77)
+    lidar, vec, goal = synth_batch(rng, nfiles, C)
+    for i in range(nfiles):
+      fut = np.cumsum(np.abs(rng.normal(size=(80, 3))) * 0.4, axis=0).astype(np.float32)
+      ep.append(lidar=lidar[i], velocity=vec[i, :3], is_at_traffic_light=vec[i, 3], traffic_light_state=vec[i, 4],
+                player_future=fut)
+    files = ep.files() * repeats
+    t_inline0 = time.perf_counter()
+    for f in files[:64]:
+      replay.load_datum(f)
+    inline_rate = 64 / (time.perf_counter() - t_inline0)
+    n_done, t0 = 0, None
+    for lid, v, g in replay.DatumBatches(files, B, workers=workers, prefetch=2, channels=C):
+      plan = agent.plan_batch(lid.to(dev, non_blocking=True), v.to(dev, non_blocking=True), g.to(dev, non_blocking=True))
+      plan.cpu()
+      if t0 is None:
+        t0 = time.perf_counter()
+      else:
+        n_done += lid.shape[0]
+    el = time.perf_counter() - t0
+    return {"observations_per_s": n_done / el, "decode_processes": workers, "files": len(files), "batch": B,
+            "inline_decode_per_s": inline_rate,
+            "note": "np.load (zipfile + zlib) of compressed 200x200x%d datums in %d worker processes -> shared-memory "
+                    "batch -> H2D -> act(); one process decodes %.0f datums/s, which is what bounds a single-process "
+                    "replay; this process may use %d CPUs (affinity / cgroup quota) of the host's %d" %
+                    (C, workers, inline_rate, replay.effective_cpus(), os.cpu_count() or 0)}
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _bench_scoring(args, lib, h, batches, z, enc_dtype, dev, timed, K, N, B, G, algo):

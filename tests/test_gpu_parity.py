@@ -1133,6 +1133,14 @@ def test_replay_512_cached_observations(dev, tmp_path):
   # another batching of the same files gives the same plans (observations are independent)
   plans2 = replay.replay(agent, files[::-1], batch_size=128)[::-1]
   np.testing.assert_allclose(plans2, plans, atol=1e-5)
+  # decode in worker processes (shared-memory batch buffers): same plans; the rate includes the workers' start-up
+  # (spawn + import, seconds) on a job this small — bench.py's `replay` line measures the steady state
+  nw = max(1, min(32, replay.effective_cpus() - 1))
+  t0 = time.perf_counter()
+  plans3 = replay.replay(agent, files, batch_size=256, workers=nw)
+  dt = time.perf_counter() - t0
+  print("same replay with %d decode processes: %.0f observations/s including their start-up" % (nw, F / dt))
+  np.testing.assert_array_equal(plans3, plans)
 
 
 def _run_bench_two_ranks(extra):

@@ -281,3 +281,29 @@ def test_validation_of_raw_pointer_inputs():
     _lib.expect_shape(torch.zeros(2, 3), (2, 4), "t")
   _lib.expect_shape(torch.zeros(2, 3), (None, 3), "t")
   assert _lib.ptr(None).value in (None, 0)
+
+
+def test_datum_batches_worker_processes_equal_inline(tmp_path):
+  """`replay.DatumBatches`: batches decoded by worker processes into shared-memory buffers (ragged last batch, more
+  workers than rows in it) equal the inline decode, in file order."""
+  from oatomobile_amd import replay
+  ep = replay.Episode(str(tmp_path), "ep")
+  rng = np.random.default_rng(7)
+  for i in range(21):
+    ep.append("t%02d" % i, lidar=(rng.random((200, 200, 2)) < 0.1).astype(np.float32) * (1 + i % 5) / 5.0,
+              velocity=rng.normal(size=3).astype(np.float32), is_at_traffic_light=np.float32(i % 2),
+              traffic_light_state=np.float32(i % 4),
+              player_future=np.cumsum(np.abs(rng.normal(size=(80, 3))), axis=0).astype(np.float32))
+  files = ep.files()
+  inline = [tuple(t.clone() for t in b) for b in replay.DatumBatches(files, 8)]
+  multi = [tuple(t.clone() for t in b) for b in replay.DatumBatches(files, 8, workers=3, prefetch=2)]
+  assert [b[0].shape[0] for b in inline] == [8, 8, 5] == [b[0].shape[0] for b in multi]
+  for x, y in zip(inline, multi):
+    for u, v in zip(x, y):
+      assert u.dtype == torch.float32 and torch.equal(u, v)
+  d0 = replay.load_datum(files[9])
+  np.testing.assert_array_equal(inline[1][0][1].numpy(), d0["lidar"])
+  np.testing.assert_array_equal(inline[1][2][1].numpy(), replay.goal_from_future(d0["player_future"]))
+  assert list(replay.DatumBatches([], 8)) == []
+  with pytest.raises(ValueError, match="BEV channels"):
+    replay.DatumBatches(files, 8, channels=4)
