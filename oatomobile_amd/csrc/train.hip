@@ -21,12 +21,13 @@
 //   flow_train_kernel   (flow.hip) teacher-forced inverse, its adjoint through all 4 steps into z, and the per-step gate
 //                       gradients whose outer products with the saved inputs are the GRU / head weight gradients (GEMMs)
 //   adam_kernel         torch.optim.Adam defaults, skipping the running statistics
-// This is the first correct path of the row (parity with the reference's step, tests/golden/g15): the kernels are
-// plain, not yet tuned like the inference path.
+// Parity with the reference's step: tests/golden/g15.  The kernels are one tuning pass beyond the first correct path
+// (48.7 -> 11 ms per 128-observation step); the step is still one launch per layer and operation.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <vector>
 
@@ -44,64 +45,147 @@ constexpr float BN_EPS = 1e-5f, BN_MOMENTUM = 0.1f;
 
 // ------------------------------------------------------------------------------------------------------------
 // GEMM: C[M,N] (ldc) (+)= op(A)[M,K] op(B)[K,N];  TA: A is stored [K,M]; TB: B is stored [N,K].
-// 256 threads, 64x64 tile, K chunks of 16; wave w computes the 32x32 quadrant (w >> 1, w & 1) as 2x2 MFMA tiles.
+// 256 threads = 4 waves as WR x WC, each computing TM x TN tiles of v_mfma_f32_16x16x4_f32 out of a BM x BN block
+// (64x64, 128x32 or 256x16: the pointwise convs have 16..96 channels on one side and B*H*W on the other).  K runs in
+// chunks of BK through double-buffered LDS tiles [k][m] / [k][n]; the next chunk's global loads (16-byte when the
+// operand's contiguous dimension allows: VEC) are in flight while the current one is multiplied, one barrier per chunk.
 // gridDim.z > 1: split-K, partial sums added with atomics (C zeroed by the caller); accumulate: C += (no split).
 // ------------------------------------------------------------------------------------------------------------
-template <bool TA, bool TB>
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                        int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                        int kchunk, int accumulate) {
-  __shared__ float As[16][64 + 4];
-  __shared__ float Bs[16][64 + 4];
+  constexpr int WC = 4 / WR, TM = BM / WR / 16, TN = BN / WC / 16;
+  constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+  constexpr int A4 = BM * BK / 4 / 256, B4 = (BN * BK / 4 + 255) / 256;  // float4 groups per thread and chunk
+  static_assert(BM * BK / 4 % 256 == 0, "A tile");
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB_S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int n = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  f32x4 acc[2][2];
+  const int wm = (wave / WC) * (TM * 16), wn = (wave % WC) * (TN * 16);
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = kb; k0 < ke; k0 += 16) {
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // a group = 4 consecutive elements along the stored matrix's contiguous dimension
+  float4 ra[A4], rb[B4];
+  auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < A4; ++i) {
       const int e = tid + i * 256;
-      {  // A tile: consecutive threads follow the contiguous dimension of the stored matrix
-        const int m = TA ? (e & 63) : (e >> 4), k = TA ? (e >> 6) : (e & 15);
-        const int gm = m0 + m, gk = k0 + k;
-        float v = 0.f;
-        if (gm < M && gk < ke) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-        As[k][m] = v;
-      }
-      {
-        const int n = TB ? (e >> 4) : (e & 63), k = TB ? (e & 15) : (e >> 6);
-        const int gn = n0 + n, gk = k0 + k;
-        float v = 0.f;
-        if (gn < N && gk < ke) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
-        Bs[k][n] = v;
-      }
-    }
-    __syncthreads();
+      const int m = TA ? (e % (BM / 4)) * 4 : e / (BK / 4), k = TA ? e / (BM / 4) : (e % (BK / 4)) * 4;
+      const int gm = m0 + m, gk = k0 + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* p = TA ? A + (size_t)gk * lda + gm : A + (size_t)gm * lda + gk;
+      if (VEC) {
+        if (TA ? (gk < ke && gm < M) : (gm < M && gk < ke)) v = *reinterpret_cast<const float4*>(p);
+      } else {
+        const int st = TA ? 1 : 1;  // both walk the contiguous dimension
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int k = kk * 4 + (lane >> 4);
-      const float a0 = As[k][wm + (lane & 15)], a1 = As[k][wm + 16 + (lane & 15)];
-      const float b0 = Bs[k][wn + (lane & 15)], b1 = Bs[k][wn + 16 + (lane & 15)];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+          const bool ok = TA ? (gk < ke && gm + c < M) : (gm < M && gk + c < ke);
+          if (ok) t[c] = p[c * st];
+        }
+        v = make_float4(t[0], t[1], t[2], t[3]);
+      }
+      ra[i] = v;
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int e = tid + i * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < BN * BK / 4) {
+        const int nn = TB ? e / (BK / 4) : (e % (BN / 4)) * 4, k = TB ? (e % (BK / 4)) * 4 : e / (BN / 4);
+        const int gn = n0 + nn, gk = k0 + k;
+        const float* p = TB ? B + (size_t)gn * ldb + gk : B + (size_t)gk * ldb + gn;
+        if (VEC) {
+          if (TB ? (gn < N && gk < ke) : (gk < ke && gn < N)) v = *reinterpret_cast<const float4*>(p);
+        } else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bool ok = TB ? (gn < N && gk + c < ke) : (gk < ke && gn + c < N);
+            if (ok) t[c] = p[c];
+          }
+          v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A4; ++i) {
+      const int e = tid + i * 256;
+      if (TA) {
+        const int m = (e % (BM / 4)) * 4, k = e / (BM / 4);
+        *reinterpret_cast<float4*>(&As[buf][k][m]) = ra[i];
+      } else {
+        const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
+        As[buf][k][m] = ra[i].x;
+        As[buf][k + 1][m] = ra[i].y;
+        As[buf][k + 2][m] = ra[i].z;
+        As[buf][k + 3][m] = ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B4; ++i) {
+      const int e = tid + i * 256;
+      if (e < BN * BK / 4) {
+        if (TB) {
+          const int nn = e / (BK / 4), k = (e % (BK / 4)) * 4;
+          Bs[buf][k][nn] = rb[i].x;
+          Bs[buf][k + 1][nn] = rb[i].y;
+          Bs[buf][k + 2][nn] = rb[i].z;
+          Bs[buf][k + 3][nn] = rb[i].w;
+        } else {
+          const int nn = (e % (BN / 4)) * 4, k = e / (BN / 4);
+          *reinterpret_cast<float4*>(&Bs[buf][k][nn]) = rb[i];
+        }
+      }
+    }
+  };
+
+  if (kb < ke) {
+    load_tiles(kb);
+    store_tiles(0);
   }
-  // result tile: lane (n = lane & 15, q = lane >> 4), register r <-> row 4 q + r, column n
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += BK) {
+    const bool more = k0 + BK < ke;
+    if (more) load_tiles(k0 + BK);  // in flight during this chunk's MFMAs
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int k = kk * 4 + q;
+      float av[TM], bv[TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < TM; ++i) av[i] = As[buf][k][wm + 16 * i + n];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][k][wn + 16 * j + n];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(buf ^ 1);  // the other buffer: its last readers passed the previous barrier
+    __syncthreads();
+    buf ^= 1;
+  }
+  // result tile: lane (n, q), register r <-> row 4 q + r, column n
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gm = m0 + wm + i * 16 + 4 * (lane >> 4) + r, gn = n0 + wn + j * 16 + (lane & 15);
+        const int gm = m0 + wm + i * 16 + 4 * q + r, gn = n0 + wn + j * 16 + n;
         if (gm < M && gn < N) {
           float* p = C + (size_t)gm * ldc + gn;
           if (gridDim.z > 1)
@@ -114,18 +198,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
       }
 }
 
+template <bool TA, bool TB, int BM, int BN, int BK, int WR>
+void gemm_launch(bool vec, dim3 grid, hipStream_t s, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 int M, int N, int K, int kchunk, int accumulate) {
+  if (vec)
+    hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, BK, WR, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N,
+                       K, kchunk, accumulate);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, BK, WR, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N,
+                       K, kchunk, accumulate);
+}
+
+template <bool TA, bool TB>
+void gemm_shape(bool vec, int bn_sel, dim3 grid, hipStream_t s, const float* A, int lda, const float* B, int ldb, float* C,
+                int ldc, int M, int N, int K, int kchunk, int accumulate) {
+  if (bn_sel == 16)
+    gemm_launch<TA, TB, 256, 16, 16, 4>(vec, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
+  else if (bn_sel == 32)
+    gemm_launch<TA, TB, 128, 32, 32, 4>(vec, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
+  else
+    gemm_launch<TA, TB, 64, 64, 32, 2>(vec, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
+}
+
 hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                 int K, int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
-  dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
-  int kchunk = K;
+  // block shape by the narrow side; wide-and-short outputs (M small, N large) keep the square block
+  const int bn = (N <= 16 && M >= 256) ? 16 : ((N <= 32 && M >= 128) ? 32 : 64);
+  const int bm = bn == 16 ? 256 : (bn == 32 ? 128 : 64), bk = bn == 16 ? 16 : 32;
+  dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, 1);
+  int kchunk = (K + bk - 1) / bk * bk;
   // reductions over B*H*W with few output tiles: split K so that the chip has work (C must then be pre-zeroed or
   // hold the value to add to: atomics add into it)
   const long tiles = (long)grid.x * grid.y;
   if (K >= 4096 && tiles < 512) {
-    int splits = (int)std::min<long>((512 + tiles - 1) / tiles, (K + 1023) / 1024);
+    // ~1024 workgroups (4 per CU), chunks of at least 256: with 1024-long chunks the 13x13 / 7x7 weight gradients
+    // (K = 21632 / 6272, a handful of output tiles) ran as 60-120 workgroups of 30+ serial iterations each (68 us)
+    int splits = (int)std::min<long>((1024 + tiles - 1) / tiles, (K + 255) / 256);
     if (splits > 1) {
-      kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+      kchunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
       grid.z = (K + kchunk - 1) / kchunk;
       if (!accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
@@ -133,17 +244,18 @@ hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int l
       }
     }
   }
-#define GEMM_LAUNCH(TA_, TB_) \
-  hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate)
+  // 16-byte loads need the contiguous dimension of both stored operands to be whole groups of four floats
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = lda % 4 == 0 && ldb % 4 == 0 && al16(A) && al16(B) && (ta ? M % 4 == 0 : K % 4 == 0) &&
+                   (tb ? K % 4 == 0 : N % 4 == 0);
   if (ta && tb)
-    GEMM_LAUNCH(true, true);
+    gemm_shape<true, true>(vec, bn, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
   else if (ta)
-    GEMM_LAUNCH(true, false);
+    gemm_shape<true, false>(vec, bn, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
   else if (tb)
-    GEMM_LAUNCH(false, true);
+    gemm_shape<false, true>(vec, bn, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
   else
-    GEMM_LAUNCH(false, false);
-#undef GEMM_LAUNCH
+    gemm_shape<false, false>(vec, bn, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
   return hipGetLastError();
 }
 
@@ -221,15 +333,22 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 }
 
 // depthwise: x NHWC [B,Hi,Hi,C] -> out [B,Ho,Ho,C]; w [C][3][3]
+// thread = (pixel, 4 channels): 16-byte activation accesses; per element the FMA chain runs over (ky, kx) ascending
+__device__ __forceinline__ float4 dw_taps4(const float* __restrict__ w, int c4, int t) {
+  const float* p = w + (size_t)(4 * c4) * 9 + t;
+  return make_float4(p[0], p[9], p[18], p[27]);
+}
 __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int B,
                               int C, int Hi, int Ho, int stride) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)B * Ho * Ho * C;
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * Ho * Ho * C4;
   if (idx >= total) return;
-  const int c = idx % C;
-  const size_t p = idx / C;
+  const int c4 = idx % C4;
+  const size_t p = idx / C4;
   const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
-  float acc = 0.f;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = stride * oy - 1 + ky;
@@ -238,22 +357,29 @@ __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restri
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = stride * ox - 1 + kx;
       if (ix < 0 || ix >= Hi) continue;
-      acc = fmaf(x[(((size_t)b * Hi + iy) * Hi + ix) * C + c], w[c * 9 + ky * 3 + kx], acc);
+      const float4 v = x4[(((size_t)b * Hi + iy) * Hi + ix) * C4 + c4];
+      const float4 wv = dw_taps4(w, c4, ky * 3 + kx);
+      acc.x = fmaf(v.x, wv.x, acc.x);
+      acc.y = fmaf(v.y, wv.y, acc.y);
+      acc.z = fmaf(v.z, wv.z, acc.z);
+      acc.w = fmaf(v.w, wv.w, acc.w);
     }
   }
-  out[idx] = acc;
+  reinterpret_cast<float4*>(out)[idx] = acc;
 }
 
 // dx[b,iy,ix,c] += sum_{ky,kx} dpre[b,oy,ox,c] w[c,ky,kx] with stride*oy - 1 + ky == iy
 __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ dx,
                                 int B, int C, int Hi, int Ho, int stride) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)B * Hi * Hi * C;
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * Hi * Hi * C4;
   if (idx >= total) return;
-  const int c = idx % C;
-  const size_t p = idx / C;
+  const int c4 = idx % C4;
+  const size_t p = idx / C4;
   const int ix = p % Hi, iy = (p / Hi) % Hi, b = p / ((size_t)Hi * Hi);
-  float acc = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(dpre);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int ty = iy + 1 - ky;
@@ -266,46 +392,97 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __r
       if (tx < 0 || tx % stride != 0) continue;
       const int ox = tx / stride;
       if (ox >= Ho) continue;
-      acc = fmaf(dpre[(((size_t)b * Ho + oy) * Ho + ox) * C + c], w[c * 9 + ky * 3 + kx], acc);
+      const float4 g = g4[(((size_t)b * Ho + oy) * Ho + ox) * C4 + c4];
+      const float4 wv = dw_taps4(w, c4, ky * 3 + kx);
+      acc.x = fmaf(g.x, wv.x, acc.x);
+      acc.y = fmaf(g.y, wv.y, acc.y);
+      acc.z = fmaf(g.z, wv.z, acc.z);
+      acc.w = fmaf(g.w, wv.w, acc.w);
     }
   }
-  dx[idx] += acc;
+  float4* d4 = reinterpret_cast<float4*>(dx) + idx;
+  float4 o = *d4;
+  o.x += acc.x;
+  o.y += acc.y;
+  o.z += acc.z;
+  o.w += acc.w;
+  *d4 = o;
 }
 
-// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c]: blocks own pixel chunks; thread
-// (c = t % Cb, sub = t / Cb) with Cb = min(C, 256) channels per sweep walks every (256 / Cb)-th pixel (channel fastest:
-// coalesced); partial sums meet in LDS, then one global atomic per (block, channel, tap) (dw zeroed by the caller)
+// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c].  A block owns (observation, band of output
+// rows); a thread owns (output column, 4 channels) and walks DOWN the band with a 3x3 register window of 16-byte x
+// values (three new loads per row at stride 1, six at stride 2) and one 16-byte dpre value per row: 36 FMAs per 4-7
+// loads, no index arithmetic in the loop.  The 36 partial sums per thread meet in LDS, then one global atomic per
+// (block, channel, tap) (dw zeroed by the caller).  (The first version walked pixel chunks with scalar loads and a
+// div / mod per pixel: 289 us per layer on average, 4.9 ms of a 26 ms step.)
+template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
-                                                       float* __restrict__ dw, int B, int C, int Hi, int Ho, int stride,
-                                                       int pix_per_block) {
+                                                       float* __restrict__ dw, int B, int C, int Hi, int Ho, int bands) {
   extern __shared__ float sm[];  // [C * 9]
   for (int i = threadIdx.x; i < C * 9; i += 256) sm[i] = 0.f;
   __syncthreads();
-  const size_t npix = (size_t)B * Ho * Ho;
-  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
-  const size_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
-  const int Cb = C < 256 ? C : 256;
-  const int groups = 256 / Cb;
-  const int sub = threadIdx.x / Cb;
-  if (sub < groups) {
-    for (int c = threadIdx.x % Cb; c < C; c += Cb) {
-      float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (size_t p = p0 + sub; p < p1; p += groups) {
-        const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
-        const float g = dpre[p * C + c];
+  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+  const int rows = (Ho + bands - 1) / bands;
+  const int oy0 = band * rows, oy1 = min(Ho, oy0 + rows);
+  const int C4 = C >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)b * Hi * Hi * C4;
+  const float4* g4 = reinterpret_cast<const float4*>(dpre) + (size_t)b * Ho * Ho * C4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int item = threadIdx.x; item < Ho * C4; item += 256) {
+    const int c4 = item % C4, ox = item / C4;
+    const int ix0 = STRIDE * ox - 1;
+    const bool okl = ix0 >= 0, okr = ix0 + 2 < Hi;  // the centre column always lies inside
+    auto load_row = [&](int iy, float4(&r)[3]) {
+      if (iy < 0 || iy >= Hi) {
+        r[0] = r[1] = r[2] = zero;
+        return;
+      }
+      const float4* p = x4 + ((size_t)iy * Hi + ix0) * C4 + c4;
+      r[0] = okl ? p[0] : zero;
+      r[1] = p[C4];
+      r[2] = okr ? p[2 * C4] : zero;
+    };
+    float4 acc[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = stride * oy - 1 + ky;
+    for (int t = 0; t < 9; ++t) acc[t] = zero;
+    float4 win[3][3];
+    load_row(STRIDE * oy0 - 1, win[0]);
+    if (STRIDE == 1) load_row(oy0, win[1]);
+    for (int oy = oy0; oy < oy1; ++oy) {
+      if (STRIDE == 1) {
+        load_row(oy + 1, win[2]);
+      } else {
+        load_row(2 * oy, win[1]);
+        load_row(2 * oy + 1, win[2]);
+      }
+      const float4 g = g4[((size_t)oy * Ho + ox) * C4 + c4];
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = stride * ox - 1 + kx;
-            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Hi)
-              acc[ky * 3 + kx] = fmaf(g, x[(((size_t)b * Hi + iy) * Hi + ix) * C + c], acc[ky * 3 + kx]);
-          }
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float4& a = acc[ky * 3 + kx];
+          const float4 v = win[ky][kx];
+          a.x = fmaf(g.x, v.x, a.x);
+          a.y = fmaf(g.y, v.y, a.y);
+          a.z = fmaf(g.z, v.z, a.z);
+          a.w = fmaf(g.w, v.w, a.w);
+        }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        if (STRIDE == 1) {
+          win[0][kx] = win[1][kx];
+          win[1][kx] = win[2][kx];
+        } else {
+          win[0][kx] = win[2][kx];
         }
       }
+    }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(&sm[c * 9 + t], acc[t]);
+    for (int t = 0; t < 9; ++t) {
+      atomicAdd(&sm[(4 * c4 + 0) * 9 + t], acc[t].x);
+      atomicAdd(&sm[(4 * c4 + 1) * 9 + t], acc[t].y);
+      atomicAdd(&sm[(4 * c4 + 2) * 9 + t], acc[t].z);
+      atomicAdd(&sm[(4 * c4 + 3) * 9 + t], acc[t].w);
     }
   }
   __syncthreads();
@@ -332,31 +509,58 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   __syncthreads();
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  auto accumulate = [&](int c, size_t rbeg, size_t rstep, float& s1, float& s2) {
-    const float mu = mean[c];  // STAT_SHIFTED: the shift k[c]
-    const float is = MODE == STAT_BWD ? invstd[c] : 0.f;
-    for (size_t r = rbeg; r < r1; r += rstep) {
-      const float v = x[r * C + c];
-      if (MODE == STAT_SHIFTED) {
-        const float d = v - mu;
-        s1 += d;
-        s2 = fmaf(d, d, s2);
-      } else {
-        s1 += v;
-        s2 = fmaf(v, (y[r * C + c] - mu) * is, s2);
+  // thread = (4 channels, row lane): 16-byte loads, 256 / (C / 4) rows in flight per block (C is a multiple of 4 for
+  // every layer of the network; the scalar loop below covers anything else)
+  if ((C & 3) == 0) {
+    const int C4 = C >> 2;
+    const int RL = C4 <= 256 ? 256 / C4 : 1;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    for (int g0 = 0; g0 < C4; g0 += 256) {
+      const int c4 = C4 <= 256 ? (int)(threadIdx.x % C4) : g0 + (int)threadIdx.x;
+      const int rl = C4 <= 256 ? (int)(threadIdx.x / C4) : 0;
+      if (c4 < C4 && rl < RL) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);  // STAT_SHIFTED: the shift k[c]
+        const float4 is = MODE == STAT_BWD ? *reinterpret_cast<const float4*>(invstd + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        for (size_t r = r0 + rl; r < r1; r += RL) {
+          const float4 v = x4[r * C4 + c4];
+          if (MODE == STAT_SHIFTED) {
+            const float4 d = make_float4(v.x - mu.x, v.y - mu.y, v.z - mu.z, v.w - mu.w);
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
+          } else {
+            const float4 yy = y4[r * C4 + c4];
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x = fmaf(v.x, (yy.x - mu.x) * is.x, s2.x);
+            s2.y = fmaf(v.y, (yy.y - mu.y) * is.y, s2.y);
+            s2.z = fmaf(v.z, (yy.z - mu.z) * is.z, s2.z);
+            s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
+          }
+        }
+        atomicAdd(&sm[4 * c4 + 0], s1.x); atomicAdd(&sm[4 * c4 + 1], s1.y);
+        atomicAdd(&sm[4 * c4 + 2], s1.z); atomicAdd(&sm[4 * c4 + 3], s1.w);
+        atomicAdd(&sm[C + 4 * c4 + 0], s2.x); atomicAdd(&sm[C + 4 * c4 + 1], s2.y);
+        atomicAdd(&sm[C + 4 * c4 + 2], s2.z); atomicAdd(&sm[C + 4 * c4 + 3], s2.w);
       }
+      if (C4 <= 256) break;
     }
-  };
-  if (C <= 256 && 256 % C == 0) {  // a thread keeps one channel, 256 / C threads share it
-    const int c = threadIdx.x % C;
-    float s1 = 0.f, s2 = 0.f;
-    accumulate(c, r0 + threadIdx.x / C, 256 / C, s1, s2);
-    atomicAdd(&sm[c], s1);
-    atomicAdd(&sm[C + c], s2);
   } else {
     for (int c = threadIdx.x; c < C; c += 256) {  // this thread is the only writer of channel c
+      const float mu = mean[c];
+      const float is = MODE == STAT_BWD ? invstd[c] : 0.f;
       float s1 = 0.f, s2 = 0.f;
-      accumulate(c, r0, 1, s1, s2);
+      for (size_t r = r0; r < r1; ++r) {
+        const float v = x[r * C + c];
+        if (MODE == STAT_SHIFTED) {
+          const float d = v - mu;
+          s1 += d;
+          s2 = fmaf(d, d, s2);
+        } else {
+          s1 += v;
+          s2 = fmaf(v, (y[r * C + c] - mu) * is, s2);
+        }
+      }
       sm[c] += s1;
       sm[C + c] += s2;
     }
@@ -649,7 +853,7 @@ hipError_t trainer_create(Trainer** out, int in_channels, int max_batch, int dev
   alloc(&t->gbuf, B * t->max_act);
   alloc(&t->dpre, B * t->max_act);
   alloc(&t->stats, t->stats_floats);
-  alloc(&t->sums, 2 * 1280 * 2);
+  alloc(&t->sums, 2 * t->stats_floats);  // per layer (sum, sum of squares) forward and (sum g, sum g xhat) backward
   alloc(&t->tail, B * (size_t)TRAIN_TAIL_FLOATS);
   alloc(&t->flowbuf, B * (size_t)FLOW_TRAIN_ROW_FLOATS + FW_SIZE);
   if (e != hipSuccess) {
@@ -695,6 +899,7 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
   auto A = [&](float* base, int i) { return base + Bz * t->tl[i].act_off; };
   TRY(hipMemsetAsync(grads, 0, t->numel * sizeof(float), s));
   TRY(hipMemsetAsync(t->dpost, 0, Bz * t->act_per_image * sizeof(float), s));
+  TRY(hipMemsetAsync(t->sums, 0, 2 * t->stats_floats * sizeof(float), s));  // every layer's reduction targets at once
   // ================================== forward ==================================
   size_t st_off = 0;
   std::vector<size_t> stat_off(nl);
@@ -710,7 +915,7 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
       hipLaunchKernelGGL(stem_fwd_kernel, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in, l.h_out,
                          l.cout);
     } else if (l.kind == L_DW) {
-      hipLaunchKernelGGL(dw_fwd_kernel, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cout, l.h_in, l.h_out,
+      hipLaunchKernelGGL(dw_fwd_kernel, dim3(nblk(total / 4)), dim3(256), 0, s, x, params + q.w, pre, B, l.cout, l.h_in, l.h_out,
                          l.stride);
     } else {
       TRY(gemm(false, true, x, l.cin, params + q.w, l.cin, pre, l.cout, (int)M, l.cout, l.cin, 0, s));
@@ -719,13 +924,13 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     float* invstd = mean + l.cout;
     stat_off[i] = st_off;
     st_off += 2 * (size_t)l.cout;
+    float* sums_f = t->sums + stat_off[i];
     if (batch_stats) {
-      TRY(hipMemsetAsync(t->sums, 0, 2 * (size_t)l.cout * sizeof(float), s));
       const int rows_per_block = (int)std::max<size_t>(64, (M + 2047) / 2048);
       // shift = the channel's value in the first row of `pre` (read in place: row 0 IS a [C] vector)
       hipLaunchKernelGGL(colstats_kernel<STAT_SHIFTED>, dim3(nblk(M, rows_per_block)), dim3(256), 2 * l.cout * sizeof(float),
-                         s, pre, (const float*)nullptr, pre, (const float*)nullptr, t->sums, M, l.cout, rows_per_block);
-      hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, pre, mean, invstd,
+                         s, pre, (const float*)nullptr, pre, (const float*)nullptr, sums_f, M, l.cout, rows_per_block);
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, sums_f, pre, mean, invstd,
                          params + q.rmean, params + q.rvar, M, l.cout, 1);
     } else {
       hipLaunchKernelGGL(bn_from_running_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, params + q.rmean, params + q.rvar, mean,
@@ -812,14 +1017,14 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, A(t->dpost, i), A(t->post, i), t->gbuf, dres, total,
                        l.relu6);
     // NOTE: for residual layers `post` holds bn + res; they carry no ReLU6, so the mask is not needed there
-    TRY(hipMemsetAsync(t->sums, 0, 2 * (size_t)l.cout * sizeof(float), s));
+    float* sums_b = t->sums + t->stats_floats + stat_off[i];
     const int rpb = (int)std::max<size_t>(64, (M + 2047) / 2048);
     hipLaunchKernelGGL(colstats_kernel<STAT_BWD>, dim3(nblk(M, rpb)), dim3(256), 2 * l.cout * sizeof(float), s, t->gbuf,
-                       A(t->pre, i), mean, invstd, t->sums, M, l.cout, rpb);
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, t->sums, mean, invstd, grads + q.gamma,
+                       A(t->pre, i), mean, invstd, sums_b, M, l.cout, rpb);
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, sums_b, mean, invstd, grads + q.gamma,
                        grads + q.beta, l.cout);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(total)), dim3(256), 0, s, t->gbuf, A(t->pre, i), mean, invstd,
-                       params + q.gamma, t->sums, t->dpre, total, l.cout, M, batch_stats);
+                       params + q.gamma, sums_b, t->dpre, total, l.cout, M, batch_stats);
     const float* x = i == 0 ? visual : A(t->post, i - 1);
     if (l.kind == L_STEM) {
       const int ppb = 512;
@@ -830,14 +1035,19 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
         hipLaunchKernelGGL(stem_wgrad_kernel<16>, dim3(nblk(M, ppb)), dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cin, l.h_in,
                            l.h_out, l.cout, ppb);
     } else if (l.kind == L_DW) {
-      const int ppb = (int)std::max<size_t>(64, (M + 1023) / 1024);
-      hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nblk(M, ppb)), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
-                         grads + q.w, B, l.cout, l.h_in, l.h_out, l.stride, ppb);
+      // (observation, row band) blocks: enough bands for ~2 blocks per CU, at least 4 rows each
+      int bands = std::max(1, std::min(l.h_out / 4, (int)((512 + B - 1) / B)));
+      if (l.stride == 1)
+        hipLaunchKernelGGL(dw_wgrad_kernel<1>, dim3(B * bands), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
+                           grads + q.w, B, l.cout, l.h_in, l.h_out, bands);
+      else
+        hipLaunchKernelGGL(dw_wgrad_kernel<2>, dim3(B * bands), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
+                           grads + q.w, B, l.cout, l.h_in, l.h_out, bands);
       const size_t tin = Bz * l.h_in * l.h_in * l.cout;
-      hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nblk(tin)), dim3(256), 0, s, t->dpre, params + q.w, A(t->dpost, i - 1), B, l.cout,
+      hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nblk(tin / 4)), dim3(256), 0, s, t->dpre, params + q.w, A(t->dpost, i - 1), B, l.cout,
                          l.h_in, l.h_out, l.stride);
     } else {
-      TRY(gemm(true, false, t->dpre, l.cout, x, l.cin, grads + q.w, l.cin, l.cout, l.cin, (int)M, 0, s));
+      TRY(gemm(true, false, t->dpre, l.cout, x, l.cin, grads + q.w, l.cin, l.cout, l.cin, (int)M, 1, s));  // grads are zero: add
       TRY(gemm(false, false, t->dpre, l.cout, params + q.w, l.cin, A(t->dpost, i - 1), l.cin, (int)M, l.cin, l.cout, 1, s));
     }
   }
