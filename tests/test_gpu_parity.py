@@ -212,6 +212,30 @@ def test_bf16_fused_blocks_match_layerwise_same_batch(dev):
 
 
 @pytest.mark.gpu
+def test_bf16_fused_kernels_four_channel_bev(dev):
+  """BASELINE configs[1] input (200x200x4 BEV) on the bf16 encoder: the fused front (stem + features.1 with C = 4:
+  its LDS input band is twice as large, one workgroup per CU), the row-streaming and the tile blocks against the
+  layer-wise kernels on the same 160 observations."""
+  B = 160
+  m = hip_model(33, dev, in_channels=4, max_batch=B)
+  m.encoder_dtype = "bf16"
+  rng = np.random.default_rng(81)
+  ctx = dict(visual_features=torch.from_numpy(rng.random((B, 4, 100, 100), dtype=np.float32)).to(dev),
+             velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
+             is_at_traffic_light=torch.zeros(B, 1, device=dev),
+             traffic_light_state=torch.ones(B, 1, device=dev))
+  m.fused_encoder = 0
+  z_layer = m._params(**ctx).cpu().numpy()
+  for nfused in (1, 17):  # 1: only the front kernel; 17: everything that has a fused kernel
+    m.fused_encoder = nfused
+    z_fused = m._params(**ctx).cpu().numpy()
+    d = np.abs(z_fused - z_layer)
+    print("C=4 bf16 fused=%d vs layer-wise: max|dz| = %.3g of max|z| = %.3g" % (nfused, d.max(), np.abs(z_layer).max()))
+    assert np.isfinite(z_fused).all()
+    assert d.max() <= 0.02 * np.abs(z_layer).max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 3, 9, 130])
 def test_bf16_tile_blocks_ragged_batches(dev, B):
   """encoder_bf16_tile.hip (features.8-17 fused per block): batches that leave the last workgroup's observation
