@@ -25,8 +25,6 @@
 //     persist in registers across the chunks.
 // Epilogue: bias (+ residual from the block input) -> bf16.  Arithmetic order is the layer-wise kernels': MFMA chain
 // over ascending K from zero, then bias; depthwise = bias, then taps in (ky, kx) order; RNE rounding at the same points.
-#include <stdlib.h>
-
 #include "encoder.h"
 
 namespace rip {
@@ -67,6 +65,12 @@ __device__ __forceinline__ f32x2 relu6_2(f32x2 v) {
   return __builtin_elementwise_min(__builtin_elementwise_max(v, f32x2{0.f, 0.f}), f32x2{6.f, 6.f});
 }
 
+// development only (tools/dev/tile_abl.sh rebuilds with -DRIP_TILE_ABL=<bits>; wrong results): 1 = no depthwise,
+// 2 = no matrix work, 4 = no tap loads, 8 = no LDS zeroing, 16 = no epilogue stores
+#ifndef RIP_TILE_ABL
+#define RIP_TILE_ABL 0
+#endif
+
 constexpr int HC = 64;        // hidden channels per chunk
 constexpr int LD = HC + 8;    // bf16 elements per LDS pixel row (odd multiple of 16 bytes)
 
@@ -79,7 +83,6 @@ struct TileArgs {
   int k0;
   size_t we_off, be_off, wd_off, bd_off, wp_off, bp_off;
   int B, HID, residual, G;
-  int abl;  // development: 1 = no depthwise, 2 = no matrix work, 4 = no tap loads, 8 = no weight loads
 };
 
 template <int HIN, int STRIDE, int G>
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // zero both E buffers once: the padding columns are never written again
-  if (!(a.abl & 8))
+  if (!(RIP_TILE_ABL & 8))
     for (int e = tid; e < 2 * Geo::E_ROWS * LD / 8; e += 512) reinterpret_cast<u32x4*>(Ebuf)[e] = zero4;
   __syncthreads();
 
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       }
       if (APF && c + 1 < nch) load_ap(c + 1, 0);  // projected in the next step
     };
-    const bool mx_on = !(a.abl & 2);
+    const bool mx_on = !(RIP_TILE_ABL & 2);
 #pragma unroll 1
     for (int s = 0; s < nch; ++s) {  // steps with an expansion
       if (mx_on) expand(s);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
       const int p = 16 * (w + 4 * t) + n;
-      if (p >= m_out || (a.abl & 16)) continue;
+      if (p >= m_out || (RIP_TILE_ABL & 16)) continue;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         f32x2 v0 = {acc[t][ct][0] + bpj[ct].x, acc[t][ct][1] + bpj[ct].y};
@@ -313,14 +316,14 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
 #pragma unroll 1
     for (int s = 0; s < nch + 2; s += 2) {
       // even step s: depthwise of chunk s-1 (odd buffers), taps of chunk s arrive in set 0
-      if (s >= 1 && s <= nch && dw_on && !(a.abl & 1))
+      if (s >= 1 && s <= nch && dw_on && !(RIP_TILE_ABL & 1))
         depthwise(Ebuf + (size_t)Geo::E_ROWS * LD, Dbuf + (size_t)Geo::D_ROWS * LD, wt[1], bd[1]);
-      if (s + 1 < nch && !(a.abl & 4)) load_taps(s + 1, wt[1], bd[1]);
+      if (s + 1 < nch && !(RIP_TILE_ABL & 4)) load_taps(s + 1, wt[1], bd[1]);
       __syncthreads();
       if (s + 1 >= nch + 2) break;
       // odd step s+1: depthwise of chunk s (even buffers)
-      if (s + 1 <= nch && dw_on && !(a.abl & 1)) depthwise(Ebuf, Dbuf, wt[0], bd[0]);
-      if (s + 2 < nch && !(a.abl & 4)) load_taps(s + 2, wt[0], bd[0]);
+      if (s + 1 <= nch && dw_on && !(RIP_TILE_ABL & 1)) depthwise(Ebuf, Dbuf, wt[0], bd[0]);
+      if (s + 2 < nch && !(RIP_TILE_ABL & 4)) load_taps(s + 2, wt[0], bd[0]);
       __syncthreads();
     }
   }
@@ -383,8 +386,6 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
   a.HID = ld.cout;
   a.residual = lp.residual;
   a.G = 1;
-  a.abl = 0;
-  if (const char* e = getenv("RIP_TILE_ABL")) a.abl = atoi(e);
   const int cin = le->cin, cout = lp.cout;
   //                                          HIN S CIN COUT GMAX AEF APF
   if (ld.h_in == 7 && ld.stride == 1) {
