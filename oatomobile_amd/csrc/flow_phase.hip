@@ -29,7 +29,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int T = 4;
 constexpr int CB = 16;                        // candidates per wave
-constexpr int WPB = 8;                        // waves (= candidate blocks) per workgroup
+constexpr int WPB_MAX = 8;                    // waves (= candidate blocks) per workgroup: 8 (two per SIMD), 4 or 2
 // Adjoint tape of one heavy step, per lane: rows 0..15 = (r, z, n, gh_n) of the 4 unit tiles, rows 16..19 = hprev (not
 // written at t = 1: that is the prefix H1), then ONE dword with the ReLU mask of a1 (8 bits).  A pass has 3 heavy steps.
 constexpr int TAPE_ROWS = 20;
@@ -74,6 +74,7 @@ __device__ __forceinline__ float4 tape_ld(const float4* p) {
   return *p;
 }
 
+template <int WPB>
 struct PShared {
   float4 fbuf[F_ROWS * 64];      // forward operands of the current model
   float4 tbuf[T_ROWS * 64];      // transposed operands of the current model
@@ -596,16 +597,20 @@ __device__ __forceinline__ void pass_backward(const float4* tw, const float4* wq
 }
 
 // ---- operand staging: direct global -> LDS DMA, one 1 KB lane-major row per wave instruction ----
+template <int WPB>
 __device__ __forceinline__ void dma_rows(const float4* __restrict__ src, float4* dst, int rows, int wave, int lane) {
   for (int r = wave; r < rows; r += WPB)
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + r * 64 + lane), (lds_ptr_t)(dst + r * 64), 16, 0, 0);
 }
-__device__ __forceinline__ void load_fbuf(PShared& sh, const float* __restrict__ mwk, int wave, int lane) {
-  dma_rows(reinterpret_cast<const float4*>(mwk), sh.fbuf, F_ROWS, wave, lane);
+template <int WPB>
+__device__ __forceinline__ void load_fbuf(PShared<WPB>& sh, const float* __restrict__ mwk, int wave, int lane) {
+  dma_rows<WPB>(reinterpret_cast<const float4*>(mwk), sh.fbuf, F_ROWS, wave, lane);
 }
-__device__ __forceinline__ void load_tbuf(PShared& sh, const float* __restrict__ mwk, int wave, int lane, int tid) {
+template <int WPB>
+__device__ __forceinline__ void load_tbuf(PShared<WPB>& sh, const float* __restrict__ mwk, int wave, int lane, int tid) {
+  static_assert(WPB * 64 >= 96, "the W_ih^T table is copied by 96 threads");
   const float4* src = reinterpret_cast<const float4*>(mwk + MWF_FLOATS);
-  dma_rows(src, sh.tbuf, T_ROWS, wave, lane);
+  dma_rows<WPB>(src, sh.tbuf, T_ROWS, wave, lane);
   // W_ih^T table: entry (g, q, d) = the lane-major row 57 + g at lane 16 q + d (its 16 rows only differ in m & 1)
   if (tid < 96) sh.wihc[tid] = src[(T_ROWS + (tid >> 3)) * 64 + ((tid & 7) >> 1) * 16 + (tid & 1)];
 }
@@ -650,12 +655,15 @@ __global__ __launch_bounds__(64) void phase_prefix_kernel(SearchArgs a, const fl
 #define TK_STOP(i_)
 #endif
 
-template <bool TRACE>
+// WPB: waves per workgroup.  8 = two per SIMD (full launches); 4 / 2 for launches that would otherwise leave CUs idle
+// (one workgroup per CU holds the operand buffers: 128 observations x 8 blocks are 128 eight-wave workgroups on 256
+// CUs, but 256 four-wave ones).
+template <bool TRACE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, const float* __restrict__ mw_all,
                                                                 const float* __restrict__ pre_all,
                                                                 float4* __restrict__ tape_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  PShared& sh = *reinterpret_cast<PShared*>(smem_raw);
+  PShared<WPB>& sh = *reinterpret_cast<PShared<WPB>*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -862,35 +870,52 @@ bool search_phase_supported(const SearchArgs& a) { return a.K >= 1 && a.K <= MAX
 size_t search_phase_scratch_bytes(int B, int N, int K) {
   if (N < CB) return 0;
   const size_t pre = ((size_t)K * B * PRE_FLOATS * sizeof(float) + 255) / 256 * 256;
-  const size_t items = ((size_t)B * (N / CB) + WPB - 1) / WPB * WPB;
+  const size_t items = ((size_t)B * (N / CB) + WPB_MAX - 1) / WPB_MAX * WPB_MAX;
   return pre + items * 2 * TAPE_SLOT_F4 * sizeof(float4);
 }
 
-hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* scratch, hipStream_t s) {
+namespace {
+template <int WPB>
+hipError_t launch_phase_wpb(const SearchArgs& a, const float* mw_all, const float* pre, float4* tape, int items, hipStream_t s) {
   static bool attr_set[16] = {false};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 16 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_phase_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_phase_kernel<false, WPB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared<WPB>));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_phase_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_phase_kernel<true, WPB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared<WPB>));
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
+  const dim3 grid((items + WPB - 1) / WPB);
+  if (wants_trace(a))
+    hipLaunchKernelGGL((search_phase_kernel<true, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mw_all, pre, tape);
+  else
+    hipLaunchKernelGGL((search_phase_kernel<false, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mw_all, pre, tape);
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* scratch, hipStream_t s) {
   float* pre = reinterpret_cast<float*>(scratch);
   const size_t pre_bytes = ((size_t)a.K * a.B * PRE_FLOATS * sizeof(float) + 255) / 256 * 256;
   float4* tape = reinterpret_cast<float4*>(reinterpret_cast<char*>(scratch) + pre_bytes);
   hipLaunchKernelGGL(phase_prefix_kernel, dim3(a.B, a.K), dim3(64), 0, s, a, mw_all, pre);
   const int items = a.B * (a.N / CB);
-  const dim3 grid((items + WPB - 1) / WPB);
-  if (wants_trace(a))
-    hipLaunchKernelGGL(search_phase_kernel<true>, grid, dim3(WPB * 64), sizeof(PShared), s, a, mw_all, pre, tape);
-  else
-    hipLaunchKernelGGL(search_phase_kernel<false>, grid, dim3(WPB * 64), sizeof(PShared), s, a, mw_all, pre, tape);
-  return hipGetLastError();
+  // waves per workgroup: as many as keep ~256 workgroups (one per CU: the operand buffers fill its LDS) in the launch
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  if (items >= 8 * cus) return launch_phase_wpb<8>(a, mw_all, pre, tape, items, s);
+  if (items >= 4 * cus) return launch_phase_wpb<4>(a, mw_all, pre, tape, items, s);
+  return launch_phase_wpb<2>(a, mw_all, pre, tape, items, s);
 }
 
 }  // namespace rip

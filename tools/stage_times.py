@@ -16,6 +16,7 @@ def main():
   ap.add_argument("--algorithm", default="WCM")
   ap.add_argument("--enc", default="fp32")
   ap.add_argument("--fused", type=int, default=-1, help="RIP_OPT_ENCODER_FUSED (-1 = auto)")
+  ap.add_argument("--search-kernel", type=int, default=0, help="RIP_OPT_SEARCH_KERNEL (0 auto, 1 chain, 2 mfma, 3 phase)")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
   dev = torch.device("cuda", 0)
@@ -24,6 +25,7 @@ def main():
   agent = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, max_batch=B, device=dev)
   lib, h = _lib.load(), agent._handle.raw
   _lib.check(lib.rip_set_option(h, 1, args.fused))
+  _lib.check(lib.rip_set_option(h, 0, args.search_kernel))
   lidar, vec, goal = (torch.from_numpy(a).to(dev) for a in synth_batch(np.random.default_rng(0), B, 2))
   x0 = agent._x0(B)
   z = torch.empty(K, B, 64, device=dev); plan = torch.empty(B, 4, 2, device=dev); loss = torch.empty(B, N, device=dev)
