@@ -254,7 +254,7 @@ int rip_train_peek(rip_trainer* t, int layer, int what, int B, float* dst_dev, s
 int rip_train_num_layers(const rip_trainer* t);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
- *   RIP_OPT_SEARCH_KERNEL: 0 = auto (phase-sequential MFMA kernel when B*N >= 2048 and N % 16 == 0, else
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (phase-sequential MFMA kernel when B*N >= 2304 and N % 16 == 0, else
  *     wave-per-chain),
  *     1 = wave-per-chain kernel (lowest latency, any K/N),
  *     2 = MFMA wave-per-model pipeline (16 candidates per wave, wave k = model k; N % 16 == 0, K <= 4; N % 32 == 0

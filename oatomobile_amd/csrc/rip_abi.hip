@@ -402,7 +402,9 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
   // wave-per-chain kernel has the lower latency for a single observation.  Among the MFMA kernels the phase-sequential
   // one (operands in LDS, two waves per SIMD, any K) is the default; mode 2 keeps the wave-per-model pipeline.
-  const bool big = (size_t)B * N >= 2048;
+  // crossover measured at K = 4, N = 128: the chain kernel costs 64 us per observation, the phase kernel 1.1 ms per
+  // launch up to one workgroup per CU (B = 16: 1.02 vs 1.11 ms, B = 32: 2.03 vs 1.11 ms)
+  const bool big = (size_t)B * N >= 2304;
   int kernel = 1;
   if (h->search_mode == 3 || (h->search_mode == 0 && big && search_phase_supported(a))) kernel = 3;
   if (h->search_mode == 2) kernel = 2;

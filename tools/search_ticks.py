@@ -13,6 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if __name__ == "__main__":
   env = dict(os.environ, RIP_EXTRA_HIPCC_FLAGS="-DRIP_PROFILE_TICKS")
   subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], check=True, cwd=ROOT, env=env)
-  subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), "--obs-batch", "512", "--iters", "1",
+  subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), "--obs-batch", os.environ.get("TICKS_B", "512"), "--iters", "1",
                   "--enc", "bf16"] + sys.argv[1:], cwd=ROOT, env=env)
   subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], check=True, cwd=ROOT)
