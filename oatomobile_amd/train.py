@@ -104,7 +104,8 @@ class DIMTrainer:
 
   def apply(self) -> None:
     """train.py:211: `optimizer.step()` — torch.optim.Adam defaults; with `group`, the gradients are averaged over
-    the ranks first (DistributedDataParallel semantics)."""
+    the ranks first (DistributedDataParallel semantics; BatchNorm running statistics stay per-rank buffers, there is
+    no SyncBatchNorm)."""
     dist = torch.distributed
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
       dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._group)
