@@ -627,12 +627,81 @@ __global__ void act_bwd_kernel(const float* __restrict__ dpost, const float* __r
   g[idx] = v;
 }
 
+// act_bwd_kernel + colstats_kernel<STAT_BWD> in one pass (C % 4 == 0): g = dpost masked by the ReLU6 derivative is
+// written AND reduced (sum g, sum g xhat) where it is produced; same thread <-> rows mapping and accumulation order as
+// colstats_kernel.
+__global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restrict__ dpost, const float* __restrict__ post,
+                                                            const float* __restrict__ pre, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ g,
+                                                            float* __restrict__ dres, float* __restrict__ out, size_t M,
+                                                            int C, int rows_per_block, int relu6) {
+  extern __shared__ float sm[];  // [2*C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const int C4 = C >> 2;
+  const int RL = C4 <= 256 ? 256 / C4 : 1;
+  const float4* d4 = reinterpret_cast<const float4*>(dpost);
+  const float4* p4 = reinterpret_cast<const float4*>(post);
+  const float4* y4 = reinterpret_cast<const float4*>(pre);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* r4 = reinterpret_cast<float4*>(dres);
+  for (int g0 = 0; g0 < C4; g0 += 256) {
+    const int c4 = C4 <= 256 ? (int)(threadIdx.x % C4) : g0 + (int)threadIdx.x;
+    const int rl = C4 <= 256 ? (int)(threadIdx.x / C4) : 0;
+    if (c4 < C4 && rl < RL) {
+      const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
+      const float4 is = *reinterpret_cast<const float4*>(invstd + 4 * c4);
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+      for (size_t r = r0 + rl; r < r1; r += RL) {
+        const size_t e = r * C4 + c4;
+        const float4 d = d4[e];
+        if (dres != nullptr) {
+          float4 o = r4[e];
+          o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+          r4[e] = o;
+        }
+        float4 v = d;
+        if (relu6) {
+          const float4 y = p4[e];
+          v.x = (y.x > 0.f && y.x < 6.f) ? d.x : 0.f;
+          v.y = (y.y > 0.f && y.y < 6.f) ? d.y : 0.f;
+          v.z = (y.z > 0.f && y.z < 6.f) ? d.z : 0.f;
+          v.w = (y.w > 0.f && y.w < 6.f) ? d.w : 0.f;
+        }
+        g4[e] = v;
+        const float4 yy = y4[e];
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x = fmaf(v.x, (yy.x - mu.x) * is.x, s2.x);
+        s2.y = fmaf(v.y, (yy.y - mu.y) * is.y, s2.y);
+        s2.z = fmaf(v.z, (yy.z - mu.z) * is.z, s2.z);
+        s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
+      }
+      atomicAdd(&sm[4 * c4 + 0], s1.x); atomicAdd(&sm[4 * c4 + 1], s1.y);
+      atomicAdd(&sm[4 * c4 + 2], s1.z); atomicAdd(&sm[4 * c4 + 3], s1.w);
+      atomicAdd(&sm[C + 4 * c4 + 0], s2.x); atomicAdd(&sm[C + 4 * c4 + 1], s2.y);
+      atomicAdd(&sm[C + 4 * c4 + 2], s2.z); atomicAdd(&sm[C + 4 * c4 + 3], s2.w);
+    }
+    if (C4 <= 256) break;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&out[i], sm[i]);
+}
+
 // sums2 = (sum g, sum g * xhat) per channel = (dbeta, dgamma) and
 // dpre = gamma invstd (g - dbeta/M - xhat dgamma/M)   (batch statistics)   |   gamma invstd g   (running statistics)
+// (block 0 also writes dgamma / dbeta = sums2)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ pre,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ sums2,
-                                    float* __restrict__ dpre, size_t total, int C, size_t M, int batch_stats) {
+                                    float* __restrict__ dpre, size_t total, int C, size_t M, int batch_stats,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dbeta[c] = sums2[c];
+      dgamma[c] = sums2[C + c];
+    }
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int c = idx % C;
@@ -644,15 +713,6 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
   }
   dpre[idx] = gamma[c] * is * v;
 }
-__global__ void bn_param_grads_kernel(const float* __restrict__ sums2, const float* __restrict__ mean,
-                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  dbeta[c] = sums2[c];
-  dgamma[c] = sums2[C + c];
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // tail: average pool, dropout, bias / ReLU, concat
 // ------------------------------------------------------------------------------------------------------------
@@ -1014,17 +1074,20 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     const float* mean = t->stats + stat_off[i];
     const float* invstd = mean + l.cout;
     float* dres = q.block_in >= 0 ? A(t->dpost, q.block_in) : nullptr;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, A(t->dpost, i), A(t->post, i), t->gbuf, dres, total,
-                       l.relu6);
-    // NOTE: for residual layers `post` holds bn + res; they carry no ReLU6, so the mask is not needed there
     float* sums_b = t->sums + t->stats_floats + stat_off[i];
     const int rpb = (int)std::max<size_t>(64, (M + 2047) / 2048);
-    hipLaunchKernelGGL(colstats_kernel<STAT_BWD>, dim3(nblk(M, rpb)), dim3(256), 2 * l.cout * sizeof(float), s, t->gbuf,
-                       A(t->pre, i), mean, invstd, sums_b, M, l.cout, rpb);
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(nblk(l.cout)), dim3(256), 0, s, sums_b, mean, invstd, grads + q.gamma,
-                       grads + q.beta, l.cout);
+    // NOTE: for residual layers `post` holds bn + res; they carry no ReLU6, so the mask is not needed there
+    if ((l.cout & 3) == 0) {
+      hipLaunchKernelGGL(act_bwd_stats_kernel, dim3(nblk(M, rpb)), dim3(256), 2 * l.cout * sizeof(float), s, A(t->dpost, i),
+                         A(t->post, i), A(t->pre, i), mean, invstd, t->gbuf, dres, sums_b, M, l.cout, rpb, l.relu6);
+    } else {
+      hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, A(t->dpost, i), A(t->post, i), t->gbuf, dres,
+                         total, l.relu6);
+      hipLaunchKernelGGL(colstats_kernel<STAT_BWD>, dim3(nblk(M, rpb)), dim3(256), 2 * l.cout * sizeof(float), s, t->gbuf,
+                         A(t->pre, i), mean, invstd, sums_b, M, l.cout, rpb);
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(total)), dim3(256), 0, s, t->gbuf, A(t->pre, i), mean, invstd,
-                       params + q.gamma, sums_b, t->dpre, total, l.cout, M, batch_stats);
+                       params + q.gamma, sums_b, t->dpre, total, l.cout, M, batch_stats, grads + q.gamma, grads + q.beta);
     const float* x = i == 0 ? visual : A(t->post, i - 1);
     if (l.kind == L_STEM) {
       const int ppb = 512;
