@@ -264,9 +264,10 @@ int rip_train_num_layers(const rip_trainer* t);
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.
- *     bf16 encoder: the fused row-streaming kernel covers features.2 .. features.7 (blocks 1..6 of the count;
- *     features.1 and the 7x7 / 4x4 stages always run layer by layer); auto = 7 when the call carries >= 256
- *     (model, observation) pairs, else 0. */
+ *     bf16 encoder: count >= 1 fuses the stem with features.1 (one kernel), blocks 1..6 of the count are the
+ *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
+ *     features.17 / 18 always run layer by layer.  auto = everything, the tile kernel only when the call carries
+ *     >= 64 (model, observation) pairs (an explicit count uses it regardless). */
 enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1 };
 int rip_set_option(rip_handle* h, int option, int value);
 

@@ -1077,12 +1077,13 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
                                float* feat, int fused_blocks, hipStream_t s) {
   const size_t ms = plan.blob_floats;
-  // inverted-residual blocks as one fused kernel each.  auto: the row-streaming blocks (features.2-7) whenever a
-  // launch has >= 256 (model, observation) pairs to spread over the CUs, the tile blocks (features.8-16) from 1024
-  // pairs (one workgroup owns up to 4-8 observations; below that the layer-wise GEMMs fill the chip better)
+  // inverted-residual blocks as one fused kernel each.  auto (measured, K = 4): the front kernel and the row-streaming
+  // blocks (features.0-7) win at every batch size (B = 1: 304 vs 311 us, B = 4: 359 vs 401); the tile blocks
+  // (features.8-16, one workgroup per 1-8 observations walking 6-15 hidden chunks in sequence) from 64 (model,
+  // observation) pairs (B = 16: 481 vs ~500 us, B = 128: 779 vs 916; B = 1: 442 vs 304)
   const bool auto_sel = fused_blocks < 0;
-  const bool tile_ok = !auto_sel || (long)B * kc >= 1024;
-  if (auto_sel) fused_blocks = (long)B * kc >= 256 ? 17 : 0;
+  const bool tile_ok = !auto_sel || (long)B * kc >= 64;
+  if (auto_sel) fused_blocks = 17;
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
   std::vector<char> tiled(plan.blocks.size(), 0);
