@@ -471,6 +471,47 @@ __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ act,
   }
 }
 
+// classifier on the matrix cores for already pooled features (HW == 1: the bf16 encoder's features.18 epilogue pools):
+// one wave = 16 observations x 16 outputs on v_mfma_f32_16x16x4_f32, both operands read as 16-byte groups along K
+// (lane (n, q) holds k = 16 j + 4 q + e of row n: MFMA e of group j contracts the four k with that e — a partition of
+// K, so the order of the instruction's internal k does not matter).  fp32 in, fp32 accumulate; the summation order
+// differs from cls_kernel's lane-strided chain (last-bit differences).  62 -> 26 us at 512 observations x 4 models.
+__global__ __launch_bounds__(256) void cls_mfma_kernel(const float* __restrict__ pooled, const float* __restrict__ wbase,
+                                                        size_t model_stride, int k0, size_t cls_w, size_t cls_b, int B,
+                                                        float* __restrict__ feat) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.y;
+  const int bt = blockIdx.x * 4 + wave;   // 16-observation tile
+  const int ot = blockIdx.z;              // 16-output tile
+  if (bt * 16 >= B) return;
+  const float* W = wbase + (size_t)(k0 + k) * model_stride;
+  const int b = min(bt * 16 + n, B - 1);  // rows past B are computed on a valid row and not stored
+  const float4* xr = reinterpret_cast<const float4*>(pooled + ((size_t)k * B + b) * LAST_C) + q;
+  const float4* wr = reinterpret_cast<const float4*>(W + cls_w + (size_t)(ot * 16 + n) * LAST_C) + q;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 4
+  for (int j = 0; j < LAST_C / 16; ++j) {
+    const float4 a = wr[4 * j], x = xr[4 * j];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, acc1, 0, 0, 0);
+  }
+  // lane (n = observation, q): outputs 4 q + r
+  const int bo = bt * 16 + n;
+  if (bo < B) {
+    const float4 bias = *reinterpret_cast<const float4*>(W + cls_b + ot * 16 + 4 * q);
+    float4 o;
+    o.x = acc0[0] + acc1[0] + bias.x;
+    o.y = acc0[1] + acc1[1] + bias.y;
+    o.z = acc0[2] + acc1[2] + bias.z;
+    o.w = acc0[3] + acc1[3] + bias.w;
+    *reinterpret_cast<float4*>(feat + ((size_t)k * B + bo) * FEAT + ot * 16 + 4 * q) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K6: cat(feat128, vec5) -> merger 3x(Linear+ReLU) (dim/model.py:206-217).  One wave per (obs, model):
 // lane j owns output unit j, inputs broadcast from LDS.
@@ -798,8 +839,12 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
   const size_t ms = plan.blob_floats;
   // classifier logits go to `feat` if the caller wants them, else to scratch
   float* feat_buf = feat != nullptr ? feat : scratch;
-  hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, act_last,
-                     enc_w, ms, k0, plan.cls_w_off, plan.cls_b_off, B, hw, feat_buf);
+  if (hw == 1 && B >= 16)
+    hipLaunchKernelGGL(cls_mfma_kernel, dim3((B + 63) / 64, kc, FEAT / 16), dim3(256), 0, s, act_last, enc_w, ms, k0,
+                       plan.cls_w_off, plan.cls_b_off, B, feat_buf);
+  else
+    hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, act_last,
+                       enc_w, ms, k0, plan.cls_w_off, plan.cls_b_off, B, hw, feat_buf);
   hipLaunchKernelGGL(merger_kernel, dim3(B, kc), dim3(64), 0, s, (const float*)feat_buf, enc_w, ms, k0,
                      plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1], plan.mrg_b_off[1], plan.mrg_w_off[2],
                      plan.mrg_b_off[2], vec, B, z);
