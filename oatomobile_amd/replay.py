@@ -215,7 +215,26 @@ class DatumBatches:
     if not self._files:
       return
     nb = len(self)
-    if self._workers <= 0:
+    slots = None
+    if self._workers > 0:
+      from multiprocessing import shared_memory
+      ring = self._prefetch + 1
+      try:
+        slots = []
+        for _ in range(ring):
+          slot = []
+          slots.append(slot)
+          for shp in self._shapes:
+            slot.append(shared_memory.SharedMemory(create=True, size=int(np.prod(shp)) * 4))
+      except OSError as exc:  # /dev/shm too small for the batch ring: decode inline instead of failing the replay
+        import warnings
+        for slot in slots or []:
+          for blk in slot:
+            blk.close()
+            blk.unlink()
+        slots = None
+        warnings.warn("DatumBatches: no shared memory for %d batch buffers (%s); decoding in this process" % (ring, exc))
+    if slots is None:
       pinned = torch.cuda.is_available()
       arrs = [torch.empty(s).pin_memory() if pinned else torch.empty(s) for s in self._shapes]
       views = [a.numpy() for a in arrs]
@@ -225,12 +244,10 @@ class DatumBatches:
       return
     import multiprocessing as mp
     import time
-    from multiprocessing import shared_memory
-    ring = self._prefetch + 1
     nw = min(self._workers, self._bs)
     head = done = None
+    self._shm = [b for slot in slots for b in slot]
     try:
-      slots = [[shared_memory.SharedMemory(create=True, size=int(np.prod(s)) * 4) for s in self._shapes] for _ in range(ring)]
       ctrl = shared_memory.SharedMemory(create=True, size=16 + nw * nb)
       self._shm = [b for slot in slots for b in slot] + [ctrl]
       head = np.ndarray((2,), np.int64, buffer=ctrl.buf)
