@@ -56,6 +56,11 @@ __device__ __forceinline__ f32x2 relu6_2(f32x2 v) {
   return __builtin_elementwise_min(__builtin_elementwise_max(v, f32x2{0.f, 0.f}), f32x2{6.f, 6.f});
 }
 
+// development only (wrong results): 1 = no stem arithmetic, 2 = no depthwise / projection / stores, 4 = no input loads
+#ifndef RIP_FRONT_ABL
+#define RIP_FRONT_ABL 0
+#endif
+
 constexpr int RB = 10;        // output rows per workgroup
 constexpr int SC = 32;        // stem channels
 constexpr int OC = 16;        // features.1 output channels
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
         const int cr = e / q4, x4 = e - cr * q4;
         const int c = cr / IR, r = cr - c * IR;
         const int iy = iy0 + r;
-        v[j] = (e < total && iy >= 0 && iy < HI)
+        v[j] = (!(RIP_FRONT_ABL & 4) && e < total && iy >= 0 && iy < HI)
                    ? *reinterpret_cast<const u32x4*>(a.in + ((size_t)b * C + c) * HI * HI + (size_t)iy * HI + 4 * x4)
                    : zero4;
       }
@@ -160,6 +165,15 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
   {
     const float* bias = W + a.bs_off;
     const int npg = (HS + 3) >> 2;
+    f32x2 wreg[18][2];
+    if (C == 2) {
+#pragma unroll
+      for (int t = 0; t < 18; ++t) {  // t = (ky * 3 + kx) * C + c: the blob's tap order
+        const float4 w = *reinterpret_cast<const float4*>(wsm + t * SC + 4 * (tid & 7));
+        wreg[t][0] = f32x2{w.x, w.y};
+        wreg[t][1] = f32x2{w.z, w.w};
+      }
+    }
     for (int e = tid; e < (rows + 2) * npg * 8; e += 256) {
       const int c4 = e & 7, pr = e >> 3;
       const int r = pr / npg, pg = pr - r * npg;
@@ -174,7 +188,30 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
           acc[i][1] = f32x2{b0.z, b0.w};
         }
       }
-      if (rok) {
+      if (rok && !(RIP_FRONT_ABL & 1) && C == 2) {
+        // C == 2 (the LIDAR sensor's BEV): this thread's 18 x 4 tap weights live in registers (its channel group is
+        // fixed: e & 7 == tid & 7) -- half of the stem's LDS reads were tap reads, and the stem was LDS-bound
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float* xr = xs + ((size_t)c * IR + 2 * r + ky) * IW + 8 * pg;
+            const float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 4);
+            const float4 x2 = *reinterpret_cast<const float4*>(xr + 8);
+            const float x[9] = {x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const f32x2 w01 = wreg[(ky * 3 + kx) * 2 + c][0], w23 = wreg[(ky * 3 + kx) * 2 + c][1];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const f32x2 v = {x[2 * i + kx], x[2 * i + kx]};
+                acc[i][0] = __builtin_elementwise_fma(v, w01, acc[i][0]);
+                acc[i][1] = __builtin_elementwise_fma(v, w23, acc[i][1]);
+              }
+            }
+          }
+        }
+      } else if (rok && !(RIP_FRONT_ABL & 1)) {
         for (int c = 0; c < C; ++c) {
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
@@ -215,36 +252,51 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
   // ---- 3. depthwise + projection, one 16-pixel tile per wave at a time ----
   bf16_t* og = a.out + (((size_t)k * a.B + b) * HS + oy0) * HS * OC;
   const int P = rows * HS, ntiles = (P + 15) >> 4;
-  for (int tile = wv; tile < ntiles; tile += 4) {
-    const int p = 16 * tile + n;
-    const bool valid = p < P;
-    const int pc = valid ? p : P - 1;
-    const int oyl = pc / HS, ox = pc - oyl * HS;
-    // window origin: stem row oyl (= output row - 1), padded column ox (= pixel column - 1)
-    const bf16_t* sp = ss + ((size_t)oyl * SW + ox) * SC + 8 * q;
-    f32x2 s[4] = {bd[0], bd[1], bd[2], bd[3]};
+  // two tiles per trip: the 18 window reads of both are requested before the first value is unpacked, so one tile's
+  // LDS / MFMA latency is covered by the other's arithmetic (the loop bound is a run-time value: no unrolling by
+  // the compiler)
+  for (int tile0 = wv; tile0 < ((RIP_FRONT_ABL & 2) ? 0 : ntiles); tile0 += 8) {
+    u32x4 v[2][9];
+    int pp[2];
+    bool val[2];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int u = 0; u < 2; ++u) {
+      const int tile = tile0 + 4 * u;
+      const int p = 16 * tile + n;
+      val[u] = tile < ntiles && p < P;
+      pp[u] = p;
+      const int pc = val[u] ? p : P - 1;
+      const int oyl = pc / HS, ox = pc - oyl * HS;
+      // window origin: stem row oyl (= output row - 1), padded column ox (= pixel column - 1)
+      const bf16_t* sp = ss + ((size_t)oyl * SW + ox) * SC + 8 * q;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(sp + ((size_t)ky * SW + kx) * SC);
-        const int t = ky * 3 + kx;
-        s[0] = __builtin_elementwise_fma(bfpair(v.x), wt[t][0], s[0]);
-        s[1] = __builtin_elementwise_fma(bfpair(v.y), wt[t][1], s[1]);
-        s[2] = __builtin_elementwise_fma(bfpair(v.z), wt[t][2], s[2]);
-        s[3] = __builtin_elementwise_fma(bfpair(v.w), wt[t][3], s[3]);
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v[u][ky * 3 + kx] = *reinterpret_cast<const u32x4*>(sp + ((size_t)ky * SW + kx) * SC);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (tile0 + 4 * u >= ntiles) break;  // wave-uniform
+      f32x2 s[4] = {bd[0], bd[1], bd[2], bd[3]};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        s[0] = __builtin_elementwise_fma(bfpair(v[u][t].x), wt[t][0], s[0]);
+        s[1] = __builtin_elementwise_fma(bfpair(v[u][t].y), wt[t][1], s[1]);
+        s[2] = __builtin_elementwise_fma(bfpair(v[u][t].z), wt[t][2], s[2]);
+        s[3] = __builtin_elementwise_fma(bfpair(v[u][t].w), wt[t][3], s[3]);
       }
-    u32x4 d;
-    d.x = pack_bf16(relu6_2(s[0]));
-    d.y = pack_bf16(relu6_2(s[1]));
-    d.z = pack_bf16(relu6_2(s[2]));
-    d.w = pack_bf16(relu6_2(s[3]));
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(apj), as_bf16x8(d), z4, 0, 0, 0);
-    u32x2 o;
-    o.x = pack_bf16(f32x2{c[0] + bpj.x, c[1] + bpj.y});
-    o.y = pack_bf16(f32x2{c[2] + bpj.z, c[3] + bpj.w});
-    if (valid) *reinterpret_cast<u32x2*>(og + (size_t)p * OC + 4 * q) = o;
+      u32x4 d;
+      d.x = pack_bf16(relu6_2(s[0]));
+      d.y = pack_bf16(relu6_2(s[1]));
+      d.z = pack_bf16(relu6_2(s[2]));
+      d.w = pack_bf16(relu6_2(s[3]));
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(apj), as_bf16x8(d), z4, 0, 0, 0);
+      u32x2 o;
+      o.x = pack_bf16(f32x2{c[0] + bpj.x, c[1] + bpj.y});
+      o.y = pack_bf16(f32x2{c[2] + bpj.z, c[3] + bpj.w});
+      if (val[u]) *reinterpret_cast<u32x2*>(og + (size_t)pp[u] * OC + 4 * q) = o;
+    }
   }
 }
 
