@@ -57,7 +57,9 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3  # packed fp32 FMA on the vector ALUs
 # MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 flop each) of the passes of search_phase_kernel, per 16-candidate
 # block (flow_phase.hip: fwd_step_lds = 251; adjoint step = 274, 82 at t = T-1)
 MFMA_FWD_PASS = 3 * 251
-MFMA_ADJ_PASS = 2 * 274 + 82
+MFMA_ADJ_PASS = 2 * 274 + 82  # + 4 per step whose tape is read back (gi_n for the recomputed n): see below
+MFMA_ADJ_INV = MFMA_ADJ_PASS + 2 * 4   # inverse passes: steps 2, 1 from the tape, step 3 from registers
+MFMA_ADJ_FWD = MFMA_ADJ_PASS + 3 * 4   # F_0's adjoint: all three steps from the tape
 MFMA_PREFIX = 251
 
 
@@ -334,8 +336,8 @@ def main():
       run = (sign * tp).cummax(dim=1).values  # running best over models 0..k
       take = (sign * tp[:, 1:]) > run[:, :-1]  # [S,K-1,B,N]: strictly better than every earlier model
       adj_passes = float(take.view(S, K - 1, B, N // 16, 16).any(-1).sum().item())
-    mfma = blocks16 * ((S + 1) * MFMA_FWD_PASS + S * MFMA_ADJ_PASS + S * (K - 1) * MFMA_FWD_PASS) + \
-        adj_passes * MFMA_ADJ_PASS + B * K * MFMA_PREFIX
+    mfma = blocks16 * ((S + 1) * MFMA_FWD_PASS + S * MFMA_ADJ_FWD + S * (K - 1) * MFMA_FWD_PASS) + \
+        adj_passes * MFMA_ADJ_INV + B * K * MFMA_PREFIX
     exec_flops = mfma * 2048.0
     extras["adjoint_inverse_passes_executed"] = adj_passes
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
@@ -386,9 +388,10 @@ def main():
         "unit": "TFLOP/s",
         "frac": exec_tf / PEAK_FP32_TFLOPS if exec_tf else None,
         # L2 <-> fabric bytes per launch: the adjoint tape, written once and read back once per 16-candidate block,
-        # model and Adam step (F_0: 3 steps, inverses: 2 steps, the third stays in registers; a step is 16 or 20 rows
-        # of 1 KiB + 256 B of ReLU mask); rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE (profiles/)
-        "traffic": (2.0 * blocks16 * S * ((16 + 20 + 20) * 1024 + 3 * 256 + (K - 1) * ((16 + 20) * 1024 + 2 * 256))) if use_mfma else None,
+        # model and Adam step (F_0: 3 steps, inverses: 2 steps, the third stays in registers; a step is 12 or 16 rows
+        # of 1 KiB -- r, z, gh_n, hprev; n is recomputed -- + 256 B of ReLU mask); rocprofv3 FETCH_SIZE (x2 gfx950
+        # correction) + WRITE_SIZE (profiles/)
+        "traffic": (2.0 * blocks16 * S * ((12 + 16 + 16) * 1024 + 3 * 256 + (K - 1) * ((12 + 16) * 1024 + 2 * 256))) if use_mfma else None,
         "ms_per_launch": search_ms,
         "contract_tflops": flow_flops / (search_ms * 1e-3) / 1e12,
         "contract_over_peak": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,

@@ -60,6 +60,11 @@ __device__ __forceinline__ f32x4 zero4() {
 #define PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 
+// the adjoint recomputes n = tanh(gi_n + r * gh_n) from the taped r and gh_n (one 4-MFMA k-step for gi_n and 16 tanh per
+// step) instead of reading it back: 16 instead of 20 rows per taped step (RIP_TAPE_N = 1 restores the taped n)
+#ifndef RIP_TAPE_N
+#define RIP_TAPE_N 0
+#endif
 #ifndef RIP_PREFETCH
 #define RIP_PREFETCH 1  // operand rows requested one MFMA group ahead (development switch)
 #endif
@@ -206,7 +211,7 @@ __device__ __forceinline__ void fwd_step_lds(const float4* wl, float (&H)[16], f
     if (SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) {
       tape_st(trow(tape, up * 4 + 0, loff), rr[0], rr[1], rr[2], rr[3]);
       tape_st(trow(tape, up * 4 + 1, loff), zz[0], zz[1], zz[2], zz[3]);
-      tape_st(trow(tape, up * 4 + 2, loff), nn[0], nn[1], nn[2], nn[3]);
+      if (RIP_TAPE_N) tape_st(trow(tape, up * 4 + 2, loff), nn[0], nn[1], nn[2], nn[3]);
       tape_st(trow(tape, up * 4 + 3, loff), ahn[0], ahn[1], ahn[2], ahn[3]);
       if (SAVE == SAVE_TAPE) tape_st(trow(tape, 16 + up, loff), H[up * 4], H[up * 4 + 1], H[up * 4 + 2], H[up * 4 + 3]);
     }
@@ -412,7 +417,8 @@ __device__ __forceinline__ PassOut pass_forward(const float4* wl, const Prefix16
 // `tp` (global) — all rows requested BEFORE the contraction, so their latency hides under its 34 / 226 MFMAs.
 // HP_PREFIX (t = 1): hprev is the prefix H1 (`hp1`).  FIRST (t = T-1): nothing flows in from a later step.
 template <int MODE, int TS, bool FROM_REGS>
-__device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_in, const float (*gin)[8],
+__device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_in, const float4* wl_in,
+                                         const float (*io)[8], const float (*gin)[8],
                                          const float (*st)[6][CB], const float4* __restrict__ tp, const StepTape* tr,
                                          const float* hp1, int c, int q, float w0, float (&dhz)[16], float (&dgh)[48],
                                          float& carry0, float& carry1, float (&res)[8]) {
@@ -433,7 +439,9 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
 #pragma unroll
     for (int up = 0; up < 4; ++up) {
       const float4 rr = tape_ld(trow(tp, up * 4 + 0, loff)), zz = tape_ld(trow(tp, up * 4 + 1, loff));
-      const float4 nn = tape_ld(trow(tp, up * 4 + 2, loff)), gh = tape_ld(trow(tp, up * 4 + 3, loff));
+      const float4 gh = tape_ld(trow(tp, up * 4 + 3, loff));
+      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (RIP_TAPE_N) nn = tape_ld(trow(tp, up * 4 + 2, loff));
       float4 hp;
       if (TS == 1)
         hp = *reinterpret_cast<const float4*>(hp1 + 16 * up + 4 * q);  // prefix H1 (global, L2): units 16 up + 4 q + r
@@ -517,12 +525,44 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
   PRIO_VALU();
   // ---- GRUCell adjoint, lane-local in the H layout (unit pairs: v_pk_mul_f32 / v_pk_fma_f32) ----
   using f2 = __attribute__((ext_vector_type(2))) float;
+  // gi_n of this step = the (W_in[.][0], W_in[.][1], b_in, 0) k-step on the step's input y_{t-1} (still in `io`),
+  // issued after the contraction (16 accumulator registers held across it were spilled); then the same expressions as
+  // gru_gates
+  f32x4 agn_t[4];
+  if (!FROM_REGS && !RIP_TAPE_N) {
+    const float4 wxg = (wl_in + zero)[50 * 64];
+    const float yp0 = io[c][2 * (TS - 1)], yp1 = io[c][2 * (TS - 1) + 1];
+    const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
+    agn_t[0] = mfma(wxg.x, bin, zero4());
+    agn_t[1] = mfma(wxg.y, bin, zero4());
+    agn_t[2] = mfma(wxg.z, bin, zero4());
+    agn_t[3] = mfma(wxg.w, bin, zero4());
+  }
+  float nrec[16];
+  if (!FROM_REGS && !RIP_TAPE_N) {
+    constexpr float L2E = 1.4426950408889634f;
+    const f2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const f2 r2 = {tl.r[i], tl.r[i + 1]}, ghn = {tl.gh[i], tl.gh[i + 1]};
+      const f2 gin2 = {agn_t[i >> 2][i & 3], agn_t[i >> 2][(i & 3) + 1]};
+      const f2 pre = __builtin_elementwise_fma(r2, ghn, gin2);
+      const f2 pn = pre * f2{2.0f * L2E, 2.0f * L2E};
+      const f2 en = {__builtin_amdgcn_exp2f(pn.x), __builtin_amdgcn_exp2f(pn.y)};
+      const f2 dn = en + one;
+      const f2 in2 = {rcpf_(dn.x), rcpf_(dn.y)};
+      const f2 n2 = one - two * in2;
+      nrec[i] = n2.x;
+      nrec[i + 1] = n2.y;
+    }
+  }
   const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
   float dpn[16];
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {
     const f2 hp2 = {tv->hp[i], tv->hp[i + 1]}, rr2 = {tv->r[i], tv->r[i + 1]}, zz2 = {tv->z[i], tv->z[i + 1]};
-    const f2 nn2 = {tv->n[i], tv->n[i + 1]}, gh2 = {tv->gh[i], tv->gh[i + 1]};
+    const bool n_taped = FROM_REGS || RIP_TAPE_N;
+    const f2 nn2 = {n_taped ? tv->n[i] : nrec[i], n_taped ? tv->n[i + 1] : nrec[i + 1]}, gh2 = {tv->gh[i], tv->gh[i + 1]};
     const f2 one = {1.0f, 1.0f};
     f2 dh = {accs[i >> 2][i & 3], accs[i >> 2][(i & 3) + 1]};
     if (!FIRST) dh = dh + f2{dhz[i], dhz[i + 1]};
@@ -572,7 +612,8 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
 // All gate gradients are registers: the 8 + 48 entries of the dh contraction are unrolled, their A operands are
 // ds_read_b128 at static offsets.
 template <int MODE>
-__device__ __forceinline__ void pass_backward(const float4* tw, const float4* wq4, const float (*gin)[8],
+__device__ __forceinline__ void pass_backward(const float4* tw, const float4* wq4, const float4* wl, const float (*io)[8],
+                                              const float (*gin)[8],
                                               const float (*st)[6][CB], const float4* __restrict__ tape,
                                               const StepTape* last, const float* hp1, int c, int q, float (&res)[8],
                                               float w0) {
@@ -580,11 +621,11 @@ __device__ __forceinline__ void pass_backward(const float4* tw, const float4* wq
   float dgh[48];  // d pre_r (0-15), d pre_z (16-31), d gh_n (32-47) of step t+1: B operands of the W_hh^T contraction
   float carry0 = 0.f, carry1 = 0.f;
   if (MODE == MODE_INV)
-    adj_step<MODE, 3, true>(tw, wq4, gin, st, nullptr, last, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+    adj_step<MODE, 3, true>(tw, wq4, wl, io, gin, st, nullptr, last, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
   else
-    adj_step<MODE, 3, false>(tw, wq4, gin, st, tape + 2 * TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
-  adj_step<MODE, 2, false>(tw, wq4, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
-  adj_step<MODE, 1, false>(tw, wq4, gin, st, tape, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+    adj_step<MODE, 3, false>(tw, wq4, wl, io, gin, st, tape + 2 * TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+  adj_step<MODE, 2, false>(tw, wq4, wl, io, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+  adj_step<MODE, 1, false>(tw, wq4, wl, io, gin, st, tape, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
   // ---- t = 0: coupling only ----
   const float x0 = st[0][0][c], x1 = st[0][1][c], s0 = st[0][2][c], s1 = st[0][3][c];
   if (MODE == MODE_INV) {
@@ -759,7 +800,7 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
         __builtin_amdgcn_wave_barrier();
         float res[8];
         TK_START();
-        pass_backward<MODE_INV>(tw, wq4, nullptr, stI, tapeI, &last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
+        pass_backward<MODE_INV>(tw, wq4, wl, io, nullptr, stI, tapeI, &last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
                                 res, 0.f);
         TK_STOP(5);
         if (mean_mode) {
@@ -804,7 +845,7 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
     __builtin_amdgcn_wave_barrier();
     float res[8];
     TK_START();
-    pass_backward<MODE_FWD>(tw, wq4, gy, stF, tapeF, nullptr, pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, c, q, res, w0);
+    pass_backward<MODE_FWD>(tw, wq4, wl, io, gy, stF, tapeF, nullptr, pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, c, q, res, w0);
     TK_STOP(8);
     const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
     const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
