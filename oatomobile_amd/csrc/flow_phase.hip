@@ -15,6 +15,10 @@
 //     wave's gate math, tape traffic and LDS waits run under the other wave's MFMAs.
 //   * per-candidate exchange buffers shrink to 1 KB per wave (x -> y in place, dLoss/dy), the gate gradients of the
 //     adjoint are registers (the contraction is fully unrolled: its A operands have static LDS offsets).
+//   * the adjoint tape (what a step's adjoint needs from its forward: r, z, gh_n, hprev + the ReLU mask; n is
+//     recomputed from r, gh_n and a 4-MFMA k-step on the step's input) goes to global memory, 16 KB per wave and taped
+//     step; the last inverse step of a pass is handed to its adjoint in registers.
+//   * launches with fewer than 8 blocks per CU use 4- or 2-wave workgroups (template WPB) so that every CU has one.
 // LDS: 121.5 KB operands + 8 x 4 KB = 153.5 KB per workgroup, one workgroup per CU.
 #include "flow.h"
 #include "flow_math.h"
