@@ -74,89 +74,98 @@ struct FrontArgs {
   int k0;
   size_t ws_off, bs_off, wd_off, bd_off, wp_off, bp_off;
   int B, C, HI, HS;
+  int bands;  // row bands per observation; a workgroup loops over (observation, band) items of ONE model
 };
 
+// CC: compile-time channel count (2 = the LIDAR sensor's BEV: register-resident stem taps, one-trip input staging
+// with the next item's loads in flight during step 3); 0 = any C <= 4 at run time
+template <int CC>
 __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int C = a.C, HI = a.HI, HS = a.HS;
+  const int C = CC ? CC : a.C, HI = a.HI, HS = a.HS;
   const int IW = HI + 8, SW = HS + 2;  // input row: 4 zeros, HI pixels, 4 zeros (the last 4-pixel group reads to HI + 7)
   constexpr int IR = 2 * (RB + 2) + 1;  // input rows of the band incl. halo
   float* xs = reinterpret_cast<float*>(smem_raw);            // [C][IR][IW], zero borders
   float* wsm = xs + (size_t)C * IR * IW;                     // [9][C][32] stem taps
   bf16_t* ss = reinterpret_cast<bf16_t*>(wsm + 9 * C * SC);  // [RB + 2][SW][32] stem output (bf16)
+  float* wdm = reinterpret_cast<float*>(ss + (size_t)(RB + 2) * SW * SC);  // [9][32] depthwise taps + [32] bias
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int k = blockIdx.z, b = blockIdx.y, band = blockIdx.x;
-  const int oy0 = band * RB;
-  const int rows = min(RB, HS - oy0);
+  const int k = blockIdx.z;
   const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
   const bf16_t* Wh = a.whbase + (size_t)(a.k0 + k) * a.model_stride;
 
-  // per-lane constants of step 3, requested first so that they arrive under steps 1 and 2
+  // per-lane constants of step 3 (projection operand / bias: 8 registers; the 72 depthwise taps are re-read from an LDS
+  // copy per item, like the stem's, so that neither set is live across the other's step)
   const int n = lane & 15, q = lane >> 4;
-  f32x2 wt[9][4], bd[4];
-  {
-    const float* wd = W + a.wd_off + 8 * q;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float4 w0 = *reinterpret_cast<const float4*>(wd + (size_t)t * SC);
-      const float4 w1 = *reinterpret_cast<const float4*>(wd + (size_t)t * SC + 4);
-      wt[t][0] = f32x2{w0.x, w0.y};
-      wt[t][1] = f32x2{w0.z, w0.w};
-      wt[t][2] = f32x2{w1.x, w1.y};
-      wt[t][3] = f32x2{w1.z, w1.w};
-    }
-    const float4 b0 = *reinterpret_cast<const float4*>(W + a.bd_off + 8 * q);
-    const float4 b1 = *reinterpret_cast<const float4*>(W + a.bd_off + 8 * q + 4);
-    bd[0] = f32x2{b0.x, b0.y};
-    bd[1] = f32x2{b0.z, b0.w};
-    bd[2] = f32x2{b1.x, b1.y};
-    bd[3] = f32x2{b1.z, b1.w};
-  }
   const u32x4 apj = *reinterpret_cast<const u32x4*>(Wh + a.wp_off + (size_t)n * SC + 8 * q);  // row n = output channel
   const float4 bpj = *reinterpret_cast<const float4*>(W + a.bp_off + 4 * q);
 
-  // ---- 1. stage the input band: stem rows oy0-1 .. oy0+rows need input rows 2(oy0-1)-1 .. 2(oy0+rows)+1.
-  // 16-byte loads, ALL requested before the first LDS write (a load -> store loop pays the memory latency per trip);
-  // padded row = 4 zeros, HI pixels, zeros: pixel column ix sits at ix + 4, so the LDS writes are 16-byte aligned. ----
-  const int iy0 = 2 * (oy0 - 1) - 1;
+  // once per workgroup (one model): stem taps, zero paddings
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int e = tid; e < 9 * C * SC; e += 256) wsm[e] = W[a.ws_off + e];
+  for (int e = tid; e < 10 * SC; e += 256) wdm[e] = e < 9 * SC ? W[a.wd_off + e] : W[a.bd_off + e - 9 * SC];
+  for (int e = tid; e < (RB + 2) * 2 * (SC / 8); e += 256) {  // border columns of the stem rows
+    const int c8 = e % (SC / 8), side = (e / (SC / 8)) & 1, r = e / (2 * (SC / 8));
+    *reinterpret_cast<u32x4*>(ss + ((size_t)r * SW + (side ? SW - 1 : 0)) * SC + 8 * c8) = zero4;
+  }
   {
-    const int q4 = HI >> 2;                // float4 per input row
-    const int total = C * IR * q4;
-    constexpr int NL = 6;                  // C <= 4: 4 * 25 * 25 / 256 < 10; C == 2: 5 trips
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int e0 = 0; e0 < total; e0 += 256 * NL) {
-      u32x4 v[NL];
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int e = e0 + tid + 256 * j;
-        const int cr = e / q4, x4 = e - cr * q4;
-        const int c = cr / IR, r = cr - c * IR;
-        const int iy = iy0 + r;
-        v[j] = (!(RIP_FRONT_ABL & 4) && e < total && iy >= 0 && iy < HI)
-                   ? *reinterpret_cast<const u32x4*>(a.in + ((size_t)b * C + c) * HI * HI + (size_t)iy * HI + 4 * x4)
-                   : zero4;
-      }
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int e = e0 + tid + 256 * j;
-        const int cr = e / q4, x4 = e - cr * q4;
-        if (e < total) *reinterpret_cast<u32x4*>(xs + (size_t)cr * IW + 4 + 4 * x4) = v[j];
-      }
-    }
-    const int pads = (IW - HI) >> 2;       // float4 of padding per row: one on the left, the rest on the right
+    const int pads = (IW - HI) >> 2;  // float4 of padding per input row: one on the left, the rest on the right
     for (int e = tid; e < C * IR * pads; e += 256) {
       const int cr = e / pads, j = e - cr * pads;
       *reinterpret_cast<u32x4*>(xs + (size_t)cr * IW + (j == 0 ? 0 : HI + 4 * j)) = zero4;
     }
   }
-  for (int e = tid; e < 9 * C * SC; e += 256) wsm[e] = W[a.ws_off + e];
-  // zero border columns of the stem rows
-  for (int e = tid; e < (RB + 2) * 2 * (SC / 8); e += 256) {
-    const int c8 = e % (SC / 8), side = (e / (SC / 8)) & 1, r = e / (2 * (SC / 8));
-    *reinterpret_cast<u32x4*>(ss + ((size_t)r * SW + (side ? SW - 1 : 0)) * SC + 8 * c8) = u32x4{0u, 0u, 0u, 0u};
+
+  // ---- persistent loop over this model's (observation, band) items.  Staging: stem rows oy0-1 .. oy0+rows need input
+  // rows 2(oy0-1)-1 .. 2(oy0+rows)+1; 16-byte loads, ALL requested before the first LDS write (a load -> store loop
+  // pays the memory latency per trip); padded row = 4 zeros, HI pixels, zeros: pixel column ix sits at ix + 4, so the
+  // LDS writes are 16-byte aligned.  With C == 2 the band is one trip of loads (5 per thread): the NEXT item's are
+  // requested before step 3 of the current one, so the HBM latency is covered by it. ----
+  constexpr int NL = 6;
+  const int q4 = HI >> 2;  // float4 per input row
+  const int total = C * IR * q4;
+  const bool one_trip = CC == 2 && total <= 256 * NL;
+  const int nitems = a.B * a.bands;
+  auto load_input = [&](int item, int e0, u32x4(&v)[NL]) {
+    const int ib = item / a.bands, iband = item - ib * a.bands;
+    const int iiy0 = 2 * (iband * RB - 1) - 1;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int e = e0 + tid + 256 * j;
+      const int cr = e / q4, x4 = e - cr * q4;
+      const int c = cr / IR, r = cr - c * IR;
+      const int iy = iiy0 + r;
+      v[j] = (!(RIP_FRONT_ABL & 4) && e < total && iy >= 0 && iy < HI)
+                 ? *reinterpret_cast<const u32x4*>(a.in + ((size_t)ib * C + c) * HI * HI + (size_t)iy * HI + 4 * x4)
+                 : zero4;
+    }
+  };
+  auto store_input = [&](int e0, const u32x4(&v)[NL]) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int e = e0 + tid + 256 * j;
+      const int cr = e / q4, x4 = e - cr * q4;
+      if (e < total) *reinterpret_cast<u32x4*>(xs + (size_t)cr * IW + 4 + 4 * x4) = v[j];
+    }
+  };
+  u32x4 vnext[NL];
+  if (one_trip && (int)blockIdx.x < nitems) load_input(blockIdx.x, 0, vnext);
+#pragma unroll 1
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int b = item / a.bands, band = item - b * a.bands;
+  const int oy0 = band * RB;
+  const int rows = min(RB, HS - oy0);
+  if (one_trip) {
+    store_input(0, vnext);
+  } else {
+    for (int e0 = 0; e0 < total; e0 += 256 * NL) {
+      u32x4 v[NL];
+      load_input(item, e0, v);
+      store_input(e0, v);
+    }
   }
-  __syncthreads();
+  __syncthreads();  // (also: every wave has left step 3 of the previous item, the stem rows may be overwritten)
 
   // ---- 2. stem rows oy0-1 .. oy0+rows (rows off the map: zeros = the depthwise's padding).
   // thread = (row, 4 adjacent pixels, 4 output channels): one 16-byte tap read feeds 8 packed FMAs, the 9 input
@@ -166,10 +175,12 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
     const float* bias = W + a.bs_off;
     const int npg = (HS + 3) >> 2;
     f32x2 wreg[18][2];
-    if (C == 2) {
+    int opq2 = 0;
+    asm volatile("" : "+v"(opq2));  // (keeps the tap reads inside the item loop, see step 3)
+    if (CC == 2) {
 #pragma unroll
       for (int t = 0; t < 18; ++t) {  // t = (ky * 3 + kx) * C + c: the blob's tap order
-        const float4 w = *reinterpret_cast<const float4*>(wsm + t * SC + 4 * (tid & 7));
+        const float4 w = *reinterpret_cast<const float4*>(wsm + t * SC + 4 * (tid & 7) + opq2);
         wreg[t][0] = f32x2{w.x, w.y};
         wreg[t][1] = f32x2{w.z, w.w};
       }
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
           acc[i][1] = f32x2{b0.z, b0.w};
         }
       }
-      if (rok && !(RIP_FRONT_ABL & 1) && C == 2) {
+      if (rok && !(RIP_FRONT_ABL & 1) && CC == 2) {
         // C == 2 (the LIDAR sensor's BEV): this thread's 18 x 4 tap weights live in registers (its channel group is
         // fixed: e & 7 == tid & 7) -- half of the stem's LDS reads were tap reads, and the stem was LDS-bound
 #pragma unroll
@@ -248,8 +259,26 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
     }
   }
   __syncthreads();
+  if (one_trip && item + (int)gridDim.x < nitems) load_input(item + gridDim.x, 0, vnext);  // lands under step 3
 
   // ---- 3. depthwise + projection, one 16-pixel tile per wave at a time ----
+  f32x2 wt[9][4], bd[4];
+  {
+    int opq = 0;
+    asm volatile("" : "+v"(opq));  // the (loop-invariant) tap reads must stay inside the item loop: hoisted they are 80
+                                       // registers live across both steps
+    const float* wd = wdm + 8 * q + opq;
+#pragma unroll
+    for (int t = 0; t <= 9; ++t) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wd + t * SC);
+      const float4 w1 = *reinterpret_cast<const float4*>(wd + t * SC + 4);
+      f32x2(&dst)[4] = t < 9 ? wt[t < 9 ? t : 0] : bd;
+      dst[0] = f32x2{w0.x, w0.y};
+      dst[1] = f32x2{w0.z, w0.w};
+      dst[2] = f32x2{w1.x, w1.y};
+      dst[3] = f32x2{w1.z, w1.w};
+    }
+  }
   bf16_t* og = a.out + (((size_t)k * a.B + b) * HS + oy0) * HS * OC;
   const int P = rows * HS, ntiles = (P + 15) >> 4;
   // two tiles per trip: the 18 window reads of both are requested before the first value is unpacked, so one tile's
@@ -298,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void front_bf16_kernel(FrontArgs a) {
       if (val[u]) *reinterpret_cast<u32x2*>(og + (size_t)pp[u] * OC + 4 * q) = o;
     }
   }
+  }  // items
 }
 
 }  // namespace
@@ -330,19 +360,34 @@ hipError_t launch_front_bf16(const Layer& ls, const Layer& ld, const Layer& lp, 
   a.HS = ls.h_out;
   constexpr int IR = 2 * (RB + 2) + 1;
   const size_t lds = ((size_t)a.C * IR * (a.HI + 8) + 9 * a.C * SC) * sizeof(float) +
-                     (size_t)(RB + 2) * (a.HS + 2) * SC * sizeof(bf16_t);
+                     (size_t)(RB + 2) * (a.HS + 2) * SC * sizeof(bf16_t) + 10 * SC * sizeof(float);
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(front_bf16_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(front_bf16_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(front_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            96 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   if (lds > 96 * 1024) return hipErrorInvalidValue;
-  const int bands = (a.HS + RB - 1) / RB;
-  hipLaunchKernelGGL(front_bf16_kernel, dim3(bands, B, kc), dim3(256), lds, s, a);
+  a.bands = (a.HS + RB - 1) / RB;
+  // persistent workgroups: two per CU in total (what the LDS footprint admits), each looping over the (observation,
+  // band) items of one model
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  int wgs = (per_cu * cus + kc - 1) / kc;
+  if (B * a.bands < 2 * wgs) wgs = B * a.bands;  // small launches: one item per workgroup (no uneven 1-or-2 split)
+  if (wgs < 1) wgs = 1;
+  if (a.C == 2 && a.HI == 100)
+    hipLaunchKernelGGL(front_bf16_kernel<2>, dim3(wgs, 1, kc), dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL(front_bf16_kernel<0>, dim3(wgs, 1, kc), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
