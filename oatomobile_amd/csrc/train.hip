@@ -523,7 +523,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
         const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);  // STAT_SHIFTED: the shift k[c]
         const float4 is = MODE == STAT_BWD ? *reinterpret_cast<const float4*>(invstd + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-        for (size_t r = r0 + rl; r < r1; r += RL) {
+  #pragma unroll 4
+      for (size_t r = r0 + rl; r < r1; r += RL) {
           const float4 v = x4[r * C4 + c4];
           if (MODE == STAT_SHIFTED) {
             const float4 d = make_float4(v.x - mu.x, v.y - mu.y, v.z - mu.z, v.w - mu.w);
@@ -654,6 +655,7 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
       const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
       const float4 is = *reinterpret_cast<const float4*>(invstd + 4 * c4);
       float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
       for (size_t r = r0 + rl; r < r1; r += RL) {
         const size_t e = r * C4 + c4;
         const float4 d = d4[e];
@@ -755,13 +757,23 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, float*
   const int c = idx % n, r = idx / n;
   dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
 }
-// out[c] = sum_r x[r, c]
-__global__ void colsum_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int rows, int n) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+// out[c] = sum_r x[r, c]: a block owns 32 columns, its 8 groups of 32 threads stride the rows (the first version was
+// one thread per column walking all rows: 118 us for the flow's 512 x 192 gate gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int rows,
+                                                     int n) {
+  __shared__ float part[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += x[(size_t)r * ld + c];
-  out[c] = s;
+  if (c < n)
+    for (int r = rg; r < rows; r += 8) s += x[(size_t)r * ld + c];
+  part[rg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rg == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+    out[c] = t;
+  }
 }
 __global__ void mean_loss_kernel(const float* __restrict__ q, float* __restrict__ loss, int B) {
   __shared__ float red[256];
@@ -1041,27 +1053,27 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     TRY(gemm(true, false, dgh, ld, hprev, ld, grads + t->f_whh, 64, 192, 64, R, 0, s));
     TRY(gemm(true, false, da1, ld, hh, ld, grads + t->f_w1, 64, 32, 64, R, 0, s));
     TRY(gemm(true, false, dout, ld, ra1, ld, grads + t->f_w2, 32, 4, 32, R, 0, s));
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dgi, ld, grads + t->f_bih, R, 192);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dgh, ld, grads + t->f_bhh, R, 192);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, da1, ld, grads + t->f_b1, R, 32);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dout, ld, grads + t->f_b2, R, 4);
+    hipLaunchKernelGGL(colsum_kernel, dim3((192 + 31) / 32), dim3(256), 0, s, dgi, ld, grads + t->f_bih, R, 192);
+    hipLaunchKernelGGL(colsum_kernel, dim3((192 + 31) / 32), dim3(256), 0, s, dgh, ld, grads + t->f_bhh, R, 192);
+    hipLaunchKernelGGL(colsum_kernel, dim3((32 + 31) / 32), dim3(256), 0, s, da1, ld, grads + t->f_b1, R, 32);
+    hipLaunchKernelGGL(colsum_kernel, dim3((4 + 31) / 32), dim3(256), 0, s, dout, ld, grads + t->f_b2, R, 4);
   }
   // ================================== backward ==================================
   // ---- merger / classifier ----
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dz, zz, B * HID);
   TRY(gemm(true, false, dz, HID, h2, HID, grads + t->mrg_w[2], HID, HID, HID, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dz, HID, grads + t->mrg_b[2], B, HID);
+  hipLaunchKernelGGL(colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dz, HID, grads + t->mrg_b[2], B, HID);
   TRY(gemm(false, false, dz, HID, params + t->mrg_w[2], HID, dh2, HID, B, HID, HID, 0, s));
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dh2, h2, B * HID);
   TRY(gemm(true, false, dh2, HID, h1, HID, grads + t->mrg_w[1], HID, HID, HID, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dh2, HID, grads + t->mrg_b[1], B, HID);
+  hipLaunchKernelGGL(colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dh2, HID, grads + t->mrg_b[1], B, HID);
   TRY(gemm(false, false, dh2, HID, params + t->mrg_w[1], HID, dh1, HID, B, HID, HID, 0, s));
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dh1, h1, B * HID);
   TRY(gemm(true, false, dh1, HID, merged, FEAT + VEC, grads + t->mrg_w[0], FEAT + VEC, HID, FEAT + VEC, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dh1, HID, grads + t->mrg_b[0], B, HID);
+  hipLaunchKernelGGL(colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dh1, HID, grads + t->mrg_b[0], B, HID);
   TRY(gemm(false, false, dh1, HID, params + t->mrg_w[0], FEAT + VEC, dmerged, FEAT + VEC, B, FEAT + VEC, HID, 0, s));
   TRY(gemm(true, false, dmerged, FEAT + VEC, pooled, LAST_C, grads + t->cls_w, LAST_C, FEAT, LAST_C, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, dmerged, FEAT + VEC, grads + t->cls_b, B, FEAT);
+  hipLaunchKernelGGL(colsum_kernel, dim3((FEAT + 31) / 32), dim3(256), 0, s, dmerged, FEAT + VEC, grads + t->cls_b, B, FEAT);
   TRY(gemm(false, false, dmerged, FEAT + VEC, params + t->cls_w, LAST_C, dpooled, LAST_C, B, LAST_C, FEAT, 0, s));
   hipLaunchKernelGGL(pool_drop_bwd_kernel, dim3(nblk(Bz * P * LAST_C)), dim3(256), 0, s, dpooled, dropout_mask,
                      A(t->dpost, nl - 1), B, P, LAST_C);
