@@ -69,6 +69,9 @@ __device__ __forceinline__ f32x4 zero4() {
 #ifndef RIP_TAPE_N
 #define RIP_TAPE_N 0
 #endif
+#ifndef RIP_ADJ_PF
+#define RIP_ADJ_PF 3  // adjoint contraction: operand rows in flight
+#endif
 #ifndef RIP_PREFETCH
 #define RIP_PREFETCH 1  // operand rows requested one MFMA group ahead (development switch)
 #endif
@@ -507,7 +510,7 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
     // rows 1..8 (W1^T, B = da1) then 9..56 (W_hh^T, B = dgh), each feeding 4 MFMAs; requested PF rows (PF * 128
     // cycles of MFMAs) ahead of their use
     constexpr int NROW = FIRST ? 8 : 56;
-    constexpr int PF = 3;
+    constexpr int PF = RIP_ADJ_PF;
     float4 ring[PF];
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = tw[(1 + e) * 64];
