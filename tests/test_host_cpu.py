@@ -307,3 +307,33 @@ def test_datum_batches_worker_processes_equal_inline(tmp_path):
   assert list(replay.DatumBatches([], 8)) == []
   with pytest.raises(ValueError, match="BEV channels"):
     replay.DatumBatches(files, 8, channels=4)
+
+
+def test_datum_batches_falls_back_without_shared_memory(tmp_path, monkeypatch):
+  """A `/dev/shm` that cannot hold the batch ring (small container default) must not fail the replay: the loader warns
+  and decodes inline."""
+  from multiprocessing import shared_memory
+  from oatomobile_amd import replay
+  ep = replay.Episode(str(tmp_path), "ep")
+  rng = np.random.default_rng(9)
+  for i in range(5):
+    ep.append("t%d" % i, lidar=rng.random((200, 200, 2)).astype(np.float32), velocity=np.zeros(3, np.float32),
+              is_at_traffic_light=np.float32(0), traffic_light_state=np.float32(1), player_future=np.ones((80, 3), np.float32))
+  real = shared_memory.SharedMemory
+
+  class NoSpace(real):
+    def __init__(self, *a, **k):
+      if k.get("create"):
+        raise OSError(28, "No space left on device")
+      super().__init__(*a, **k)
+
+  monkeypatch.setattr(shared_memory, "SharedMemory", NoSpace)
+  with pytest.warns(UserWarning, match="no shared memory"):
+    sizes = [b[0].shape[0] for b in replay.DatumBatches(ep.files(), 2, workers=2)]
+  assert sizes == [2, 2, 1]
+
+
+def test_effective_cpus_is_positive_and_bounded():
+  from oatomobile_amd import replay
+  n = replay.effective_cpus()
+  assert 1 <= n <= (os.cpu_count() or 1)
