@@ -100,11 +100,17 @@ struct TileGeom {
 // AEF / APF: the expansion / projection weights of the next step are requested a step ahead (register budget
 // permitting: KSX * 16 / NCT * 8 more live registers); otherwise they are requested where the phase starts and the
 // wave's stall is covered by the vector wave on the same SIMD.
-template <int HIN, int STRIDE, int CIN, int COUT, int G, bool AEF, bool APF>
+// WCH: the four matrix waves split as (4 / WCH pixel partitions) x (WCH channel partitions).  WCH = 2 for the 4x4
+// blocks: a wave then streams HALF of a chunk's weights for twice as many pixel tiles (the weight loads are what
+// bounds those blocks: K = 160 / 960 against 128 pixels per workgroup).
+template <int HIN, int STRIDE, int CIN, int COUT, int G, bool AEF, bool APF, int WCH = 1>
 __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   using Geo = TileGeom<HIN, STRIDE, G>;
-  constexpr int HOUT = Geo::HOUT, HWI = Geo::HWI, HWO = Geo::HWO, PW = Geo::PW, TIN = Geo::TIN, TOUT = Geo::TOUT;
-  constexpr int KSX = CIN / 32, NCT = COUT / 16, NHT = HC / 16, NKP = HC / 32;
+  constexpr int HOUT = Geo::HOUT, HWI = Geo::HWI, HWO = Geo::HWO, PW = Geo::PW;
+  constexpr int WP = 4 / WCH;  // pixel partitions of the matrix waves
+  constexpr int TIN = (Geo::TIN * 4 + WP - 1) / WP, TOUT = (Geo::TOUT * 4 + WP - 1) / WP;
+  constexpr int KSX = CIN / 32, NCT = COUT / 16 / WCH, NHT = HC / 16 / WCH, NKP = HC / 32;
+  static_assert((COUT / 16) % WCH == 0 && (HC / 16) % WCH == 0, "channel partitions");
   constexpr int CTG = NCT > 10 ? 10 : NCT;  // channel tiles per projection pass (weights of one pass are live at a time)
   static_assert(NCT % CTG == 0 && (CTG == NCT || !APF), "projection passes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -132,12 +138,14 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   if (w < 4) {
     // ================= matrix waves: expand + project =================
     const int n = lane & 15, q = lane >> 4;
+    const int wpix = w / WCH, wch = w % WCH;  // this wave's pixel partition / channel partition
+    const int ht0 = wch * NHT, ct0w = wch * NCT;
     const int npt_in = (m_in + 15) >> 4, npt_out = (m_out + 15) >> 4;
     u32x4 xb[TIN][KSX];   // block input, B operands
     int erow[TIN];        // padded E row of this lane's pixel per tile (-1: beyond the workgroup's pixels)
 #pragma unroll
     for (int t = 0; t < TIN; ++t) {
-      const int px = 16 * (w + 4 * t) + n;
+      const int px = 16 * (wpix + WP * t) + n;
 #pragma unroll
       for (int ks = 0; ks < KSX; ++ks)
         xb[t][ks] = px < m_in ? *reinterpret_cast<const u32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q) : zero4;
@@ -157,12 +165,12 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       for (int ht = 0; ht < NHT; ++ht) {
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks)
-          ae[ht][ks] = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)(c * HC + 16 * ht + n) * CIN + 32 * ks + 8 * q);
-        be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * ht + 4 * q);
+          ae[ht][ks] = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)(c * HC + 16 * (ht0 + ht) + n) * CIN + 32 * ks + 8 * q);
+        be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q);
       }
     };
     auto load_ap = [&](int c, int ct0) {  // projection weights of chunk c, channel tiles ct0 .. ct0 + CTG - 1
-      const bf16_t* wp = Wh + a.wp_off + (size_t)(16 * ct0 + n) * HID + c * HC + 8 * q;
+      const bf16_t* wp = Wh + a.wp_off + (size_t)(16 * (ct0w + ct0) + n) * HID + c * HC + 8 * q;
 #pragma unroll
       for (int ct = 0; ct < CTG; ++ct)
 #pragma unroll
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       if (!AEF) load_ae(c);
 #pragma unroll
       for (int t = 0; t < TIN; ++t) {
-        if (w + 4 * t >= npt_in) continue;  // wave-uniform
+        if (wpix + WP * t >= npt_in) continue;  // wave-uniform
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
           u32x2 o;
           o.x = pack_bf16(relu6_2(f32x2{v[0] + be[ht].x, v[1] + be[ht].y}));
           o.y = pack_bf16(relu6_2(f32x2{v[2] + be[ht].z, v[3] + be[ht].w}));
-          if (erow[t] >= 0) *reinterpret_cast<u32x2*>(E + (size_t)erow[t] * LD + 16 * ht + 4 * q) = o;
+          if (erow[t] >= 0) *reinterpret_cast<u32x2*>(E + (size_t)erow[t] * LD + 16 * (ht0 + ht) + 4 * q) = o;
         }
       }
       if (AEF && c + 1 < nch) load_ae(c + 1);  // lands during the projection and the barrier
@@ -197,11 +205,11 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         if (!APF) load_ap(c, cg);
 #pragma unroll
         for (int t = 0; t < TOUT; ++t) {
-          if (w + 4 * t >= npt_out) continue;  // wave-uniform
+          if (wpix + WP * t >= npt_out) continue;  // wave-uniform
           u32x4 bv[NKP];
 #pragma unroll
           for (int ks = 0; ks < NKP; ++ks)
-            bv[ks] = *reinterpret_cast<const u32x4*>(D + (size_t)(16 * (w + 4 * t) + n) * LD + 32 * ks + 8 * q);
+            bv[ks] = *reinterpret_cast<const u32x4*>(D + (size_t)(16 * (wpix + WP * t) + n) * LD + 32 * ks + 8 * q);
 #pragma unroll
           for (int ct = 0; ct < CTG; ++ct)
 #pragma unroll
@@ -222,13 +230,13 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     float4 bpj[NCT];
     u32x2 rres[TOUT][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) bpj[ct] = *reinterpret_cast<const float4*>(W + a.bp_off + 16 * ct + 4 * q);
+    for (int ct = 0; ct < NCT; ++ct) bpj[ct] = *reinterpret_cast<const float4*>(W + a.bp_off + 16 * (ct0w + ct) + 4 * q);
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
-      const int p = 16 * (w + 4 * t) + n;
+      const int p = 16 * (wpix + WP * t) + n;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
-        rres[t][ct] = (a.residual && p < m_out) ? *reinterpret_cast<const u32x2*>(xg + (size_t)p * CIN + 16 * ct + 4 * q)
+        rres[t][ct] = (a.residual && p < m_out) ? *reinterpret_cast<const u32x2*>(xg + (size_t)p * CIN + 16 * (ct0w + ct) + 4 * q)
                                                 : u32x2{0u, 0u};
     }
     if (nch >= 2 && mx_on) project(nch - 2);
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
-      const int p = 16 * (w + 4 * t) + n;
+      const int p = 16 * (wpix + WP * t) + n;
       if (p >= m_out || (RIP_TILE_ABL & 16)) continue;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         u32x2 o;
         o.x = pack_bf16(v0);
         o.y = pack_bf16(v1);
-        *reinterpret_cast<u32x2*>(yg + (size_t)p * COUT + 16 * ct + 4 * q) = o;
+        *reinterpret_cast<u32x2*>(yg + (size_t)p * COUT + 16 * (ct0w + ct) + 4 * q) = o;
       }
     }
   } else {
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   }
 }
 
-template <int HIN, int STRIDE, int CIN, int COUT, int GMAX, bool AEF, bool APF>
+template <int HIN, int STRIDE, int CIN, int COUT, int GMAX, bool AEF, bool APF, int WCH = 1>
 hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
   using Geo = TileGeom<HIN, STRIDE, GMAX>;
   static_assert(GMAX * Geo::HOUT * 8 <= 256, "one depthwise thread per (observation, column, 8 channels)");
@@ -339,7 +347,7 @@ hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
   if (G < 1) G = 1;
   a.G = G;
   static bool attr_set[64] = {};  // per device: > 64 KB of dynamic LDS needs the opt-in
-  auto kern = irb_tile_bf16_kernel<HIN, STRIDE, CIN, COUT, GMAX, AEF, APF>;
+  auto kern = irb_tile_bf16_kernel<HIN, STRIDE, CIN, COUT, GMAX, AEF, APF, WCH>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
@@ -389,13 +397,13 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
   const int cin = le->cin, cout = lp.cout;
   //                                          HIN S CIN COUT GMAX AEF APF
   if (ld.h_in == 7 && ld.stride == 1) {
-    if (cin == 64 && cout == 64) return launch_tile<7, 1, 64, 64, 4, true, true>(a, kc, s);    // features.8-10
-    if (cin == 64 && cout == 96) return launch_tile<7, 1, 64, 96, 4, true, false>(a, kc, s);    // features.11
+    if (cin == 64 && cout == 64) return launch_tile<7, 1, 64, 64, 4, true, true, 2>(a, kc, s);    // features.8-10
+    if (cin == 64 && cout == 96) return launch_tile<7, 1, 64, 96, 4, true, true, 2>(a, kc, s);    // features.11
     if (cin == 96 && cout == 96) return launch_tile<7, 1, 96, 96, 4, false, false>(a, kc, s);    // features.12, 13
   }
-  if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_tile<7, 2, 96, 160, 4, true, true>(a, kc, s);  // 14
+  if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_tile<7, 2, 96, 160, 4, true, true, 2>(a, kc, s);  // 14
   if (ld.h_in == 4 && ld.stride == 1 && cin == 160) {
-    if (cout == 160) return launch_tile<4, 1, 160, 160, 8, false, false>(a, kc, s);              // features.15, 16
+    if (cout == 160) return launch_tile<4, 1, 160, 160, 8, false, false, 2>(a, kc, s);              // features.15, 16
   }
   return hipErrorInvalidValue;
 }
