@@ -74,7 +74,7 @@ def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype):
   """The encoder stage against its three ceilings.  Work per (model, observation) from the architecture (arch.py):
   pointwise convs 68.63 M MAC on the matrix cores, depthwise + stem (4.64 + 0.72 C) M fp32 FMA on the vector ALUs;
   HBM bytes MEASURED at the bench configuration (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all encoder kernels of one
-  512-observation x 4-model step, profiles/r2/pmc_summary_v3.csv: 2.370 GB) scaled by (B K) / 2048."""
+  512-observation x 4-model step, profiles/r2/pmc_summary_v6.csv: 2.296 GB) scaled by (B K) / 2048."""
   t = enc_ms * 1e-3
   pw_flops = 2.0 * 68.627e6 * B * K
   valu_fma = (4.641e6 + 0.720e6 * C) * B * K
@@ -86,10 +86,10 @@ def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype):
                   "bytes_pre + bytes_enc (every layer's input and output through HBM) / time: what the UNFUSED network "
                   "would have to move, not what the fused kernels move." % enc_dtype}
   if enc_dtype == "bf16" and C == 2:
-    meas = 2.370e9 * (B * K) / 2048.0
+    meas = 2.296e9 * (B * K) / 2048.0
     line.update({"measured_hbm_bytes": meas, "measured_GBps": meas / t / 1e9, "frac_hbm": meas / t / 1e9 / PEAK_HBM_GBS})
     line["note"] += ("  `measured_*`: HBM bytes from the PMC passes in profiles/r2 (fused blocks keep the expanded tensors "
-                     "in LDS: 2.37 GB per step instead of the layer-wise 12.2 GB).  The stage sits far below all three "
+                     "in LDS: 2.30 GB per step instead of the layer-wise 12.2 GB).  The stage sits far below all three "
                      "ceilings: 25 dependent launches of small-tile work (16-96 channel GEMMs, 9-tap depthwise).")
   return line
 
