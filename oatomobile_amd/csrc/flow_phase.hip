@@ -961,8 +961,13 @@ hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* s
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  if (items >= 8 * cus) return launch_phase_wpb<8>(a, mw_all, pre, tape, items, s);
-  if (items >= 4 * cus) return launch_phase_wpb<4>(a, mw_all, pre, tape, items, s);
+  // cost model from the measurements: an 8-wave workgroup (two waves per SIMD) takes twice as long as a 4-wave one
+  // (2.3 vs 1.15 ms for 10 Adam steps at K = 4), a 2-wave one about as long as a 4-wave one (1.1 ms); a launch is
+  // ceil(workgroups / CUs) rounds of that.  Ties go to the larger workgroup (fewer operand DMA streams).
+  auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
+  const double c8 = 2.0 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
+  if (c8 <= c4 && c8 <= c2) return launch_phase_wpb<8>(a, mw_all, pre, tape, items, s);
+  if (c4 <= c2) return launch_phase_wpb<4>(a, mw_all, pre, tape, items, s);
   return launch_phase_wpb<2>(a, mw_all, pre, tape, items, s);
 }
 
