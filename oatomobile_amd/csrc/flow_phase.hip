@@ -69,6 +69,9 @@ __device__ __forceinline__ f32x4 zero4() {
 #ifndef RIP_TAPE_N
 #define RIP_TAPE_N 0
 #endif
+#ifndef RIP_REGTAPE
+#define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
+#endif
 #ifndef RIP_ADJ_PF
 #define RIP_ADJ_PF 3  // adjoint contraction: operand rows in flight
 #endif
@@ -319,7 +322,9 @@ struct PassOut {
 // forward (x -> y, in place in `io`) or inverse (reads y from `io`) pass of the current model for this wave's 16
 // candidates.  Steps 1..3 are "heavy"; step 0 is the candidate-independent prefix.  MODE_FWD tapes all three heavy steps
 // (its adjoint runs K-1 model phases later); MODE_INV tapes steps 1, 2 and hands step 3 over in registers (`last`).
-template <int MODE>
+// REGTAPE (inverse passes of the 4- / 2-wave workgroups: one wave per SIMD owns the whole register file): ALL three
+// steps are handed to the adjoint in registers (`last[0..2]`, spilled to AGPRs by the compiler), no tape traffic.
+template <int MODE, bool REGTAPE = false>
 __device__ __forceinline__ PassOut pass_forward(const float4* wl, const Prefix16& pre, float (*io)[8],
                                                 float (*st)[6][CB], float4* __restrict__ tape, StepTape* last, int c,
                                                 int q, unsigned lane) {
@@ -397,14 +402,20 @@ __device__ __forceinline__ PassOut pass_forward(const float4* wl, const Prefix16
     float o[4];
     int zero = 0;
     asm volatile("" : "+v"(zero));
-    fwd_step_lds<SAVE_TAPE_NOHP>(wl + zero, H, yp0, yp1, q, lane, tape, nullptr, o);
+    if (REGTAPE)
+      fwd_step_lds<SAVE_REGS>(wl + zero, H, yp0, yp1, q, lane, nullptr, &last[0], o);
+    else
+      fwd_step_lds<SAVE_TAPE_NOHP>(wl + zero, H, yp0, yp1, q, lane, tape, nullptr, o);
     coupling(1, o);
   }
   {
     float o[4];
     int zero = 0;
     asm volatile("" : "+v"(zero));
-    fwd_step_lds<SAVE_TAPE>(wl + zero, H, yp0, yp1, q, lane, tape + TAPE_STEP_F4, nullptr, o);
+    if (REGTAPE)
+      fwd_step_lds<SAVE_REGS>(wl + zero, H, yp0, yp1, q, lane, nullptr, &last[1], o);
+    else
+      fwd_step_lds<SAVE_TAPE>(wl + zero, H, yp0, yp1, q, lane, tape + TAPE_STEP_F4, nullptr, o);
     coupling(2, o);
   }
   {
@@ -414,7 +425,7 @@ __device__ __forceinline__ PassOut pass_forward(const float4* wl, const Prefix16
     if (MODE == MODE_FWD)
       fwd_step_lds<SAVE_TAPE>(wl + zero, H, yp0, yp1, q, lane, tape + 2 * TAPE_STEP_F4, nullptr, o);
     else
-      fwd_step_lds<SAVE_REGS>(wl + zero, H, yp0, yp1, q, lane, nullptr, last, o);
+      fwd_step_lds<SAVE_REGS>(wl + zero, H, yp0, yp1, q, lane, nullptr, &last[2], o);
     coupling(3, o);
   }
   return po;
@@ -618,7 +629,7 @@ __device__ __forceinline__ void adj_step(const float4* tw_in, const float4* wq4_
 // (model, observation) in global memory (its H1 is step 1's hprev).
 // All gate gradients are registers: the 8 + 48 entries of the dh contraction are unrolled, their A operands are
 // ds_read_b128 at static offsets.
-template <int MODE>
+template <int MODE, bool REGTAPE = false>
 __device__ __forceinline__ void pass_backward(const float4* tw, const float4* wq4, const float4* wl, const float (*io)[8],
                                               const float (*gin)[8],
                                               const float (*st)[6][CB], const float4* __restrict__ tape,
@@ -628,11 +639,16 @@ __device__ __forceinline__ void pass_backward(const float4* tw, const float4* wq
   float dgh[48];  // d pre_r (0-15), d pre_z (16-31), d gh_n (32-47) of step t+1: B operands of the W_hh^T contraction
   float carry0 = 0.f, carry1 = 0.f;
   if (MODE == MODE_INV)
-    adj_step<MODE, 3, true>(tw, wq4, wl, io, gin, st, nullptr, last, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+    adj_step<MODE, 3, true>(tw, wq4, wl, io, gin, st, nullptr, &last[2], hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
   else
     adj_step<MODE, 3, false>(tw, wq4, wl, io, gin, st, tape + 2 * TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
-  adj_step<MODE, 2, false>(tw, wq4, wl, io, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
-  adj_step<MODE, 1, false>(tw, wq4, wl, io, gin, st, tape, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+  if (REGTAPE) {
+    adj_step<MODE, 2, true>(tw, wq4, wl, io, gin, st, nullptr, &last[1], hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+    adj_step<MODE, 1, true>(tw, wq4, wl, io, gin, st, nullptr, &last[0], hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+  } else {
+    adj_step<MODE, 2, false>(tw, wq4, wl, io, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+    adj_step<MODE, 1, false>(tw, wq4, wl, io, gin, st, tape, nullptr, hp1, c, q, w0, dhz, dgh, carry0, carry1, res);
+  }
   // ---- t = 0: coupling only ----
   const float x0 = st[0][0][c], x1 = st[0][1][c], s0 = st[0][2][c], s1 = st[0][3][c];
   if (MODE == MODE_INV) {
@@ -794,8 +810,9 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
       TK_STOP(3);
       TK_START();
       const Prefix16 pre = load_prefix(pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, q);
-      StepTape last;
-      const PassOut po = pass_forward<MODE_INV>(wl, pre, io, stI, tapeI, &last, c, q, (unsigned)lane);
+      constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
+      StepTape last[3];
+      const PassOut po = pass_forward<MODE_INV, REGTAPE>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
       TK_STOP(4);
       const float qk = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
       if (TRACE && a.trace_post != nullptr && q == 0 && active)
@@ -807,7 +824,7 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
         __builtin_amdgcn_wave_barrier();
         float res[8];
         TK_START();
-        pass_backward<MODE_INV>(tw, wq4, wl, io, nullptr, stI, tapeI, &last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
+        pass_backward<MODE_INV, REGTAPE>(tw, wq4, wl, io, nullptr, stI, tapeI, last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
                                 res, 0.f);
         TK_STOP(5);
         if (mean_mode) {
