@@ -85,6 +85,33 @@ class Episode:
     return [self.sample_path(t) for t in self.fetch()]
 
 
+def as_torch(dataset_dir: str, modalities: Sequence[str] = MODALITIES, transform=None, mode: bool = False,
+             only_array: bool = False) -> "torch.utils.data.Dataset":
+  """`CARLADataset.as_torch` (datasets/carla.py:617-695): the unbatched map-style dataset over `<dataset_dir>/*.npz` —
+  every item is `load_datum(..., dataformat="CHW")` without its non-array entries (`name`), with `transform` applied to
+  each value.  Files are taken in sorted order (the reference keeps `glob`'s).  `only_array` is accepted for signature
+  parity; the reference filters the non-array keys regardless of it."""
+  import glob
+  del only_array
+
+  class _Datums(torch.utils.data.Dataset):
+
+    def __init__(self):
+      self._npz_files = sorted(glob.glob(os.path.join(dataset_dir, "*.npz")))
+
+    def __len__(self) -> int:
+      return len(self._npz_files)
+
+    def __getitem__(self, idx: int):
+      sample = load_datum(self._npz_files[idx], modalities=modalities, mode=mode, dataformat="CHW")
+      sample = {k: v for k, v in sample.items() if isinstance(v, np.ndarray)}
+      if transform is not None:
+        sample = {k: transform(v) for k, v in sample.items()}
+      return sample
+
+  return _Datums()
+
+
 def goal_from_future(player_future: np.ndarray, num_goals: int = 10, stride: int = 8) -> np.ndarray:
   """`player_future[stride-1::stride][:num_goals, :2]`, padded by repeating the last waypoint."""
   g = np.asarray(player_future, dtype=np.float32)[stride - 1::stride][:num_goals, :2]

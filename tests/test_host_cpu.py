@@ -270,6 +270,18 @@ def test_g13_episode_written_by_reference(golden, tmp_path):
   ep2.append(lidar=g["datum0_lidar"], velocity=g["datum0_velocity"])
   with np.load(ep2.files()[0]) as z:
     np.testing.assert_array_equal(z["lidar"], g["datum0_lidar"])
+  # the unbatched dataset (`CARLADataset.as_torch`, datasets/carla.py:617-695) over the reference-written files:
+  # same length, keys, CHW shapes and values (a doubling transform was recorded)
+  ds = replay.as_torch(ep._episode_dir, modalities=("lidar", "velocity", "is_at_traffic_light", "traffic_light_state",
+                                                    "player_future"), transform=lambda v: v * 2.0, mode=True)
+  assert len(ds) == int(g["torch_len"])
+  by_name = {os.path.basename(f)[:-4]: j for j, f in enumerate(ds._npz_files)}
+  for i, tok in enumerate(tokens):
+    item = ds[by_name[tok]]
+    assert sorted(item.keys()) == list(g["torch%d_keys" % i])
+    for k in item:
+      assert tuple(np.asarray(item[k]).shape) == tuple(g["torch%d_%s_shape" % (i, k)]), k
+      assert float(np.asarray(item[k], dtype=np.float64).sum()) == float(g["torch%d_%s_sum" % (i, k)]), k
 
 
 def test_validation_of_raw_pointer_inputs():
