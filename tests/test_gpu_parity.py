@@ -1228,3 +1228,45 @@ def test_data_parallel_training_two_ranks():
   assert rec["local_grads_differ_by"] > 0        # the ranks really saw different data
   assert rec["avg_grad_rel_err"] <= 1e-6, rec
   assert rec["params_identical"], rec
+
+
+@pytest.mark.gpu
+def test_training_from_datum_files_end_to_end(dev, tmp_path):
+  """The reference's training data path with this package's pieces (dim/train.py:122-160, 175-213): datum files ->
+  `replay.as_torch` -> `torch.utils.data.DataLoader` -> `.to(device)` + `ImitativeModel.transform` (the `transform`
+  closure) -> `DIMTrainer.train_step`.  The loss of the first step equals the oracle's on the same batch and draws."""
+  from oatomobile_amd import DIMTrainer, replay
+  from oracle import reference_cpu as O
+  ep = replay.Episode(str(tmp_path), "train")
+  rng = np.random.default_rng(77)
+  for i in range(6):
+    o = synth_observation(np.random.default_rng(7700 + i))
+    fut = np.cumsum(np.abs(rng.normal(size=(80, 3))) * 0.3, axis=0).astype(np.float32)
+    ep.append("d%d" % i, lidar=o["lidar"], velocity=o["velocity"], is_at_traffic_light=o["is_at_traffic_light"],
+              traffic_light_state=o["traffic_light_state"], player_future=fut)
+  ds = replay.as_torch(ep._episode_dir, modalities=("lidar", "is_at_traffic_light", "traffic_light_state", "player_future",
+                                                    "velocity"))
+  loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, num_workers=0)
+  model = hip_model(41, dev)
+  trainer = DIMTrainer(model, lr=1e-3, max_batch=4, device=dev)
+  losses = []
+  for batch in loader:
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    batch = model.transform(batch)
+    assert tuple(batch["visual_features"].shape) == (3, 2, 100, 100) and tuple(batch["player_future"].shape) == (3, 4, 3)
+    y = batch["player_future"][..., :2].contiguous()
+    keep = torch.ones(3, 1280, device=dev)
+    if not losses:  # first batch: the oracle's loss on the same inputs (train-mode BatchNorm, no dropout / noise)
+      ref = oracle_model(41)
+      ref.train()
+      for mod in ref.modules():
+        if isinstance(mod, torch.nn.Dropout):
+          mod.eval()  # the step below runs with an all-ones keep mask
+      with torch.no_grad():
+        z = O.params(ref, batch["visual_features"].cpu(), batch["velocity"].cpu().reshape(3, 3),
+                     batch["is_at_traffic_light"].cpu().reshape(3, 1), batch["traffic_light_state"].cpu().reshape(3, 1))
+        _, lp, lad = O.flow_inverse(ref, y.cpu(), z)
+        loss_ref = float(-(lp - lad).mean())
+    losses.append(float(trainer.train_step(batch, y=y, dropout_mask=keep)))
+  assert len(losses) == 2 and all(np.isfinite(losses))
+  assert abs(losses[0] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (losses[0], loss_ref)
