@@ -17,7 +17,7 @@ The reference has no distributed code.  The path shards three ways:
   winner — the near-linear mode for candidate throughput.
 """
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

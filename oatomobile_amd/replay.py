@@ -16,7 +16,7 @@ from the recorded future: every `stride`-th waypoint of `player_future`, first `
 import io
 import os
 import uuid
-from typing import Iterable, List, Mapping, Optional, Sequence
+from typing import List, Mapping, Optional, Sequence
 
 import numpy as np
 import torch
