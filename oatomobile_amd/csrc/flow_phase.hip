@@ -981,6 +981,9 @@ hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* s
   // cost model from the measurements: an 8-wave workgroup (two waves per SIMD) takes twice as long as a 4-wave one
   // (2.3 vs 1.15 ms for 10 Adam steps at K = 4), a 2-wave one about as long as a 4-wave one (1.1 ms); a launch is
   // ceil(workgroups / CUs) rounds of that.  Ties go to the larger workgroup (fewer operand DMA streams).
+#ifdef RIP_FORCE_WPB  // development: pin the workgroup shape (profiling the register-tape builds at full launches)
+  return launch_phase_wpb<RIP_FORCE_WPB>(a, mw_all, pre, tape, items, s);
+#endif
   auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
   const double c8 = 2.0 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
   if (c8 <= c4 && c8 <= c2) return launch_phase_wpb<8>(a, mw_all, pre, tape, items, s);
