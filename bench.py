@@ -455,9 +455,14 @@ def _bench_online(args, models, dev, host_batch):
   obs = [dict(lidar=lidar[i], velocity=vec[i, :3], is_at_traffic_light=vec[i, 3], traffic_light_state=vec[i, 4],
               goal=np.c_[goal[i], np.zeros((goal.shape[1], 1), np.float32)]) for i in range(8)]
   res = {}
-  for name, graph in (("graph", True), ("eager", False)):
+  # the agent's own default encoder is fp32 (the parity mode); at one observation it is also the faster one (fewer,
+  # simpler launches: 283 vs 302 us), so the headline of this line is the class used as it comes, the bench step's
+  # encoder (`--encoder-dtype`, bf16) is reported next to it
+  for name, graph, enc in (("graph", True, "fp32"), ("eager", False, "fp32"), ("graph_" + args.encoder_dtype, True, args.encoder_dtype)):
+    if name in res:
+      continue
     a1 = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=args.candidates,
-                  num_steps=args.search_steps, max_batch=1, seed=0, device=dev, encoder_dtype=args.encoder_dtype, graph=graph)
+                  num_steps=args.search_steps, max_batch=1, seed=0, device=dev, encoder_dtype=enc, graph=graph)
     n = args.online_calls if graph else max(20, args.online_calls // 5)
     for i in range(10):
       a1(dict(obs[i % 8]))
@@ -471,11 +476,15 @@ def _bench_online(args, models, dev, host_batch):
     lat = np.sort(np.asarray(lat)) * 1e6
     captured = any(st["graph"] is not None for st in a1._online.values())
     res[name] = {"calls_per_s": n / dt, "p50_us": float(lat[len(lat) // 2]), "p99_us": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]),
-                 "mean_us": float(lat.mean()), "hipgraph": captured}
-  return {"calls_per_s": res["graph"]["calls_per_s"], "latency_us": res["graph"]["mean_us"], "p50_us": res["graph"]["p50_us"],
-          "p99_us": res["graph"]["p99_us"], "hipgraph_captured": res["graph"]["hipgraph"], "eager": res["eager"],
-          "pattern": "agent(observation): B=1 sequential, host numpy observation in, [30,3] numpy plan out; pinned "
-                     "staging + H2D + transform + K encoders + search + D2H + stream sync inside every call"}
+                 "mean_us": float(lat.mean()), "hipgraph": captured, "encoder": enc}
+  out = {"calls_per_s": res["graph"]["calls_per_s"], "latency_us": res["graph"]["mean_us"], "p50_us": res["graph"]["p50_us"],
+         "p99_us": res["graph"]["p99_us"], "hipgraph_captured": res["graph"]["hipgraph"], "encoder": "fp32 (RIPAgent default)",
+         "eager": res["eager"],
+         "pattern": "agent(observation): B=1 sequential, host numpy observation in, [30,3] numpy plan out; pinned "
+                    "staging + H2D + transform + K encoders + search + D2H + stream sync inside every call"}
+  if "graph_" + args.encoder_dtype in res:
+    out["with_" + args.encoder_dtype + "_encoder"] = res["graph_" + args.encoder_dtype]
+  return out
 
 
 def _bench_pcie(args, encode_search, host_batches, dev, B, C, G, timed):
