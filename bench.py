@@ -10,9 +10,12 @@ Workload (BASELINE.json configs[2]): K=4 ensemble, algorithm "WCM" (as coded), N
 (`oatomobile_amd.weights.synthetic_state_dict`), bf16 MobileNetV2 encoder (bf16 MFMA, fp32 accumulate) + fp32 flow /
 search — the precision configs[2] names; `--encoder-dtype fp32` is the 1e-4-parity mode (reported as `fp32_parity`).
 
-A *step* = one pass of the whole hot path (R1..R11: transform, K encoders + merger, plan search, candidate
-selection, plan copy-back) over one batch of `--obs-batch` observations already resident in HBM; every observation
-is one `RIPAgent.act()` call, so value = obs_batch * steps * n_gpus / time.
+A *step* = the whole unit of SURVEY.md §8(d), R1..R11, over one batch of `--obs-batch` observations: the float32
+observations start in PINNED HOST memory (what R1's host preparation leaves behind), their H2D copy runs on a copy
+stream double-buffered under the previous step's kernels, then transform, K encoders + merger, plan search, candidate
+selection with the [30,3] float64 interpolation (R11 on the device) and the copy of the [B,30,3] float64 plans back
+to pinned host memory.  Every observation is one `RIPAgent.act()` call: value = obs_batch * steps * n_gpus / time.
+`hbm_resident` is the same step on observations already in HBM without R11 (R2..R10: last round's headline).
 
 Multi-GPU (`--mode`; one process per GPU, RCCL):
   replay      (default) observation-parallel replicas, no data-path collective                  -> "weak"
@@ -27,7 +30,8 @@ The JSON line also carries
                   contract-formula figure is reported separately (it prices work the kernel legitimately skips)
   cpu_baseline  — the CPU oracle (oracle/reference_cpu.py, "port") timed on this box's host cores
   online        — `agent(observation)` one call at a time, host numpy in -> host numpy out (H2D + D2H inside)
-  pcie_inclusive— the same steps with observations staged in pinned host memory, H2D overlapped on a copy stream
+  hbm_resident  — the step without R1 / R11: observations resident in HBM, [B,4,2] plans copied back
+  backend / world_size_seen — what torch.distributed reports (a mismatch with --gpus aborts the run)
   scoring_only  — rip/agent.py:109-127 scoring mode (no gradient search): encode + K x N scores + aggregation
 """
 
@@ -70,11 +74,30 @@ def synth_batch(rng, B, C, G=10):
   return lidar.astype(np.float32), vec.astype(np.float32), goal.astype(np.float32)
 
 
-def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype):
+def _measured(args):
+  """profiles/measured.json: HBM-side bytes per launch from the round's rocprofv3 PMC passes (FETCH_SIZE x 2 — the
+  gfx950 correction of MI355X_MICROARCH.md — + WRITE_SIZE, separate passes), written by tools/prof_round.sh next to
+  the CSV summaries it condenses.  Used only when it was taken at this launch configuration (observations scale the
+  bytes linearly); otherwise the line says so instead of quoting a stale constant."""
+  try:
+    with open(os.path.join(ROOT, "profiles", "measured.json")) as f:
+      m = json.load(f)
+    c = m["config"]
+    same = (c["models"] == args.models and c["candidates"] == args.candidates and c["search_steps"] == args.search_steps and
+            c["channels"] == args.channels and c["encoder_dtype"] == args.encoder_dtype and c["algorithm"] == args.algorithm)
+    if not same:
+      return None
+    m["scale"] = args.obs_batch / float(c["obs_batch"])
+    return m
+  except (OSError, KeyError, ValueError):
+    return None
+
+
+def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype, measured=None):
   """The encoder stage against its three ceilings.  Work per (model, observation) from the architecture (arch.py):
   pointwise convs 68.63 M MAC on the matrix cores, depthwise + stem (4.64 + 0.72 C) M fp32 FMA on the vector ALUs;
-  HBM bytes MEASURED at the bench configuration (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all encoder kernels of one
-  512-observation x 4-model step, profiles/r2/pmc_summary_v6.csv: 2.296 GB) scaled by (B K) / 2048."""
+  HBM bytes MEASURED (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all encoder kernels of one step, read from
+  profiles/measured.json and scaled by the observation count)."""
   t = enc_ms * 1e-3
   pw_flops = 2.0 * 68.627e6 * B * K
   valu_fma = (4.641e6 + 0.720e6 * C) * B * K
@@ -85,12 +108,14 @@ def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype):
           "note": "transform + stem + MobileNetV2 features (%s) + classifier + merger.  `layerwise_GBps` = SURVEY §8d "
                   "bytes_pre + bytes_enc (every layer's input and output through HBM) / time: what the UNFUSED network "
                   "would have to move, not what the fused kernels move." % enc_dtype}
-  if enc_dtype == "bf16" and C == 2:
-    meas = 2.296e9 * (B * K) / 2048.0
-    line.update({"measured_hbm_bytes": meas, "measured_GBps": meas / t / 1e9, "frac_hbm": meas / t / 1e9 / PEAK_HBM_GBS})
-    line["note"] += ("  `measured_*`: HBM bytes from the PMC passes in profiles/r2 (fused blocks keep the expanded tensors "
-                     "in LDS: 2.30 GB per step instead of the layer-wise 12.2 GB).  The stage sits far below all three "
-                     "ceilings: 25 dependent launches of small-tile work (16-96 channel GEMMs, 9-tap depthwise).")
+  if measured is not None and measured.get("encoder", {}).get("traffic_bytes"):
+    meas = measured["encoder"]["traffic_bytes"] * measured["scale"]
+    line.update({"measured_hbm_bytes": meas, "measured_GBps": meas / t / 1e9, "frac_hbm": meas / t / 1e9 / PEAK_HBM_GBS,
+                 "measured_source": measured.get("source")})
+    line["note"] += ("  `measured_*`: HBM bytes from the PMC passes named in `measured_source` (the fused blocks keep the "
+                     "expanded tensors in LDS, so this is far below the layer-wise count).")
+  else:
+    line["measured_hbm_bytes"] = None
   return line
 
 
@@ -117,29 +142,32 @@ def _cpu_baseline_worker(argv):
       O.rip_call(models, lidar[0], vec[0, :3], vec[0, 3], vec[0, 4], goal3, x0=x0, algorithm=algo, num_steps=nsteps,
                  as_written=as_written)
 
-    one()
+    for _ in range(warm):
+      one()
     t0 = time.perf_counter()
     n = 0
     while True:
       one()
       n += 1
       dt = time.perf_counter() - t0
-      if dt > budget or n >= 200:
+      if n >= calls or dt > budget:
         break
     return {"n": n, "dt": dt, "threads": nthreads}
 
-  out = {"fair": run(threads, False, seconds), "fair_1thread": run(1, False, seconds / 3.0),
-         "as_written": run(threads, True, seconds / 3.0)}
+  # BASELINE.md §4 protocol on the variant the speed-up is quoted against (fair, one thread: the fastest setting of
+  # this batch-1 workload): 50 warm-up calls, 200 timed calls; the other variants are bounded samples
+  warm, calls = 50, 200
+  fair1 = run(1, False, 6.0 * seconds)
+  warm, calls = 3, 200
+  out = {"fair_1thread": fair1, "fair": run(threads, False, seconds / 2.0), "as_written": run(threads, True, seconds / 2.0)}
   print(json.dumps(out))
 
 
 def cpu_baseline(args):
   """Bounded sample of the same workload on the CPU oracle ("port")."""
-  try:
-    avail = len(os.sched_getaffinity(0))
-  except AttributeError:
-    avail = os.cpu_count() or 1
-  threads = max(1, min(avail, 16))  # the oracle's ops are tiny; more threads only add barrier cost
+  from oatomobile_amd.replay import effective_cpus
+  avail = effective_cpus()  # affinity mask capped by the cgroup CPU quota (the bench container: 16 of 256 threads)
+  threads = avail  # all host cores this process may use; one thread is timed beside it
   cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(args.models), str(args.candidates),
          str(args.channels), args.algorithm, str(args.search_steps), str(args.cpu_seconds), str(threads)]
   env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
@@ -147,7 +175,7 @@ def cpu_baseline(args):
     env.pop(k, None)
   base = {"unit": "calls/s", "cores": threads, "kind": "port"}
   try:
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=max(180.0, 12 * args.cpu_seconds), env=env, cwd=ROOT)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=max(240.0, 20 * args.cpu_seconds), env=env, cwd=ROOT)
     r = json.loads(out.stdout.strip().splitlines()[-1])
   except Exception as e:  # timeout / crash: report, never hang
     base.update({"value": None, "sample": "cpu baseline failed: %r" % (e,)})
@@ -159,10 +187,11 @@ def cpu_baseline(args):
   base.update({
       "value": f["n"] / f["dt"],
       "cores": f["threads"],
-      "sample": "%d sequential act() calls (K=%d, N=%d, %d Adam steps; encoders under no_grad = the 'fair' variant) of "
-                "oracle/reference_cpu.py (PyTorch CPU), %d thread(s) of %d available host cores (the faster of 1 and "
-                "%d threads), %.1f s" % (f["n"], args.models, args.candidates, args.search_steps, f["threads"], avail,
-                                         threads, f["dt"]),
+      "sample": "%d sequential act() calls after 50 warm-ups (K=%d, N=%d, %d Adam steps; encoders under no_grad = the "
+                "'fair' variant) of oracle/reference_cpu.py (PyTorch CPU), %d thread(s) of %d available host cores (the "
+                "faster of 1 and %d threads; os.cpu_count() = %d), %.1f s" %
+                (f["n"], args.models, args.candidates, args.search_steps, f["threads"], avail, threads,
+                 os.cpu_count() or 0, f["dt"]),
       "variants": {
           "fair_%dthreads" % threads: r["fair"]["n"] / r["fair"]["dt"],
           "fair_1thread": r["fair_1thread"]["n"] / r["fair_1thread"]["dt"],
@@ -206,10 +235,10 @@ def main():
   ap.add_argument("--algorithm", default="WCM")
   ap.add_argument("--search-steps", type=int, default=10)
   ap.add_argument("--mode", default="replay", choices=["replay", "candidates", "models"])
-  ap.add_argument("--cpu-seconds", type=float, default=9.0)
+  ap.add_argument("--cpu-seconds", type=float, default=5.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (online, pcie, scoring, fp32, C=4)")
-  ap.add_argument("--online-calls", type=int, default=300)
+  ap.add_argument("--online-calls", type=int, default=1000)
   if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
     return _cpu_baseline_worker(sys.argv[2:])
   args = ap.parse_args()
@@ -230,13 +259,26 @@ def main():
   torch.cuda.set_device(dev_index)
   dev = torch.device("cuda", dev_index)
   dist = None
-  if world > 1:
+  # a process group exists when there is more than one rank, and also for ONE rank of the --mode candidates / models
+  # compositions (RIP_DIST_ALWAYS_COLLECTIVE=1 then sends the one-rank group through RCCL: the collective code path
+  # of oatomobile_amd/distributed.py executes on a one-GPU box)
+  if world > 1 or args.mode != "replay":
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+      os.environ.setdefault("MASTER_PORT", str(_free_port()))
+      os.environ.setdefault("RIP_DIST_ALWAYS_COLLECTIVE", "1")
     if backend == "nccl":
       dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     else:
       dist.init_process_group(backend=backend, rank=rank, world_size=world)
+  # what torch.distributed itself reports goes into every line; a silent fallback or a rank mismatch aborts here
+  backend_seen = dist.get_backend() if dist is not None else "none (single process, no process group)"
+  world_seen = dist.get_world_size() if dist is not None else 1
+  if world_seen != args.gpus or (dist is not None and backend_seen != backend):
+    raise SystemExit("bench.py: torch.distributed reports backend %r / world size %d, expected %r / %d" %
+                     (backend_seen, world_seen, backend, args.gpus))
+  args.backend_seen, args.world_seen = backend_seen, world_seen
 
   import __graft_entry__ as entry
   if rank == 0:
@@ -246,7 +288,7 @@ def main():
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
 
   def sync_all():
-    if dist is not None:
+    if dist is not None and world > 1:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -260,7 +302,7 @@ def main():
       step_fn(i, events[i] if events is not None else None)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
+    if dist is not None and world > 1:
       t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       elapsed = float(t.item())
@@ -280,19 +322,35 @@ def main():
   enc_dtype = _lib.ENC_DTYPES[args.encoder_dtype]
   h = agent._handle.raw
 
-  # distinct observation batches per rank and per step parity (resident in HBM before timing)
+  # distinct observation batches per rank and per step parity: float32 in PINNED HOST memory (the state R1's host
+  # preparation, rip/agent.py:59-75, leaves an observation in); two device slots, a copy stream
   rng = np.random.default_rng(1000 + rank)
   host_batches = [synth_batch(rng, B, C) for _ in range(2)]
-  batches = [tuple(torch.from_numpy(a).to(dev) for a in hb) for hb in host_batches]
+  pinned = [tuple(torch.from_numpy(a).pin_memory() for a in hb) for hb in host_batches]
+  slots = [tuple(torch.empty_like(t, device=dev) for t in pinned[0]) for _ in range(2)]
   x0 = agent._x0(B)
   z = torch.empty(K, B, 64, device=dev)
   plan = torch.empty(B, 4, 2, device=dev)
+  plan30 = torch.empty(B, 30, 3, device=dev, dtype=torch.float64)
   loss = torch.empty(B, N, device=dev)
   plan_host = torch.empty(B, 4, 2).pin_memory()
-  G = batches[0][2].shape[1]
+  plan30_host = [torch.empty(B, 30, 3, dtype=torch.float64).pin_memory() for _ in range(2)]
+  G = pinned[0][2].shape[1]
   stream = torch.cuda.current_stream(dev)
+  copy_stream = torch.cuda.Stream(device=dev)
+  ready = [torch.cuda.Event() for _ in range(2)]
+  freed = [torch.cuda.Event() for _ in range(2)]
 
-  def encode_search(lidar, vec, goal, ev=None, handle=h, zz=z, enc=enc_dtype):
+  def upload(i):
+    """H2D of step i's observations into slot i & 1, on the copy stream, once the slot's previous user is done."""
+    j = i & 1
+    with torch.cuda.stream(copy_stream):
+      copy_stream.wait_event(freed[j])
+      for d, src in zip(slots[j], pinned[j]):
+        d.copy_(src, non_blocking=True)
+      ready[j].record(copy_stream)
+
+  def encode_search(lidar, vec, goal, ev=None, handle=h, zz=z, enc=enc_dtype, interp=None):
     s = _lib.current_stream(dev)
     if ev is not None:
       ev[0].record(stream)
@@ -303,18 +361,53 @@ def main():
                               _lib.ptr(plan), None, _lib.ptr(loss), None, None, None, None, s))
     if ev is not None:
       ev[2].record(stream)
-    plan_host.copy_(plan, non_blocking=True)  # the reference's D2H (rip/agent.py:139)
+    if interp is None:
+      plan_host.copy_(plan, non_blocking=True)  # the reference's D2H (rip/agent.py:139)
+    else:  # R11 (rip/agent.py:141-151) on the device, then the D2H of what act() hands to the controller
+      _lib.check(lib.rip_interpolate_plans(_lib.ptr(plan), B, _lib.ptr(plan30, torch.float64), s))
+      interp.copy_(plan30, non_blocking=True)
 
-  def step(i, ev):
-    encode_search(*batches[i & 1], ev=ev)
+  tick = [0]  # steps since prime(): warm-up and timed steps are ONE pipeline (slot parity carries over)
 
+  def make_unit_step(enc):
+    def step(_, ev):
+      i = tick[0]
+      tick[0] += 1
+      j = i & 1
+      upload(i + 1)  # the next step's observations travel under this step's kernels
+      stream.wait_event(ready[j])
+      encode_search(*slots[j], ev=ev, enc=enc, interp=plan30_host[j])
+      freed[j].record(stream)
+    return step
+
+  def prime():
+    torch.cuda.synchronize()
+    tick[0] = 0
+    for j in range(2):
+      freed[j].record(stream)
+    upload(0)
+
+  prime()
   events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-  elapsed = timed(step, args.steps, args.warmup, events)
-  assert torch.isfinite(plan).all()
+  elapsed = timed(make_unit_step(enc_dtype), args.steps, args.warmup, events)
+  assert torch.isfinite(plan).all() and bool(np.isfinite(plan30_host[0].numpy()).all())
+  # the [30,3] float64 plans on the host are the reference's R11 of the device's [4,2] plans, bit for bit
+  from oatomobile_amd.agents import interpolate_plan
+  last = (tick[0] - 1) & 1
+  r11_ok = all(np.array_equal(plan30_host[last].numpy()[i], interpolate_plan(plan.cpu().numpy()[i])) for i in (0, B // 2, B - 1))
   enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
   search_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
   calls = B * args.steps * world
   value = calls / elapsed
+  h2d_bytes = sum(t.numel() * 4 for t in pinned[0])
+
+  # the same step without R1 / R11 (observations resident in HBM, [B,4,2] plans back): last round's `value`
+  batches = [tuple(torch.from_numpy(a).to(dev) for a in hb) for hb in host_batches]
+  hbm_steps = max(4, args.steps // 2)
+  hbm_el = timed(lambda i, ev: encode_search(*batches[i & 1]), hbm_steps, 2)
+  hbm_line = {"calls_per_s": B * hbm_steps * world / hbm_el, "ms_per_step": 1e3 * hbm_el / hbm_steps,
+              "note": "R2..R10 on observations already in HBM, [B,4,2] fp32 plans copied back: no H2D, no R11 (round 2's "
+                      "headline definition)"}
 
   extras = {}
   use_mfma = (B * N >= 2048 and N % 16 == 0)  # rip_search auto: the phase-sequential MFMA kernel (flow_phase.hip)
@@ -343,7 +436,7 @@ def main():
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
 
   # ---------------- secondary lines (rank 0, N = 1 only; untimed by the driver's contract) ----------------
-  online = pcie = scoring = fp32_line = c4_line = train_line = replay_line = None
+  online = scoring = fp32_line = c4_line = train_line = replay_line = None
   if rank == 0 and world == 1 and not args.no_extras:
     def extra(fn, *a):
       """A secondary line must never cost the headline: a failure becomes {"error": ...} in its place."""
@@ -355,15 +448,24 @@ def main():
 
     def fp32_step():
       e32 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(5)]
-      el = timed(lambda i, ev: encode_search(*batches[i & 1], ev=ev, enc=0), 5, 2, e32)
+      prime()
+      el = timed(make_unit_step(0), 5, 2, e32)
+      # plan-level effect of the bf16 encoder on THIS batch: the fp32-encoder plans of the last step's slot against the
+      # bf16-encoder plans of the same observations
+      j = (tick[0] - 1) & 1
+      p32 = plan.clone()
+      encode_search(*slots[j], enc=enc_dtype)
+      dev_m = (plan - p32).norm(dim=(1, 2)) / 2.0  # RMS-like: metres per waypoint coordinate pair
+      scale = float(p32.abs().max())
       return {"calls_per_s": B * 5 / el, "ms_per_step": 1e3 * el / 5,
               "encoder_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in e32])),
-              "note": "same step with the fp32 encoder: the mode in which z, plans and log-probs hold the 1e-4 "
-                      "parity contract (the bf16 encoder's z deviates by up to ~6 % of max|z|; tests report the "
-                      "plan-level effect)"}
+              "bf16_vs_fp32_plan_deviation_m": {"max_abs": float((plan - p32).abs().max()), "mean_abs": float((plan - p32).abs().mean()),
+                                                "plan_scale_m": scale},
+              "note": "the same whole-unit step with the fp32 encoder: the mode in which z, plans and log-probs hold the "
+                      "1e-4 parity contract.  `bf16_vs_fp32_plan_deviation_m`: what the bf16 encoder of `value` (the "
+                      "precision BASELINE configs[2] names) moves the winning plans by on this batch"}
 
     online = extra(_bench_online, args, models, dev, host_batches[0])
-    pcie = extra(_bench_pcie, args, encode_search, host_batches, dev, B, C, G, timed)
     scoring = extra(_bench_scoring, args, lib, h, batches, z, enc_dtype, dev, timed, K, N, B, G, algo)
     if args.encoder_dtype == "bf16":
       fp32_line = extra(fp32_step)
@@ -372,6 +474,7 @@ def main():
     train_line = extra(_bench_train, args, dev, timed)
     replay_line = extra(_bench_replay, args, agent, dev, B, C)
   if rank == 0:
+    measured = _measured(args)
     flow_flops = 2.0 * 3.0 * (1 + K) * 4 * FLOW_MAC_PER_STEP * N * S * B  # SURVEY §8(d) flops_flow(grad)
     sb = 2 if args.encoder_dtype == "bf16" else 4  # bytes per encoder element (SURVEY §8d `s`)
     enc_bytes = B * (200 * 200 * C * 4 + 100 * 100 * C * 4) + K * (B * (ENC_ACT_ELEMS + 10000 * (C - 2)) * sb + ENC_WEIGHT_ELEMS * sb)
@@ -391,7 +494,8 @@ def main():
         # model and Adam step (F_0: 3 steps, inverses: 2 steps, the third stays in registers; a step is 12 or 16 rows
         # of 1 KiB -- r, z, gh_n, hprev; n is recomputed -- + 256 B of ReLU mask); rocprofv3 FETCH_SIZE (x2 gfx950
         # correction) + WRITE_SIZE (profiles/)
-        "traffic": (2.0 * blocks16 * S * ((12 + 16 + 16) * 1024 + 3 * 256 + (K - 1) * ((12 + 16) * 1024 + 2 * 256))) if use_mfma else None,
+        "traffic": measured["search"]["traffic_bytes"] * measured["scale"] if (measured and use_mfma and measured.get("search")) else None,
+        "traffic_source": measured.get("source") if measured else "no PMC profile at this launch configuration in profiles/measured.json",
         "ms_per_launch": search_ms,
         "contract_tflops": flow_flops / (search_ms * 1e-3) / 1e12,
         "contract_over_peak": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
@@ -406,7 +510,7 @@ def main():
                 "(inverse_0(F_0(x)) == x) and K adjoints per candidate, none of which the algorithm needs, so it can "
                 "exceed the peak.  `whole_act_*`: §8(d) algorithmic bytes per act (weights amortised over the batch) x "
                 "calls/s vs 8 TB/s.  `traffic`: the adjoint tape.",
-        "encoder": _encoder_roofline(enc_ms, enc_bytes, B, K, C, args.encoder_dtype),
+        "encoder": _encoder_roofline(enc_ms, enc_bytes, B, K, C, args.encoder_dtype, measured),
     }
     roof.update(extras)
     out = {
@@ -427,8 +531,14 @@ def main():
                    "obs_per_step_per_gpu": B, "models": K, "candidates": N, "bev_channels": C,
                    "parallelism": "observation-parallel replicas x%d (no data-path collective)" % world},
         "roofline": roof,
+        "unit_of_work": {"covers": "R1..R11: pinned-host float32 observations -> H2D (copy stream, double-buffered) -> transform -> "
+                           "K encoders + merger -> plan search -> selection + [30,3] float64 interpolation -> D2H to pinned host",
+                         "h2d_MB_per_step": h2d_bytes / 1e6, "d2h_KB_per_step": B * 30 * 3 * 8 / 1e3,
+                         "r11_bit_identical_to_reference_arithmetic": bool(r11_ok)},
+        "hbm_resident": hbm_line,
+        "backend": args.backend_seen,
+        "world_size_seen": args.world_seen,
         "online": online,
-        "pcie_inclusive": pcie,
         "scoring_only": scoring,
         "fp32_parity": fp32_line,
         "bev_c4": c4_line,
@@ -464,7 +574,7 @@ def _bench_online(args, models, dev, host_batch):
     a1 = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=args.candidates,
                   num_steps=args.search_steps, max_batch=1, seed=0, device=dev, encoder_dtype=enc, graph=graph)
     n = args.online_calls if graph else max(20, args.online_calls // 5)
-    for i in range(10):
+    for i in range(50):  # 50 warm-ups, >= 1000 timed calls
       a1(dict(obs[i % 8]))
     lat = []
     t0 = time.perf_counter()
@@ -485,44 +595,6 @@ def _bench_online(args, models, dev, host_batch):
   if "graph_" + args.encoder_dtype in res:
     out["with_" + args.encoder_dtype + "_encoder"] = res["graph_" + args.encoder_dtype]
   return out
-
-
-def _bench_pcie(args, encode_search, host_batches, dev, B, C, G, timed):
-  """SURVEY §8(d) staging: observations start in pinned HOST memory; the H2D of step i+1 runs on a copy stream
-  under the compute of step i (two device slots), the plan D2H as before."""
-  pinned = [tuple(torch.from_numpy(a).pin_memory() for a in hb) for hb in host_batches]
-  slots = [tuple(torch.empty_like(t, device=dev) for t in pinned[0]) for _ in range(2)]
-  copy_stream = torch.cuda.Stream(device=dev)
-  ready = [torch.cuda.Event() for _ in range(2)]
-  freed = [torch.cuda.Event() for _ in range(2)]
-  main = torch.cuda.current_stream(dev)
-
-  def upload(i):
-    j = i & 1
-    with torch.cuda.stream(copy_stream):
-      copy_stream.wait_event(freed[j])
-      for d, s in zip(slots[j], pinned[i & 1]):
-        d.copy_(s, non_blocking=True)
-      ready[j].record(copy_stream)
-
-  for j in range(2):
-    freed[j].record(main)
-  upload(0)
-
-  def step(i, ev):
-    j = i & 1
-    upload(i + 1)  # next step's observations, overlapped
-    main.wait_event(ready[j])
-    encode_search(*slots[j])
-    freed[j].record(main)
-
-  steps = max(4, args.steps // 2)
-  el = timed(step, steps, 2)
-  nbytes = sum(t.numel() * 4 for t in pinned[0])
-  return {"calls_per_s": B * steps / el, "ms_per_step": 1e3 * el / steps, "h2d_MB_per_step": nbytes / 1e6,
-          "note": "inputs staged in pinned host memory, H2D double-buffered on a copy stream under the previous "
-                  "step's kernels (PCIe Gen5 x16: %.1f ms of transfer per step at 63 GB/s); never `value`" %
-                  (nbytes / 63e9 * 1e3)}
 
 
 def _bench_replay(args, agent, dev, B, C):
@@ -693,6 +765,7 @@ def _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all):
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32 flow/search, %s encoder" % args.encoder_dtype, "data": "synthetic",
         "candidate_plans_per_s": calls / elapsed * n_total,
+        "backend": args.backend_seen, "world_size_seen": args.world_seen,
         "config": {"workload": "RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV" % (K, args.algorithm, n_total, S, C),
                    "obs_per_step": B, "models": K, "candidates": n_total, "bev_channels": C, "mode": args.mode, "parallelism": par}}))
   if dist is not None:

@@ -207,13 +207,23 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
                     int G, int num_steps, float lr, float epsilon, float* y_dev, float* trace_loss_dev,
                     rip_stream_t stream);
 
-/* Whole act() for B observations in one call: rip_encode_raw + rip_search.
+/* R11 — the plan post-processing at the end of RIPAgent.__call__ / DIMAgent.__call__ (rip/agent.py:141-151,
+ * dim/agent.py:74-84): scipy.interpolate.interp1d (linear) through the T = 4 waypoints at ticks 0, 10, 20, 30
+ * (player_future_length 40 // T), sampled at ticks 0..29, z = 0 appended.  plan_dev [B,4,2] fp32 ->
+ * out_dev [B,RIP_PLAN_ROWS,3] float64 — the dtype and, operation for operation, the arithmetic of the reference
+ * (float32 knot difference, float64 slope / product / sum), so the result is bit-identical.  Stateless. */
+#define RIP_PLAN_ROWS 30
+int rip_interpolate_plans(const float* plan_dev, int B, double* out_dev, rip_stream_t stream);
+
+/* Whole act() for B observations in one call: rip_encode_raw + rip_search (+ R11).
  * lidar_dev [B,H,W,C] (channels_last=1) or [B,C,H,W]; vec_dev [B,5];
- * goal_dev [B,G,2]; x0_dev [B,N,4,2]; plan_dev [B,4,2].  Scratch lives in the
- * handle (B <= max_batch, N <= max_candidates). */
+ * goal_dev [B,G,2]; x0_dev [B,N,4,2]; plan_dev [B,4,2] (NULL to skip);
+ * plan_interp_dev [B,RIP_PLAN_ROWS,3] float64 = what the agent's __call__ returns per observation (R11 fused into
+ * the candidate selection; NULL to skip).  Scratch lives in the handle (B <= max_batch, N <= max_candidates). */
 int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
             const float* goal_dev, const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr,
-            float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream);
+            float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, double* plan_interp_dev,
+            rip_stream_t stream);
 
 /* N3 — the DIM training step, oatomobile/baselines/torch/dim/train.py:175-213:
  *   z = model._params(...) in TRAIN mode (MobileNetV2 BatchNorm on batch statistics with the running-stat update,
@@ -229,7 +239,9 @@ int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int
  *   target, already perturbed by the caller: train.py:184-189), dropout_mask_dev [B,1280] keep/scale factors (0 or
  *   1/(1-p); NULL = no dropout).  batch_stats != 0: BatchNorm train mode, the running statistics inside params_dev are
  *   updated (momentum 0.1); 0: running statistics are used and left alone ("frozen" BatchNorm / evaluate_step).
- *   Writes grads_dev (running-statistic slots: 0), *loss_dev, z_dev [B,64] (optional).
+ *   Writes grads_dev (running-statistic slots: 0), *loss_dev, z_dev [B,64] (optional).  grads_dev == NULL: forward
+ *   only (evaluate_step, train.py:229-249): loss and z, no backward launches, no gradient buffer touched.
+ *   Any B in [1, max_batch] (batch statistics of one observation are defined: the smallest map is 4 x 4).
  * rip_train_adam: torch.optim.Adam step `step` (1-based) on the entries with trainable_dev[i] != 0
  *   (rip_train_trainable_mask: everything but the running statistics); weight_decay is added to the gradient.
  * Both enqueue on `stream` without synchronising; rip_train_create / _destroy / _trainable_mask are setup calls. */

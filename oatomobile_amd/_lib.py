@@ -48,8 +48,9 @@ SIGNATURES = [
       c_void_p]),
     ("rip_act", c_int, [
         c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-        c_float, c_float, c_int, c_void_p, c_void_p, c_void_p
+        c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p
     ]),
+    ("rip_interpolate_plans", c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     ("rip_set_option", c_int, [c_void_p, c_int, c_int]),
     ("rip_num_models", c_int, [c_void_p]),
     ("rip_in_channels", c_int, [c_void_p]),
@@ -67,7 +68,7 @@ SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float,
       c_void_p]),
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}

@@ -74,7 +74,8 @@ hipError_t launch_score(const float* flow_w, int k0, int K, const float* z, cons
                         int N, int G, float eps, float* S, hipStream_t s);
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
 hipError_t launch_select_best(const float* plans, const float* loss_best, int B, int N, float* plan, int32_t* best,
-                              hipStream_t s);
+                              double* interp /*[B][30][3] or nullptr*/, hipStream_t s);
+hipError_t launch_interpolate_plans(const float* plan /*[B][4][2]*/, int B, double* out /*[B][30][3]*/, hipStream_t s);
 hipError_t launch_dim_select(const float* flow_w_k, const float* z, const float* x0, const float* trace_loss,
                              const float* trace_x, int B, int num_steps, float* y, float* trace_mean, hipStream_t s);
 hipError_t launch_cil_decode(const float* feat, const float* vec, const float* w, int B, int T, float* y, hipStream_t s);  // cil.hip
@@ -83,6 +84,9 @@ hipError_t launch_lidar_bev(const float* points, const int* offsets, int B, floa
 hipError_t launch_aggregate_scores(const float* S, int K, int B, int N, int algorithm, float* loss, int32_t* best,
                                    hipStream_t s);
 size_t search_lds_bytes(int K);
+// raises a kernel's dynamic-LDS limit to the CU's 160 KiB, once per (kernel, device); thread-safe, any device index
+hipError_t allow_lds(const void* fn);
+int device_cu_count();  // compute units of the current device (cached per device)
 // MFMA-batched variant (16 candidates per wave); needs N % 16 == 0, K <= 4, no traces
 bool search_mfma_supported(const SearchArgs& a);
 size_t search_mfma_tape_bytes(int B, int N, int K);

@@ -22,6 +22,7 @@
 #include "train.h"
 
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 
@@ -1004,8 +1005,32 @@ __global__ __launch_bounds__(NW * 64) void search_pipe_kernel(SearchArgs a) {
 }
 
 // per observation: the candidate with the lowest best-loss wins (first index on ties)
+// R11 — rip/agent.py:141-151 (== dim/agent.py:74-84): the [4,2] plan is the value of a piecewise-linear curve at the
+// ticks 0, 10, 20, 30 (`player_future_length // T` apart); the agent returns it sampled at ticks 0..29 with z = 0,
+// float64 [30,3].  scipy.interpolate.interp1d's linear rule, operation by operation: the segment of tick t is found
+// with a left-sided search clipped to [1, T-1] (a tick ON a knot uses the segment that ends there), the slope is the
+// float32 difference of the knots promoted to float64 and divided by the knot distance, value = slope * (t - t_lo) +
+// y_lo in float64 without contraction.  Lanes 0..29 of a wave write one output row each.
+constexpr int PLAN_ROWS = 30;
+constexpr int PLAN_INC = 10;
+__device__ __forceinline__ void interpolate_rows(const float* __restrict__ p, double* __restrict__ o, int lane) {
+  if (lane >= PLAN_ROWS) return;
+  int hi = (lane + PLAN_INC - 1) / PLAN_INC;  // searchsorted(knots, t, 'left')
+  hi = hi < 1 ? 1 : (hi > 3 ? 3 : hi);
+  const int lo = hi - 1;
+  const double dt = (double)(lane - PLAN_INC * lo);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float ylo = p[2 * lo + d], yhi = p[2 * hi + d];
+    const float diff = yhi - ylo;
+    const double slope = (double)diff / (double)PLAN_INC;
+    o[lane * 3 + d] = __dadd_rn(__dmul_rn(slope, dt), (double)ylo);
+  }
+  o[lane * 3 + 2] = 0.0;
+}
+
 __global__ void select_best_kernel(const float* __restrict__ plans, const float* __restrict__ loss_best, int N,
-                                   float* __restrict__ plan, int32_t* __restrict__ best) {
+                                   float* __restrict__ plan, int32_t* __restrict__ best, double* __restrict__ interp) {
   const int b = blockIdx.x, lane = threadIdx.x;
   float v = INFINITY;
   int idx = 0x7fffffff;
@@ -1028,6 +1053,13 @@ __global__ void select_best_kernel(const float* __restrict__ plans, const float*
   if (idx == 0x7fffffff) idx = 0;  // all-NaN guard
   if (plan != nullptr && lane < 8) plan[(size_t)b * 8 + lane] = plans[((size_t)b * N + idx) * 8 + lane];
   if (best != nullptr && lane == 0) best[b] = idx;
+  if (interp != nullptr) interpolate_rows(plans + ((size_t)b * N + idx) * 8, interp + (size_t)b * PLAN_ROWS * 3, lane);
+}
+
+// R11 on its own: [B,4,2] fp32 plans -> [B,30,3] float64 (rip_interpolate_plans), one wave per plan
+__global__ void interpolate_plans_kernel(const float* __restrict__ plan, int B, double* __restrict__ out) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b < B) interpolate_rows(plan + (size_t)b * 8, out + (size_t)b * PLAN_ROWS * 3, threadIdx.x & 63);
 }
 
 // Ensemble aggregation of a gathered score matrix S[K][B][N] (rip/agent.py:121-127 as coded, per plan):
@@ -1398,7 +1430,7 @@ __global__ void flow_relayout_kernel(const float* __restrict__ wih, const float*
 
 // The search kernels need more dynamic LDS than the default limit: raise it ONCE per (kernel, device) to the CU's
 // 160 KiB, so that later launches are pure enqueues (no attribute call between the kernels of a captured graph).
-static hipError_t allow_lds(const void* fn) {
+hipError_t allow_lds(const void* fn) {
   static std::mutex mu;
   static std::set<std::pair<const void*, int>> done;
   int dev = 0;
@@ -1409,6 +1441,22 @@ static hipError_t allow_lds(const void* fn) {
   e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) done.insert({fn, dev});
   return e;
+}
+
+// compute units of the current device, queried once per device (hipGetDeviceProperties costs ~100 us of host time:
+// not something to pay on every eager launch)
+int device_cu_count() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cus[dev] = n;
+  return n;
 }
 
 static int rows_grid(int rows) {
@@ -1493,8 +1541,13 @@ hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_select_best(const float* plans, const float* loss_best, int B, int N, float* plan, int32_t* best,
-                              hipStream_t s) {
-  hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(64), 0, s, plans, loss_best, N, plan, best);
+                              double* interp, hipStream_t s) {
+  hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(64), 0, s, plans, loss_best, N, plan, best, interp);
+  return hipGetLastError();
+}
+
+hipError_t launch_interpolate_plans(const float* plan, int B, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(interpolate_plans_kernel, dim3((B + 3) / 4), dim3(256), 0, s, plan, B, out);
   return hipGetLastError();
 }
 

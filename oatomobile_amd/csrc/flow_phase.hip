@@ -11,8 +11,9 @@
 //     row per wave instruction) — and every MFMA A operand is a ds_read_b128 away.  The L2 operand stream of the
 //     wave-per-model kernel (235 KB per block, model and Adam step; the reason a second wave per SIMD made that kernel
 //     slower) becomes 121.5 KB per WORKGROUP, model and step: 15x less.
-//   * nothing is register resident across phases: a wave needs < 256 registers, two waves share each SIMD and one
-//     wave's gate math, tape traffic and LDS waits run under the other wave's MFMAs.
+//   * nothing is register resident across phases, so two waves share each SIMD (256 registers each: the 8-wave build
+//     fills them and spills 84 VGPRs to scratch, the 4- / 2-wave builds have the whole file and do not) and one wave's
+//     gate math, tape traffic and LDS waits run under the other wave's MFMAs.
 //   * per-candidate exchange buffers shrink to 1 KB per wave (x -> y in place, dLoss/dy), the gate gradients of the
 //     adjoint are registers (the contraction is fully unrolled: its A operands have static LDS offsets).
 //   * the adjoint tape (what a step's adjoint needs from its forward: r, z, gh_n, hprev + the ReLU mask; n is
@@ -942,19 +943,10 @@ size_t search_phase_scratch_bytes(int B, int N, int K) {
 namespace {
 template <int WPB>
 hipError_t launch_phase_wpb(const SearchArgs& a, const float* mw_all, const float* pre, float4* tape, int items, hipStream_t s) {
-  static bool attr_set[16] = {false};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+  hipError_t e = allow_lds(reinterpret_cast<const void*>(search_phase_kernel<false, WPB>));
   if (e != hipSuccess) return e;
-  if (dev < 16 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_phase_kernel<false, WPB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared<WPB>));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(search_phase_kernel<true, WPB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared<WPB>));
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
+  e = allow_lds(reinterpret_cast<const void*>(search_phase_kernel<true, WPB>));
+  if (e != hipSuccess) return e;
   const dim3 grid((items + WPB - 1) / WPB);
   if (wants_trace(a))
     hipLaunchKernelGGL((search_phase_kernel<true, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mw_all, pre, tape);
@@ -971,13 +963,7 @@ hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* s
   hipLaunchKernelGGL(phase_prefix_kernel, dim3(a.B, a.K), dim3(64), 0, s, a, mw_all, pre);
   const int items = a.B * (a.N / CB);
   // waves per workgroup: as many as keep ~256 workgroups (one per CU: the operand buffers fill its LDS) in the launch
-  int cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
+  const int cus = device_cu_count();
   // cost model from the measurements: an 8-wave workgroup (two waves per SIMD) takes twice as long as a 4-wave one
   // (2.3 vs 1.15 ms for 10 Adam steps at K = 4), a 2-wave one about as long as a 4-wave one (1.1 ms); a launch is
   // ceil(workgroups / CUs) rounds of that.  Ties go to the larger workgroup (fewer operand DMA streams).

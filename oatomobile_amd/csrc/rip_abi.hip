@@ -112,7 +112,7 @@ static int check_models(const rip_handle* h, int k0, int kc) {
 
 extern "C" {
 
-int rip_abi_version(void) { return 2; }
+int rip_abi_version(void) { return 3; }
 const char* rip_last_error(void) { return g_err; }
 
 int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_candidates, int device) {
@@ -355,10 +355,10 @@ int rip_cil_decode(const float* feat_dev, const float* vec_dev, const float* wei
 
 int rip_cil_blob_floats(void) { return cil_blob_floats(); }
 
-int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
-               int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
-               float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
-               float* trace_grad_dev, rip_stream_t stream) {
+static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
+                       int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
+                       float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
+                       float* trace_grad_dev, double* plan_interp_dev, rip_stream_t stream) {
   int rc = check_models(h, 0, h ? h->K : 1);
   if (rc != RIP_OK) return rc;
   REQUIRE(z_dev != nullptr && x0_dev != nullptr, "NULL argument");
@@ -367,7 +367,7 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   REQUIRE(algorithm == RIP_ALGO_WCM || algorithm == RIP_ALGO_MA || algorithm == RIP_ALGO_BCM, "unknown algorithm %d", algorithm);
   REQUIRE(num_steps >= 0 && num_steps <= RIP_MAX_STEPS, "num_steps=%d outside [0,%d]", num_steps, RIP_MAX_STEPS);
   REQUIRE(epsilon > 0.f && lr > 0.f, "lr and epsilon must be positive");
-  const bool need_select = plan_dev != nullptr || best_index_dev != nullptr;
+  const bool need_select = plan_dev != nullptr || best_index_dev != nullptr || plan_interp_dev != nullptr;
   float* plans = plans_dev;
   float* lbest = loss_best_dev;
   if (need_select && (plans == nullptr || lbest == nullptr)) {
@@ -424,7 +424,24 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
   } else {
     HIP_TRY(launch_search(a, (hipStream_t)stream));
   }
-  if (need_select) HIP_TRY(launch_select_best(plans, lbest, B, N, plan_dev, best_index_dev, (hipStream_t)stream));
+  if (need_select)
+    HIP_TRY(launch_select_best(plans, lbest, B, N, plan_dev, best_index_dev, plan_interp_dev, (hipStream_t)stream));
+  return RIP_OK;
+}
+
+int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
+               int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
+               float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
+               float* trace_grad_dev, rip_stream_t stream) {
+  return search_impl(h, z_dev, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, plans_dev,
+                     loss_best_dev, best_index_dev, trace_post_dev, trace_x_dev, trace_grad_dev, nullptr, stream);
+}
+
+int rip_interpolate_plans(const float* plan_dev, int B, double* out_dev, rip_stream_t stream) {
+  REQUIRE(B >= 0, "bad batch B=%d", B);
+  REQUIRE(B == 0 || (plan_dev != nullptr && out_dev != nullptr), "NULL argument");
+  if (B == 0) return RIP_OK;
+  HIP_TRY(launch_interpolate_plans(plan_dev, B, out_dev, (hipStream_t)stream));
   return RIP_OK;
 }
 
@@ -468,14 +485,15 @@ int rip_dim_forward(rip_handle* h, int k, const float* z_dev, const float* goal_
 
 int rip_act(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
             const float* goal_dev, const float* x0_dev, int B, int N, int G, int algorithm, int num_steps, float lr,
-            float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, rip_stream_t stream) {
+            float epsilon, int enc_dtype, float* plan_dev, float* loss_best_dev, double* plan_interp_dev,
+            rip_stream_t stream) {
   REQUIRE(h != nullptr, "handle is NULL");
-  REQUIRE(plan_dev != nullptr, "plan_dev is NULL");
+  REQUIRE(plan_dev != nullptr || plan_interp_dev != nullptr, "plan_dev and plan_interp_dev are both NULL");
   int rc = rip_encode_raw(h, lidar_dev, channels_last, H, W, vec_dev, B, 0, h->K, enc_dtype, h->z, stream);
   if (rc != RIP_OK) return rc;
   // h->z is [K][B][64] because rip_encode packs by the B it was given
-  return rip_search(h, h->z, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, nullptr,
-                    loss_best_dev, nullptr, nullptr, nullptr, nullptr, stream);
+  return search_impl(h, h->z, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, nullptr,
+                     loss_best_dev, nullptr, nullptr, nullptr, nullptr, plan_interp_dev, stream);
 }
 
 static int fill_mp(rip_handle* h, MpArgs& a, int k_fwd, int k_begin, int k_count, int first_is_fwd, const float* z_fwd,
@@ -575,10 +593,11 @@ int rip_train_forward_backward(rip_trainer* t, float* params_dev, float* grads_d
                                int batch_stats, float* loss_dev, float* z_dev, rip_stream_t stream) {
   REQUIRE(t != nullptr, "trainer is NULL");
   Trainer* tr = reinterpret_cast<Trainer*>(t);
-  REQUIRE(params_dev != nullptr && grads_dev != nullptr && visual_dev != nullptr && vec_dev != nullptr && y_dev != nullptr &&
-              loss_dev != nullptr, "NULL argument");
+  REQUIRE(params_dev != nullptr && visual_dev != nullptr && vec_dev != nullptr && y_dev != nullptr && loss_dev != nullptr,
+          "NULL argument");
+  // any B >= 1: like torch's BatchNorm2d, batch statistics need more than one value per channel, and the smallest map
+  // of the stack is 4 x 4 (a last DataLoader batch of one observation trains in the reference, drop_last=False)
   REQUIRE(B >= 1 && B <= trainer_max_batch(tr), "B=%d outside [1,max_batch=%d]", B, trainer_max_batch(tr));
-  REQUIRE(B >= 2 || !batch_stats, "BatchNorm batch statistics need B >= 2 (got %d)", B);
   DeviceScope scope(trainer_device(tr));
   if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice failed: %s", hipGetErrorString(scope.err));
   HIP_TRY(trainer_step(tr, params_dev, grads_dev, visual_dev, vec_dev, y_dev, dropout_mask_dev, B, batch_stats, loss_dev,
@@ -590,6 +609,7 @@ int rip_train_peek(rip_trainer* t, int layer, int what, int B, float* dst_dev, s
   REQUIRE(t != nullptr && dst_dev != nullptr, "NULL argument");
   Trainer* tr = reinterpret_cast<Trainer*>(t);
   REQUIRE(what >= 0 && what <= 2, "what=%d not in {0 pre-BN, 1 post-activation, 2 gradient}", what);
+  REQUIRE(B >= 1 && B <= trainer_max_batch(tr), "B=%d outside [1,max_batch=%d]", B, trainer_max_batch(tr));
   size_t n = 0;
   float* src = trainer_debug_layer(tr, layer, what, B, &n);
   REQUIRE(src != nullptr, "layer %d outside the conv stack", layer);
@@ -609,6 +629,11 @@ int rip_train_adam(float* params_dev, const float* grads_dev, float* m_dev, floa
   REQUIRE(params_dev != nullptr && grads_dev != nullptr && m_dev != nullptr && v_dev != nullptr, "NULL argument");
   REQUIRE(step >= 1 && lr > 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f,
           "bad Adam hyper-parameters");
+  // stateless: launch on the device that owns the parameter vector, whatever the caller's current device is
+  hipPointerAttribute_t attr;
+  HIP_TRY(hipPointerGetAttributes(&attr, params_dev));
+  DeviceScope scope(attr.device);
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", attr.device, hipGetErrorString(scope.err));
   HIP_TRY(trainer_adam(params_dev, grads_dev, m_dev, v_dev, trainable_dev, numel, step, lr, beta1, beta2, eps, weight_decay,
                        (hipStream_t)stream));
   return RIP_OK;

@@ -969,8 +969,11 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
   const size_t Bz = (size_t)B;
   // activation arenas are laid out layer-major: layer i occupies [B * act_off_i, B * act_off_i + B * a_i)
   auto A = [&](float* base, int i) { return base + Bz * t->tl[i].act_off; };
-  TRY(hipMemsetAsync(grads, 0, t->numel * sizeof(float), s));
-  TRY(hipMemsetAsync(t->dpost, 0, Bz * t->act_per_image * sizeof(float), s));
+  const bool forward_only = grads == nullptr;  // evaluate_step: loss and z only, no gradient buffers touched
+  if (!forward_only) {
+    TRY(hipMemsetAsync(grads, 0, t->numel * sizeof(float), s));
+    TRY(hipMemsetAsync(t->dpost, 0, Bz * t->act_per_image * sizeof(float), s));
+  }
   TRY(hipMemsetAsync(t->sums, 0, 2 * t->stats_floats * sizeof(float), s));  // every layer's reduction targets at once
   // ================================== forward ==================================
   size_t st_off = 0;
@@ -1042,6 +1045,7 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
   TRY(launch_flow_train(params + t->f_wih, params + t->f_whh, params + t->f_bih, params + t->f_bhh, params + t->f_w1,
                         params + t->f_b1, params + t->f_w2, params + t->f_b2, zz, y, B, qrow, dz, t->flowbuf, s));
   hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(256), 0, s, qrow, loss, B);
+  if (forward_only) return hipGetLastError();
   {
     const int R = B * 4;
     const float* fb = t->flowbuf;  // [R][FLOW_TRAIN_REC]

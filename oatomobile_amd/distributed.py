@@ -17,6 +17,7 @@ The reference has no distributed code.  The path shards three ways:
   winner — the near-linear mode for candidate throughput.
 """
 
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -38,6 +39,16 @@ def _world(group=None) -> Tuple[int, int]:
   return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _skip_collective(world: int) -> bool:
+  """A one-rank world needs no exchange and normally takes none.  `RIP_DIST_ALWAYS_COLLECTIVE=1` sends a one-rank
+  process group through the collectives all the same, so that the RCCL code path (`backend="nccl"`, device tensors)
+  can be executed and checked on a one-GPU box (tests/test_gpu_parity.py::test_rccl_world1_*, `bench.py --gpus 1
+  --mode candidates`)."""
+  if world > 1:
+    return False
+  return not (os.environ.get("RIP_DIST_ALWAYS_COLLECTIVE") == "1" and dist.is_available() and dist.is_initialized())
+
+
 
 def _all_gather_into(flat: torch.Tensor, block: torch.Tensor, group=None) -> None:
   """`dist.all_gather_into_tensor`; on the gloo backend device tensors are staged through the host (gloo has no
@@ -55,7 +66,7 @@ def all_gather_scores(local_scores: torch.Tensor, num_models: int, group=None) -
   `[K, B, N]` on every rank.  Ranks may own different numbers of models (K % world != 0): blocks are padded to
   the largest share for ONE fixed-size all-gather, then trimmed."""
   rank, world = _world(group)
-  if world == 1:
+  if _skip_collective(world):
     return local_scores
   shares = [shard_range(num_models, r, world) for r in range(world)]
   kmax = max(e - b for b, e in shares)
@@ -74,7 +85,7 @@ def gather_rows(local_rows: torch.Tensor, total_rows: int, group=None) -> torch.
   """Observation-/candidate-parallel epilogue: concatenates per-rank row blocks (`shard_range(total_rows, r, world)`
   order) of a `[rows_local, ...]` tensor on every rank."""
   rank, world = _world(group)
-  if world == 1:
+  if _skip_collective(world):
     return local_rows
   shares = [shard_range(total_rows, r, world) for r in range(world)]
   rmax = max(e - b for b, e in shares)
@@ -145,7 +156,7 @@ def all_gather_blocks(local: torch.Tensor, num_models: int, group=None) -> torch
   """`[K_local, ...]` per-model blocks in `shard_range` order -> `[K, ...]` on every rank, ONE fixed-size all-gather
   (uneven shares are padded to the largest one and trimmed)."""
   rank, world = _world(group)
-  if world == 1:
+  if _skip_collective(world):
     return local
   shares = [shard_range(num_models, r, world) for r in range(world)]
   kmax = max(e - b for b, e in shares)
@@ -184,6 +195,7 @@ class CandidateParallelRIP:
     r, w = _world(group)
     self._rank = r if rank is None else int(rank)     # explicit rank/world: a rank's share without a process group
     self._world = w if world is None else int(world)  # (one-GPU "halves == whole" tests)
+    self._explicit = world is not None
     self._algorithm, self._num_steps, self._lr, self._epsilon = algorithm, int(num_steps), float(lr), float(epsilon)
     self._n_total = int(num_candidates)
     self._begin, self._end = shard_range(self._n_total, self._rank, self._world)
@@ -228,14 +240,15 @@ class CandidateParallelRIP:
     plan_l, idx_l = select_best_plan(loss, plans)
     B = loss.shape[0]
     rec = torch.cat([loss.gather(1, idx_l[:, None]), plan_l.reshape(B, 8), (idx_l + self._begin).float()[:, None]], dim=1)
-    return reduce_rank_winners(gather_rank_winners(rec, self._group) if self._world > 1 else rec[None])
+    local_only = self._explicit or _skip_collective(self._world)
+    return reduce_rank_winners(rec[None] if local_only else gather_rank_winners(rec, self._group))
 
 
 def gather_rank_winners(rec: torch.Tensor, group=None) -> torch.Tensor:
   """The candidate-parallel exchange: every rank's `[B, 10]` winner records -> `[world, B, 10]` on every rank (ONE
   all-gather, 40 bytes per observation and rank)."""
   rank, world = _world(group)
-  if world == 1:
+  if _skip_collective(world):
     return rec[None]
   allrec = rec.new_empty((world,) + tuple(rec.shape))
   _all_gather_into(allrec.view(world * rec.shape[0], rec.shape[1]), rec, group)
@@ -275,6 +288,7 @@ class ModelParallelRIP:
     r, w = _world(group)
     self._rank = r if rank is None else int(rank)
     self._world = w if world is None else int(world)
+    self._explicit = world is not None
     self._k_total = int(num_models_total)
     self._kb, self._ke = shard_range(self._k_total, self._rank, self._world)
     if len(models) != self._ke - self._kb:
@@ -329,8 +343,8 @@ class ModelParallelRIP:
     `exchange(block)` replaces the all-gather (tests: concatenate the blocks of emulated ranks)."""
     if exchange is not None:
       gather = exchange
-    elif self._world == 1:  # one rank holds every model (also when constructed with world=1 inside a larger job)
-      gather = lambda t: t
+    elif self._explicit or _skip_collective(self._world):  # one rank holds every model (also when constructed
+      gather = lambda t: t                                   # with world=1 inside a larger job)
     else:
       gather = lambda t: all_gather_blocks(t, self._k_total, self._group)
     goal = goal.contiguous()

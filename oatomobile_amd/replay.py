@@ -319,16 +319,17 @@ class DatumBatches:
 
 
 def replay(agent, files: Sequence[str], batch_size: int, num_goals: int = 10, goal_stride: int = 8,
-           workers: Optional[int] = 0) -> np.ndarray:
-  """Plans for every datum in `files` -> [len(files), 4, 2] (host).  `agent` is a `RIPAgent` built with
-  `max_batch >= batch_size`.
+           workers: Optional[int] = 0, interpolate: bool = False) -> np.ndarray:
+  """Plans for every datum in `files` -> [len(files), 4, 2] float32 (host), or with `interpolate=True` what
+  `agent(observation)` returns per datum: [len(files), 30, 3] float64 (rip/agent.py:141-151, computed on the device).
+  `agent` is a `RIPAgent` built with `max_batch >= batch_size`.
 
   Decode (np.load: zipfile + zlib + dtype conversion, ~0.7 ms per 200x200x2 frame, under the GIL) bounds this loop:
   1.4 k observations/s inline against 70 k/s of act() on the device, and a thread pool is slower still.
   `workers = W` decodes in W processes (`DatumBatches`; None = `effective_cpus() - 1`) while the device works on the
   previous batch; sharding `files` over ranks (`distributed.shard_range`) multiplies that."""
   dev = agent._device
-  out = np.empty((len(files), 4, 2), np.float32)
+  out = np.empty((len(files), 30, 3), np.float64) if interpolate else np.empty((len(files), 4, 2), np.float32)
   if len(files) == 0:
     return out
   if workers is None:  # everything the process may use, one CPU left to the parent
@@ -337,7 +338,7 @@ def replay(agent, files: Sequence[str], batch_size: int, num_goals: int = 10, go
   for lidar, vec, goal in DatumBatches(files, batch_size, num_goals, goal_stride, workers, channels=agent._in_channels):
     n = lidar.shape[0]
     plan = agent.plan_batch(lidar.to(dev, non_blocking=True), vec.to(dev, non_blocking=True),
-                            goal.to(dev, non_blocking=True))
+                            goal.to(dev, non_blocking=True), interpolate=interpolate)
     out[i0:i0 + n] = plan.cpu().numpy()
     i0 += n
   return out

@@ -15,7 +15,8 @@ Semantics are the reference's train mode: BatchNorm on batch statistics (running
 
 Parameters, gradients and the Adam moments are single packed fp32 device tensors in the reference's state_dict order
 (`arch.packed_spec`), so data-parallel training is one `all_reduce` of `trainer.grads` between `backward()` and
-`apply()` (9.7 MB: the first bandwidth-relevant collective of this code base; `group=` enables it).
+`apply()` (9.7 MB: the first bandwidth-relevant collective of this code base; only a trainer built with `group=`
+reduces, and the averaged gradient — not the local one — is what `clip=True` clips).
 """
 
 import ctypes
@@ -68,10 +69,11 @@ class DIMTrainer:
 
   # ---- the reference's train_step, in its two halves ----
   def backward(self, batch: Mapping[str, torch.Tensor], *, y: Optional[torch.Tensor] = None,
-               dropout_mask: Optional[torch.Tensor] = None, train: bool = True) -> torch.Tensor:
+               dropout_mask: Optional[torch.Tensor] = None, train: bool = True, gradients: bool = True) -> torch.Tensor:
     """train.py:181-204: perturbs the target, runs the forward pass in train mode and back-propagates
     `-mean(log_prob - logabsdet)`; gradients land in `self.grads`.  Returns the loss (device scalar).
-    `train=False` is `evaluate_step` (train.py:229-249): running statistics, no dropout, no perturbation."""
+    `train=False`: running statistics, no dropout, no perturbation ("frozen" BatchNorm); `gradients=False`: forward
+    only — loss and `self.z`, `self.grads` is left alone (`evaluate_step`)."""
     vis = batch["visual_features"]
     if not vis.is_cuda:
       raise RuntimeError("oatomobile_amd.DIMTrainer: the batch is on %s — no CPU path" % (vis.device,))
@@ -95,21 +97,39 @@ class DIMTrainer:
       _lib.expect_shape(dropout_mask, (B, arch.LAST_CHANNELS), "dropout_mask")
     self.z = torch.empty(B, arch.HIDDEN_SIZE, device=self._device)
     _lib.check(self._lib.rip_train_forward_backward(
-        self._h, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(vis), _lib.ptr(vec), _lib.ptr(y),
+        self._h, _lib.ptr(self.params), _lib.ptr(self.grads if gradients else None), _lib.ptr(vis), _lib.ptr(vec), _lib.ptr(y),
         _lib.ptr(dropout_mask), B, int(train), _lib.ptr(self._loss.view(1)), _lib.ptr(self.z),
         _lib.current_stream(self._device)))
     if train:
       self.num_batches_tracked += 1
     return self._loss.clone()
 
-  def apply(self) -> None:
-    """train.py:211: `optimizer.step()` — torch.optim.Adam defaults; with `group`, the gradients are averaged over
-    the ranks first (DistributedDataParallel semantics; BatchNorm running statistics stay per-rank buffers, there is
-    no SyncBatchNorm)."""
+  def allreduce(self) -> None:
+    """Data-parallel exchange: averages the packed gradient vector over the ranks of the `group` this trainer was
+    built with (DistributedDataParallel semantics; BatchNorm running statistics stay per-rank buffers, there is no
+    SyncBatchNorm).  Only a trainer that was GIVEN a group reduces: a job whose ranks train independent models
+    (replay-sharded ensembles) keeps `group=None` and its gradients are never touched.  ONE all-reduce of 9.7 MB."""
+    if self._group is None:
+      return
     dist = torch.distributed
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
-      dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._group)
-      self.grads /= dist.get_world_size(self._group)
+    dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._group)
+    world = dist.get_world_size(self._group)
+    if world > 1:
+      self.grads /= world
+
+  def clip_grad_norm(self, max_norm: float = 1.0) -> torch.Tensor:
+    """train.py:207-208: `torch.nn.utils.clip_grad_norm(model.parameters(), 1.0)` on the packed gradient vector (the
+    running-statistic slots hold zeros, so its 2-norm is the norm over the parameters).  Returns the norm."""
+    norm = torch.linalg.vector_norm(self.grads)
+    self.grads *= torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    return norm
+
+  def apply(self, clip: bool = False) -> None:
+    """train.py:206-211: [all-reduce ->] [clip ->] `optimizer.step()` (torch.optim.Adam defaults).  The order is
+    DistributedDataParallel's: the AVERAGED gradient is clipped, not each rank's local one."""
+    self.allreduce()
+    if clip:
+      self.clip_grad_norm(1.0)
     self.step_count += 1
     _lib.check(self._lib.rip_train_adam(
         _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
@@ -120,15 +140,12 @@ class DIMTrainer:
                  dropout_mask: Optional[torch.Tensor] = None, clip: bool = False) -> torch.Tensor:
     """train.py:175-213."""
     loss = self.backward(batch, y=y, dropout_mask=dropout_mask)
-    if clip:  # train.py:207-208: clip_grad_norm_(model.parameters(), 1.0)
-      norm = torch.linalg.vector_norm(self.grads)
-      self.grads *= torch.clamp(1.0 / (norm + 1e-6), max=1.0)
-    self.apply()
+    self.apply(clip=clip)
     return loss
 
   def evaluate_step(self, batch: Mapping[str, torch.Tensor]) -> torch.Tensor:
     """train.py:229-249 (model.eval(): running statistics, no dropout, the unperturbed target)."""
-    return self.backward(batch, train=False)
+    return self.backward(batch, train=False, gradients=False)
 
   def peek(self, layer: int, what: str = "post") -> torch.Tensor:
     """What the last `backward` saved for conv layer `layer` (0 = features.0, ...), as NCHW: "pre" (conv output

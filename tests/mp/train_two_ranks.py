@@ -1,6 +1,7 @@
 """Two-process data-parallel DIM training step (run by tests/test_gpu_parity.py::test_data_parallel_training_two_ranks
 under torch.distributed.run; one-GPU hook: both ranks on cuda:0, gloo).  Each rank back-propagates ITS half of a batch,
-`DIMTrainer.apply()` averages the packed gradient vector over the ranks and steps Adam.  Checks, on every rank:
+`DIMTrainer.apply(clip=True)` averages the packed gradient vector over the ranks, clips the AVERAGE to norm 1
+(train.py:206-208 under DistributedDataParallel) and steps Adam.  Checks, on every rank:
   * the averaged gradients equal the mean of the two ranks' local gradients (gathered and compared),
   * trainable parameters and Adam moments are identical on both ranks after the step (the BatchNorm running
     statistics are per-rank buffers computed from the local half batch, as under DistributedDataParallel without
@@ -35,8 +36,11 @@ def main():
   local = trainer.grads.clone()
   gathered = [torch.empty_like(local).cpu() for _ in range(world)]
   dist.all_gather(gathered, local.cpu())
-  trainer.apply()
+  trainer.apply(clip=True)  # all-reduce -> clip -> Adam: the AVERAGED gradient is what gets clipped (DDP order)
   mean = torch.stack(gathered).mean(0).to(dev)
+  mean_norm = float(torch.linalg.vector_norm(mean.double()))
+  local_norm = float(torch.linalg.vector_norm(local.double()))
+  mean = mean * min(1.0, 1.0 / (mean_norm + 1e-6))
   err = float((trainer.grads - mean).abs().max() / mean.abs().max())
   p = [torch.empty_like(trainer.params).cpu() for _ in range(world)]
   dist.all_gather(p, trainer.params.cpu())
@@ -48,7 +52,7 @@ def main():
   differ = float((gathered[0] - gathered[1]).abs().max())
   if rank == 0:
     print(json.dumps({"world": world, "loss": float(loss), "avg_grad_rel_err": err, "params_identical": same, "running_stats_differ_by": buffers_differ,
-                      "local_grads_differ_by": differ}))
+                      "local_grads_differ_by": differ, "mean_grad_norm": mean_norm, "local_grad_norm": local_norm}))
   dist.barrier()
   dist.destroy_process_group()
 

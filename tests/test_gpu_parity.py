@@ -42,10 +42,41 @@ def ctx_tensors(obs_list, dev):
   )
 
 
+def candidate_gate(tag, lh, lo, plan_h=None, plan_o=None, frac=0.99, x_h=None, x_o=None):
+  """The N-candidate gate of the end-to-end search tests.  Every candidate's best loss against the oracle's within
+  1e-3 + 1e-4 |loss| for >= `frac` of the candidates (N < 100: all of them), the winning plan at 1e-4 when the winner
+  is unambiguous (its best loss more than 1e-3 below the runner-up's).  Whatever falls outside is printed: the
+  candidate, both losses, the oracle's gap to its runner-up and — when per-step latents `x_h` / `x_o` [steps,N,4,2]
+  are given — the first Adam step at which the two trajectories differ by more than 1e-4 (an Adam sign flip of a
+  near-zero gradient coordinate moves x by 2 lr there)."""
+  lh, lo = np.asarray(lh, np.float64).reshape(-1), np.asarray(lo, np.float64).reshape(-1)
+  d = np.abs(lh - lo)
+  out = np.flatnonzero(~(d <= 1e-3 + 1e-4 * np.abs(lo)))
+  srt = np.sort(lo)
+  gap = float(srt[1] - srt[0]) if lo.size > 1 else float("inf")
+  print("%s: %d / %d candidates outside 1e-3 + 1e-4|loss| (max |d loss| %.3g), winner gap %.3g" %
+        (tag, out.size, lo.size, float(d.max()), gap))
+  for n in out[:8]:
+    first = ""
+    if x_h is not None and x_o is not None:
+      dx = np.abs(np.asarray(x_h)[:, n] - np.asarray(x_o)[:, n]).reshape(len(x_h), -1).max(axis=1)
+      bad = np.flatnonzero(dx > 1e-4)
+      first = ", trajectories part at Adam step %s (max |dx| %.3g)" % (bad[0] if bad.size else "-", float(dx.max()))
+    print("   candidate %d: loss %.6f vs oracle %.6f (|d| %.3g), rank %d of the oracle's ordering%s" %
+          (n, lh[n], lo[n], d[n], int(np.sum(lo < lo[n])), first))
+  assert 1.0 - out.size / lo.size >= frac, "%s: %d of %d candidates outside the tolerance" % (tag, out.size, lo.size)
+  if plan_h is not None and (gap > 1e-3 or lo.size == 1):
+    err = float(np.abs(np.asarray(plan_h) - np.asarray(plan_o)).max())
+    print("%s: winner plan max |d| = %.3g m" % (tag, err))
+    np.testing.assert_allclose(plan_h, plan_o, atol=TOL)
+    return err
+  return None
+
+
 def test_native_library_loaded():
   from oatomobile_amd import _lib
   lib = _lib.load()
-  assert lib.rip_abi_version() == 2
+  assert lib.rip_abi_version() == _lib.ABI_VERSION
   with open("/proc/self/maps") as f:
     assert "librip_hip.so" in f.read()
 
@@ -441,13 +472,22 @@ def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
   plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
   _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"],
                       ob["goal"], x0=agent._x0_rows.cpu(), algorithm=algo)
-  lo = res["loss_best"].numpy()
-  lh = loss.cpu().numpy()[0]
-  # candidates whose trajectories hit an Adam sign flip or an arg-min tie can diverge; demand 97% within tol
-  close = np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)
-  assert close.mean() >= 0.97, (lh, lo)
-  if abs(np.sort(lo)[0] - np.sort(lo)[min(1, N - 1)]) > 1e-3 or N == 1:
-    np.testing.assert_allclose(plan.cpu().numpy()[0], res["plan"].numpy(), atol=5e-4)
+  # the kernel's own per-step latents next to the oracle's, so that an outlier can be dated (the wave-per-model MFMA
+  # kernel only traces in its dual-block form, N % 32 == 0)
+  x_h = None
+  if kernel != "mfma" or N % 32 == 0:
+    from oatomobile_amd import _lib
+    zz = torch.empty(K, 1, 64, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.rip_encode_raw(agent._handle.raw, _lib.ptr(lidar), 1, 200, 200, _lib.ptr(vec), 1, 0, K, 0, _lib.ptr(zz),
+                                  agent._handle.stream()))
+    tx = torch.empty(10, 1, N, 4, 2, device=dev)
+    _lib.check(lib.rip_search(agent._handle.raw, _lib.ptr(zz), _lib.ptr(goal), _lib.ptr(agent._x0(1)), 1, N, goal.shape[1],
+                              _lib.ALGORITHMS[algo], 10, 0.1, 1.0, None, None, None, None, None, _lib.ptr(tx), None,
+                              agent._handle.stream()))
+    x_h = tx.cpu().numpy()[:, 0]
+  candidate_gate("%s %s K=%d N=%d" % (kernel, algo, K, N), loss.cpu().numpy()[0], res["loss_best"].numpy(),
+                 plan.cpu().numpy()[0], res["plan"].numpy(), x_h=x_h, x_o=res["trace_x"].numpy())
 
 
 def test_mfma_kernel_matches_chain_kernel(dev):
@@ -465,8 +505,9 @@ def test_mfma_kernel_matches_chain_kernel(dev):
     out[kern] = (plan.cpu().numpy(), loss.cpu().numpy())
   for kern in ("mfma", "phase"):
     close = np.abs(out["chain"][1] - out[kern][1]) <= 1e-3 + 1e-4 * np.abs(out["chain"][1])
-    assert close.mean() >= 0.97, kern
-    np.testing.assert_allclose(out["chain"][0], out[kern][0], atol=5e-4, err_msg=kern)
+    print("%s vs chain: %.4f of %d candidates within tolerance" % (kern, close.mean(), close.size))
+    assert close.mean() >= 0.99, kern
+    np.testing.assert_allclose(out["chain"][0], out[kern][0], atol=TOL, err_msg=kern)
   with pytest.raises(Exception):
     RIPAgent(None, algorithm="WCM", models=models, num_candidates=5, search_kernel="mfma").plan_batch(
         lidar[:1].contiguous(), vec[:1].contiguous(), goal[:1].contiguous())
@@ -727,13 +768,11 @@ def test_bench_configuration_parity(dev):
     lo = res["loss_best"].numpy()
     close = np.abs(loss_h[b] - lo) <= 1e-3 + 1e-4 * np.abs(lo)
     frac.append(close.mean())
-    srt = np.sort(lo)
-    if srt[1] - srt[0] > 1e-3:  # unambiguous winner
-      worst_plan = max(worst_plan, float(np.abs(plan_h[b] - res["plan"].numpy()).max()))
-      np.testing.assert_allclose(plan_h[b], res["plan"].numpy(), atol=5e-4)
+    err = candidate_gate("bench configuration, observation %d" % b, loss_h[b], lo, plan_h[b], res["plan"].numpy())
+    worst_plan = max(worst_plan, err or 0.0)
   print("bench config vs oracle (given the HIP bf16 z): candidates within tolerance %.4f (min over obs %.4f), "
         "worst winner-plan error %.3g m" % (np.mean(frac), np.min(frac), worst_plan))
-  assert np.min(frac) >= 0.95 and np.mean(frac) >= 0.97
+  assert np.min(frac) >= 0.99
   # plan-level effect of the bf16 encoder (reported; the bf16 z differs from the fp32 z by up to ~6 % of max|z|)
   agent32 = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=16, seed=0, device=dev)
   sel = torch.from_numpy(idx).to(dev)
@@ -970,7 +1009,7 @@ def test_g15_train_step_vs_reference(golden, dev):
         solid = np.abs(gref) > 1e-5 + 1e-3 * np.abs(gref).max()
         np.testing.assert_allclose(pact[solid], pref[solid], rtol=1e-4, atol=2e-5, err_msg="param:" + k)
       elif step == 0:
-        assert err < 0.15, (k, err)
+        assert err < 0.02, (k, err)
       # step 1 is not held per tensor: the FIRST Adam step moves every parameter by exactly +-lr according to the sign of
       # its gradient, so the ~0.5 % kink-decision deviations of step 0 flip the direction of the near-zero gradient
       # entries and the two models then differ by 2 lr in those coordinates (the CPU oracle against this recording
@@ -1111,13 +1150,14 @@ def test_config4_k8_n512_on_the_mfma_kernel(dev):
     ob = obs[b]
     _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"], ob["goal"],
                         x0=agent._x0_rows.cpu()[:96], algorithm="WCM")
-    lo, lh = res["loss_best"].numpy(), loss.cpu().numpy()[b, :96]
-    assert (np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.97
+    candidate_gate("configs[3] K=8 N=512, observation %d (first 96 candidates)" % b, loss.cpu().numpy()[b, :96],
+                   res["loss_best"].numpy(), x_o=None)
   # the same launch through the wave-per-chain kernel (any K): per-candidate best losses agree
   chain = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=3, search_kernel="chain")
   plan_c, loss_c = chain.plan_batch(lidar, vec, goal, return_loss=True)
   close = np.abs(loss.cpu().numpy() - loss_c.cpu().numpy()) <= 1e-3 + 1e-4 * np.abs(loss_c.cpu().numpy())
-  assert close.mean() >= 0.97
+  print("phase kernel vs wave-per-chain kernel, %d candidates: %.5f within tolerance" % (close.size, close.mean()))
+  assert close.mean() >= 0.99
 
 
 def test_replay_512_cached_observations(dev, tmp_path):
@@ -1153,7 +1193,7 @@ def test_replay_512_cached_observations(dev, tmp_path):
                         x0=agent._x0_rows.cpu(), algorithm="WCM")
     srt = np.sort(res["loss_best"].numpy())
     if srt[1] - srt[0] > 1e-3:
-      np.testing.assert_allclose(plans[i], res["plan"].numpy(), atol=5e-4)
+      np.testing.assert_allclose(plans[i], res["plan"].numpy(), atol=TOL)
   # another batching of the same files gives the same plans (observations are independent)
   plans2 = replay.replay(agent, files[::-1], batch_size=128)[::-1]
   np.testing.assert_allclose(plans2, plans, atol=1e-5)
@@ -1226,7 +1266,8 @@ def test_data_parallel_training_two_ranks():
   rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
   assert rec["world"] == 2 and np.isfinite(rec["loss"])
   assert rec["local_grads_differ_by"] > 0        # the ranks really saw different data
-  assert rec["avg_grad_rel_err"] <= 1e-6, rec
+  assert rec["avg_grad_rel_err"] <= 1e-5, rec     # == clip(mean of the local gradients), not mean(clip(local))
+  assert rec["mean_grad_norm"] > 1.0, rec         # the clip was active
   assert rec["params_identical"], rec
 
 
@@ -1270,3 +1311,141 @@ def test_training_from_datum_files_end_to_end(dev, tmp_path):
     losses.append(float(trainer.train_step(batch, y=y, dropout_mask=keep)))
   assert len(losses) == 2 and all(np.isfinite(losses))
   assert abs(losses[0] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (losses[0], loss_ref)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: R11 on the device, RCCL executed, gradient clipping order
+# ---------------------------------------------------------------------------------------------------------
+def test_r11_device_interpolation_bit_identical(golden, dev):
+  """R11 (rip/agent.py:141-151) on the device: `rip_interpolate_plans` and the epilogue fused into the candidate
+  selection (`plan_batch(interpolate=True)`, `agent(observation)`) against the host restatement of scipy's interp1d
+  (`interpolate_plan`, itself pinned by the reference's `out30_*` recordings) — float64, bit for bit."""
+  from oatomobile_amd import RIPAgent, _lib
+  from oatomobile_amd.agents import interpolate_plan, interpolate_plans
+  rng = np.random.default_rng(12)
+  plans = (rng.normal(size=(257, 4, 2)) * np.array([1.0, 30.0, 1e-3, 1e4]).reshape(4, 1)).astype(np.float32)
+  plans[0] = 0.0
+  plans[1, 1] = plans[1, 0]  # a zero-slope segment
+  out = interpolate_plans(torch.from_numpy(plans).to(dev)).cpu().numpy()
+  assert out.shape == (257, 30, 3) and out.dtype == np.float64
+  for i in range(257):
+    np.testing.assert_array_equal(out[i], interpolate_plan(plans[i]))
+  assert interpolate_plans(torch.empty(0, 4, 2, device=dev)).shape == (0, 30, 3)
+  # the fused epilogue of the whole act(): [B,30,3] float64 == R11 of the same call's [B,4,2]
+  models = [hip_model(100 + k, dev) for k in range(4)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=5, seed=1)
+  obs = [synth_observation(np.random.default_rng(60 + i)) for i in range(5)]
+  lidar = torch.stack([torch.from_numpy(o["lidar"]) for o in obs]).to(dev)
+  vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
+  goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
+  p4 = agent.plan_batch(lidar, vec, goal).cpu().numpy()
+  p30, loss = agent.plan_batch(lidar, vec, goal, interpolate=True, return_loss=True)
+  assert p30.dtype == torch.float64 and tuple(p30.shape) == (5, 30, 3) and tuple(loss.shape) == (5, 16)
+  for i in range(5):
+    np.testing.assert_array_equal(p30[i].cpu().numpy(), interpolate_plan(p4[i]))
+    np.testing.assert_array_equal(agent(dict(obs[i])), interpolate_plan(p4[i]))
+  buf = torch.empty(5, 30, 3, device=dev, dtype=torch.float64)
+  assert agent.plan_batch(lidar, vec, goal, interpolate=True, out=buf) is buf
+  with pytest.raises(ValueError):
+    agent.plan_batch(lidar, vec, goal, interpolate=True, out=torch.empty(5, 4, 2, device=dev))
+  # the reference's own [30,3] output (N = 1 = its algorithm) through the fused epilogue
+  g = golden("g6_rip.npz")
+  ref_agent = RIPAgent(None, algorithm="WCM", models=models)
+  ob = synth_observation(np.random.default_rng(60))
+  one = ref_agent.plan_batch(torch.from_numpy(ob["lidar"]).to(dev)[None],
+                             torch.tensor([[*ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"]]], device=dev),
+                             torch.from_numpy(ob["goal"][None, :, :2].copy()).to(dev), interpolate=True)
+  np.testing.assert_allclose(one.cpu().numpy()[0], g["out30_WCM_o60"], atol=TOL)
+
+
+def test_rccl_world1_executes_every_collective():
+  """RCCL itself runs (one-rank `nccl` process group on this GPU, device tensors, no host staging): candidate-parallel,
+  gradient-mode model-parallel, the row / score gathers and the training all-reduce, each equal to its collective-free
+  composition; `librccl` is mapped into that process."""
+  import json, socket, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RIP_BENCH_BACKEND", "RIP_BENCH_SHARE_GPU"):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(root, "tests", "mp", "rccl_world1.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-3000:]
+  rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  print(rec)
+  assert rec["backend"] == "nccl" and rec["world"] == 1
+  assert rec["librccl_mapped"] and rec["librip_mapped"]
+  assert rec["candidates_gathers"] == 1 and rec["candidates_plan_diff"] <= 1e-6
+  assert rec["models_gathers"] == 11 and rec["models_plan_diff"] <= 1e-5  # z_0 + one block per Adam step
+  assert rec["gather_rows_equal"] and rec["all_gather_scores_equal"] and rec["epilogue_gathers"] == 2
+  assert rec["allreduce_calls"] == 1 and rec["allreduce_identity"] and np.isfinite(rec["train_loss"])
+
+
+def test_bench_candidates_mode_one_rank_under_rccl():
+  """`bench.py --gpus 1 --mode candidates`: a one-rank nccl process group, the all-gather of the winner records goes
+  through RCCL; the line names the backend and the world size torch.distributed reports."""
+  import json, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RIP_BENCH_BACKEND", "RIP_BENCH_SHARE_GPU", "MASTER_PORT"):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "candidates", "--obs-batch", "8",
+                        "--steps", "3", "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-3000:]
+  rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert rec["backend"] == "nccl" and rec["world_size_seen"] == 1 and rec["n_gpus"] == 1 and rec["value"] > 0
+  assert rec["check"]["max_abs_plan_diff_vs_single_gpu"] <= 1e-6
+
+
+def test_train_clip_is_applied_after_the_reduction(dev):
+  """train.py:206-208 `clip_grad_norm(model.parameters(), 1.0)`: the packed vector's clipped gradient equals
+  torch.nn.utils.clip_grad_norm_ on the same gradients as separate parameters, and `apply(clip=True)` steps Adam
+  with it; `evaluate_step` leaves gradients alone and runs any batch size (B = 1 included)."""
+  from oatomobile_amd import DIMTrainer
+  m = hip_model(9, dev)
+  tr = DIMTrainer(m, lr=1e-3, max_batch=4, device=dev)
+  rng = np.random.default_rng(8)
+
+  def batch_of(B):
+    return dict(visual_features=torch.from_numpy(rng.random((B, 2, 100, 100), dtype=np.float32)).to(dev),
+                velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
+                is_at_traffic_light=torch.zeros(B, 1, device=dev), traffic_light_state=torch.ones(B, 1, device=dev),
+                player_future=torch.from_numpy((np.cumsum(np.abs(rng.normal(size=(B, 4, 3))), axis=1) * 5).astype(np.float32)).to(dev))
+
+  batch = batch_of(3)
+  y = batch["player_future"][..., :2].contiguous()
+  keep = torch.ones(3, 1280, device=dev)
+  tr.backward(batch, y=y, dropout_mask=keep)
+  g = tr.grads.clone()
+  norm = float(torch.linalg.vector_norm(g.double()))
+  assert norm > 1.0, "the clip must bite for this test to mean anything (norm %g)" % norm
+  # torch's own clipping on the same gradients, held as separate parameter tensors
+  ps = []
+  for k, v in tr.named_gradients().items():
+    p_ = torch.nn.Parameter(torch.zeros_like(v))
+    p_.grad = v.clone()
+    ps.append(p_)
+  total = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+  np.testing.assert_allclose(float(total), norm, rtol=1e-5)
+  p0, m0 = tr.params.clone(), tr.exp_avg.clone()
+  tr.apply(clip=True)
+  clipped = torch.cat([p_.grad.reshape(-1) for p_ in ps])
+  np.testing.assert_allclose(tr.grads.cpu().numpy(), clipped.cpu().numpy(), rtol=1e-5, atol=1e-9)
+  np.testing.assert_allclose(float(torch.linalg.vector_norm(tr.grads.double())), 1.0, rtol=1e-4)
+  np.testing.assert_allclose(tr.exp_avg.cpu().numpy(), (0.1 * clipped).cpu().numpy(), rtol=1e-5, atol=1e-10)  # Adam's first moment
+  assert not torch.equal(tr.params, p0) and torch.equal(m0, torch.zeros_like(m0))
+  # evaluate_step: forward only, gradients untouched, B = 1 .. max_batch, equal to the frozen-statistics backward's loss
+  gkeep = tr.grads.clone()
+  for B in (1, 4):
+    b = batch_of(B)
+    le = float(tr.evaluate_step(b))
+    assert torch.equal(tr.grads, gkeep)
+    lb = float(tr.backward(b, train=False))
+    np.testing.assert_allclose(le, lb, rtol=1e-6)
+    tr.grads.copy_(gkeep)
+  # train mode with one observation (the reference's last DataLoader batch may hold one: drop_last=False)
+  l1 = float(tr.train_step(batch_of(1)))
+  assert np.isfinite(l1) and torch.isfinite(tr.params).all()
+  tr.close()

@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == bound, declared ^ bound
   for name in declared:
     assert hasattr(lib, name)
-  assert lib.rip_abi_version() == _lib.ABI_VERSION == 2
+  assert lib.rip_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_no_cpu_fallback():
