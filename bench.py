@@ -58,13 +58,26 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA 
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA (MI355X_MICROARCH.md; the headline 5 PF includes 2:1 sparsity)
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # packed fp32 FMA on the vector ALUs
-# MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 flop each) of the passes of search_phase_kernel, per 16-candidate
-# block (flow_phase.hip: fwd_step_lds = 251; adjoint step = 274, 82 at t = T-1)
-MFMA_FWD_PASS = 3 * 251
-MFMA_ADJ_PASS = 2 * 274 + 82  # + 4 per step whose tape is read back (gi_n for the recomputed n): see below
-MFMA_ADJ_INV = MFMA_ADJ_PASS + 2 * 4   # inverse passes: steps 2, 1 from the tape, step 3 from registers
-MFMA_ADJ_FWD = MFMA_ADJ_PASS + 3 * 4   # F_0's adjoint: all three steps from the tape
-MFMA_PREFIX = 251
+# flop / matrix-pipe cycles per MFMA instruction (MI355X_MICROARCH.md: v_mfma_f32_16x16x32_f16 issues every 16 cycles
+# per SIMD = the 2.5 PFLOP/s dense f16 rate, v_mfma_f32_16x16x4_f32 every 32 = the 157.3 TFLOP/s fp32 rate)
+MFMA_F16 = (16 * 16 * 32 * 2, 16)
+MFMA_F32 = (16 * 16 * 4 * 2, 32)
+PEAK_CLOCK_HZ = 2.4e9
+N_SIMD = 256 * 4
+KERNEL_NAMES = {1: "search_kernel (wave-per-chain, fp32 VALU)", 2: "search_mfma2_kernel (fp32 MFMA, wave per model)",
+                3: "search_phase_kernel (fp32 MFMA, phase-sequential)", 4: "search_split_kernel (split-f16 MFMA, phase-sequential)"}
+
+
+def search_plan(lib, h, B, N):
+  """rip_search_plan: which kernel / workgroup shape the launch uses and its MFMA instruction counts per pass (the
+  numbers live next to the kernels, flow_split.hip / flow_phase.hip; SQ_INSTS_MFMA in profiles/ is their check)."""
+  import ctypes
+  from oatomobile_amd import _lib
+  out = (ctypes.c_int32 * 10)()
+  _lib.check(lib.rip_search_plan(h, B, N, ctypes.cast(out, ctypes.c_void_p), 10))
+  v = list(out)
+  return {"kernel": v[0], "waves_per_workgroup": v[1], "pass": (v[2], v[3]), "adj_inv": (v[4], v[5]), "adj_f0": (v[6], v[7]),
+          "prefix": (v[8], v[9])}
 
 
 def synth_batch(rng, B, C, G=10):
@@ -410,8 +423,9 @@ def main():
                       "headline definition)"}
 
   extras = {}
-  use_mfma = (B * N >= 2048 and N % 16 == 0)  # rip_search auto: the phase-sequential MFMA kernel (flow_phase.hip)
-  exec_flops = None
+  plan_info = search_plan(lib, h, B, N)
+  use_mfma = plan_info["kernel"] in (3, 4)  # a phase-sequential MFMA kernel (flow_split.hip / flow_phase.hip)
+  exec_flops = pipe_cycles = None
   if rank == 0 and use_mfma:
     # exact executed-MFMA count of this launch: per 16-candidate block and Adam step the kernel runs F_0, K-1 inverses,
     # the adjoint of F_0, and the adjoint of inverse k iff model k is the running arg-best (WCM / BCM) of some candidate
@@ -429,9 +443,20 @@ def main():
       run = (sign * tp).cummax(dim=1).values  # running best over models 0..k
       take = (sign * tp[:, 1:]) > run[:, :-1]  # [S,K-1,B,N]: strictly better than every earlier model
       adj_passes = float(take.view(S, K - 1, B, N // 16, 16).any(-1).sum().item())
-    mfma = blocks16 * ((S + 1) * MFMA_FWD_PASS + S * MFMA_ADJ_FWD + S * (K - 1) * MFMA_FWD_PASS) + \
-        adj_passes * MFMA_ADJ_INV + B * K * MFMA_PREFIX
-    exec_flops = mfma * 2048.0
+    def count(info):  # (f16, fp32) MFMA instructions of the whole launch
+      return tuple(blocks16 * ((S + 1) * info["pass"][i] + S * info["adj_f0"][i] + S * (K - 1) * info["pass"][i]) +
+                   adj_passes * info["adj_inv"][i] + B * K * info["prefix"][i] for i in (0, 1))
+    n16, n32 = count(plan_info)
+    exec_flops = n16 * MFMA_F16[0] + n32 * MFMA_F32[0]
+    pipe_cycles = n16 * MFMA_F16[1] + n32 * MFMA_F32[1]  # matrix-pipe issue cycles, summed over the SIMDs
+    extras["mfma_instructions"] = {"f16_16x16x32": n16, "f32_16x16x4": n32}
+    extras["waves_per_workgroup"] = plan_info["waves_per_workgroup"]
+    if plan_info["kernel"] == 4:
+      # the same launch on the fp32-MFMA kernel (flow_phase.hip), for comparison with the fp32 floor of round 2
+      lib.rip_set_option(h, 0, 3)
+      ref = search_plan(lib, h, B, N)
+      lib.rip_set_option(h, 0, 0)
+      extras["fp32_kernel_flops_same_launch"] = count(ref)[1] * MFMA_F32[0]
     extras["adjoint_inverse_passes_executed"] = adj_passes
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
 
@@ -481,15 +506,19 @@ def main():
     bytes_act = enc_bytes / B + K * 64 * 4 + N * 8 * 4 * 2 + 32  # §8(d) bytes_pre + bytes_enc (weights amortised) + bytes_flow
     blocks16 = B * N / 16.0
     exec_tf = exec_flops / (search_ms * 1e-3) / 1e12 if exec_flops else None
+    # the matrix pipe running THIS instruction mix back to back: flops / (issue cycles / (SIMDs x 2.4 GHz))
+    mix_peak = exec_flops / (pipe_cycles / (N_SIMD * PEAK_CLOCK_HZ)) / 1e12 if exec_flops else PEAK_FP32_TFLOPS
     roof = {
-        "kernel": ("search_phase_kernel (phase-sequential MFMA plan search: per 16-candidate wave F_0 + %d inverses + adjoints "
-                   "+ Adam, operands in LDS, %d steps in one launch)" % (K - 1, S)) if use_mfma else
-                  ("search_kernel<%d> (wave-per-chain plan search, %d steps in one launch)" % (min(K, 4), S)),
+        "kernel": "%s: per 16-candidate wave F_0 + %d inverses + adjoints + Adam, operands in LDS, %d steps in one launch" %
+                  (KERNEL_NAMES[plan_info["kernel"]], K - 1, S),
         "bound": "mfma",
         "achieved": exec_tf,
-        "peak": PEAK_FP32_TFLOPS,
+        "peak": mix_peak,
         "unit": "TFLOP/s",
-        "frac": exec_tf / PEAK_FP32_TFLOPS if exec_tf else None,
+        "frac": exec_tf / mix_peak if exec_tf else None,
+        "frac_of_dense_f16_peak": exec_tf / PEAK_BF16_TFLOPS if exec_tf else None,
+        "fp32_equivalent_tflops": extras.pop("fp32_kernel_flops_same_launch") / (search_ms * 1e-3) / 1e12
+                                  if "fp32_kernel_flops_same_launch" in extras else None,
         # L2 <-> fabric bytes per launch: the adjoint tape, written once and read back once per 16-candidate block,
         # model and Adam step (F_0: 3 steps, inverses: 2 steps, the third stays in registers; a step is 12 or 16 rows
         # of 1 KiB -- r, z, gh_n, hprev; n is recomputed -- + 256 B of ReLU mask); rocprofv3 FETCH_SIZE (x2 gfx950
@@ -501,10 +530,15 @@ def main():
         "contract_over_peak": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
         "whole_act_hbm_frac": bytes_act * value / world / 1e9 / PEAK_HBM_GBS,
         "whole_act_GBps": bytes_act * value / world / 1e9,
-        "note": "`achieved` / `frac`: MFMA flops this launch EXECUTES (v_mfma_f32_16x16x4_f32 = 2048 flop; exact count "
-                "from the kernel's per-step selection trace: an inverse's adjoint only runs for blocks where some "
-                "candidate selects that model) over the mean launch time from HIP events on the launch stream, vs the "
-                "157.3 TFLOP/s dense fp32 MFMA peak; agrees with rocprofv3 SQ_INSTS_MFMA (profiles/).  `contract_*`: "
+        "note": "`achieved`: MFMA flops this launch EXECUTES (v_mfma_f32_16x16x32_f16 = 16384 flop, v_mfma_f32_16x16x4_f32 "
+                "= 2048; instruction counts per pass from rip_search_plan, passes from the kernel's per-step selection "
+                "trace: an inverse's adjoint only runs for blocks where some candidate selects that model) over the mean "
+                "launch time from HIP events on the launch stream; checked against rocprofv3 SQ_INSTS_MFMA (profiles/).  "
+                "`peak`: what the matrix pipe delivers running this launch's instruction mix back to back (f16 MFMAs at the "
+                "2.5 PFLOP/s dense rate = one per 16 cycles and SIMD, fp32 MFMAs at 157.3 TFLOP/s = one per 32), so "
+                "`frac` = the fraction of the launch the matrix pipe is busy; `frac_of_dense_f16_peak` prices every flop at "
+                "the f16 rate.  `fp32_equivalent_tflops`: the flops the fp32-MFMA kernel of round 2 executes for the same "
+                "launch / this launch's time — above 157.3 means past that kernel's floor.  `contract_*`: "
                 "SURVEY.md §8(d) flops_flow(grad) = 2*3*(1+K)*T*14848*N*steps per act x obs_batch / launch time -- NOT "
                 "a utilisation: the formula prices the candidate-independent step-0 prefix, model 0's inverse "
                 "(inverse_0(F_0(x)) == x) and K adjoints per candidate, none of which the algorithm needs, so it can "

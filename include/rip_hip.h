@@ -266,13 +266,16 @@ int rip_train_peek(rip_trainer* t, int layer, int what, int B, float* dst_dev, s
 int rip_train_num_layers(const rip_trainer* t);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
- *   RIP_OPT_SEARCH_KERNEL: 0 = auto (phase-sequential MFMA kernel when B*N >= 2304 and N % 16 == 0, else
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (the split-f16 phase-sequential kernel when B*N >= 2304 and N % 16 == 0, else
  *     wave-per-chain),
  *     1 = wave-per-chain kernel (lowest latency, any K/N),
  *     2 = MFMA wave-per-model pipeline (16 candidates per wave, wave k = model k; N % 16 == 0, K <= 4; N % 32 == 0
  *         selects its dual-block form, the only one with trace outputs),
- *     3 = MFMA phase-sequential kernel (one wave per 16-candidate block runs all K models, operands in LDS, two
- *         waves per SIMD; N % 16 == 0, any K <= 8, trace outputs).  All implement rip/agent.py:78-137.
+ *     3 = fp32-MFMA phase-sequential kernel (one wave per 16-candidate block runs all K models, operands in LDS, two
+ *         waves per SIMD; N % 16 == 0, any K <= 8, trace outputs),
+ *     4 = split-f16 phase-sequential kernel: the same decomposition with the GRU / head contractions on
+ *         v_mfma_f32_16x16x32_f16, both operands carried as two binary16 terms (22 significant bits, fp32
+ *         accumulation; same shapes and outputs as 3).  auto picks it.  All implement rip/agent.py:78-137.
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.
@@ -282,6 +285,14 @@ int rip_train_num_layers(const rip_trainer* t);
  *     >= 64 (model, observation) pairs (an explicit count uses it regardless). */
 enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1 };
 int rip_set_option(rip_handle* h, int option, int value);
+
+/* What rip_search would launch for B observations x N candidates under the handle's current options, and what that
+ * launch executes on the matrix cores (bench.py's executed-flops count; rocprofv3 SQ_INSTS_MFMA is the check):
+ * out[0] = kernel (1 wave-per-chain, 2 fp32-MFMA wave-per-model, 3 fp32-MFMA phase-sequential, 4 split-f16
+ * phase-sequential); for kernels 3 / 4: out[1] = waves per workgroup, then (16x16x32 f16, 16x16x4 fp32) MFMA
+ * instructions per 16-candidate block of out[2,3] one forward / inverse pass, out[4,5] the adjoint of an inverse pass,
+ * out[6,7] the adjoint of F_0, out[8,9] the prefix step per (model, observation).  n_out >= 10. */
+int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out);
 
 /* Introspection used by bench.py / tests. */
 int rip_num_models(const rip_handle* h);

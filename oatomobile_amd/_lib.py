@@ -51,6 +51,7 @@ SIGNATURES = [
         c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p
     ]),
     ("rip_interpolate_plans", c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    ("rip_search_plan", c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     ("rip_set_option", c_int, [c_void_p, c_int, c_int]),
     ("rip_num_models", c_int, [c_void_p]),
     ("rip_in_channels", c_int, [c_void_p]),
@@ -73,7 +74,7 @@ ABI_VERSION = 3
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
 OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED = 0, 1
-SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2, "phase": 3}
+SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2, "phase": 3, "split": 4}
 
 _lib = None
 

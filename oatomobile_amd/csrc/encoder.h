@@ -45,7 +45,8 @@ EncoderPlan build_encoder_plan(int in_channels);
 // Folds BN and re-lays the packed reference tensors (arch.py:packed_spec order) into the encoder blob
 // and the flow blob (flow.h layout).  Returns false (and a message) on size mismatch.
 bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc_blob,
-                   std::vector<float>& flow_blob, std::vector<float>& mfma_blob, const char** err);
+                   std::vector<float>& flow_blob, std::vector<float>& mfma_blob, std::vector<uint32_t>& split_blob,
+                   const char** err);
 
 hipError_t launch_transform(const float* in, int B, int C, int H, int W, int channels_last, int out_hw, float* out,
                             hipStream_t s);

@@ -8,6 +8,7 @@
 //   K5/K6 pool+classifier+merger  dim/model.py:203-217                     -> tail_kernel
 // All K ensemble members run in the same launches (blockIdx.z = model).
 #include "encoder.h"
+#include "flow_split_pack.h"
 #include "flow.h"
 
 #include <cmath>
@@ -634,7 +635,7 @@ EncoderPlan build_encoder_plan(int in_channels) {
 }
 
 bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc,
-                   std::vector<float>& flow, std::vector<float>& mw, const char** err) {
+                   std::vector<float>& flow, std::vector<float>& mw, std::vector<uint32_t>& mh, const char** err) {
   enc.assign(plan.blob_floats, 0.f);
   flow.assign(FW_SIZE, 0.f);
   size_t pos = 0;
@@ -764,6 +765,8 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
           Bk(57 + s / 4, lane, s & 3) = wih[j * 2 + (m & 1)];
         }
   }
+  // ---- operands of the split-f16 search kernel (flow_split.hip) ----
+  pack_split_operands(mw.data(), wih, whh, w1, mh);
   return true;
 }
 

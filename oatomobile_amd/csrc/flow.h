@@ -22,6 +22,14 @@ constexpr int FW_SIZE = 15300;
 constexpr int MWF_FLOATS = 63 * 64 * 4;
 constexpr int MWB_F4 = 69;
 constexpr int MW_SIZE = MWF_FLOATS + MWB_F4 * 64 * 4;
+// split-f16 search kernel operands (flow_split.hip, packed by flow_split_pack.h), in dwords; a row = 64 lanes x 16 B.
+// Forward rows: 0..47 W_hh ((gate g, unit tile up, K block kb) x (hi, lo')), 48..51 the fp32 input / bias k-steps,
+// 52..59 W1 ((tile mt, kb) x (hi, lo')), 60..62 fp32 (b1, W2, b2).  Transposed rows: 0 = W2^T (fp32), 1..8 W1^T
+// (out tile ut x (hi, lo')), 9..56 W_hh^T ((kb 0..5, ut) x (hi, lo')); then the 96-entry W_ih^T table.
+constexpr int MHF_ROWS = 63, MHF_WHH = 0, MHF_WX = 48, MHF_W1 = 52, MHF_TAIL = 60;
+constexpr int MHT_ROWS = 57, MHT_W2T = 0, MHT_W1T = 1, MHT_WHHT = 9;
+constexpr int MH_TABLE_F4 = 96;
+constexpr int MH_SIZE = (MHF_ROWS + MHT_ROWS) * 256 + MH_TABLE_F4 * 4;
 constexpr int MAX_MODELS = 8;
 constexpr int MAX_GOALS = 64;
 enum { ALGO_WCM = 0, ALGO_MA = 1, ALGO_BCM = 2 };
@@ -93,6 +101,16 @@ size_t search_mfma_tape_bytes(int B, int N, int K);
 hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s);
 // phase-sequential variant (flow_phase.hip): one wave per 16-candidate block runs all K models, operands in LDS;
 // N % 16 == 0, any K <= MAX_MODELS, traces supported
+// split-f16 variant (flow_split.hip): the same decomposition with the contractions on v_mfma_f32_16x16x32_f16 and both
+// operands carried as two binary16 terms; operands = the MH blob (flow_split_pack.h)
+bool search_split_supported(const SearchArgs& a);
+size_t search_split_scratch_bytes(int B, int N, int K);
+hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void* scratch, hipStream_t s);
+// what a launch of the phase-sequential kernels executes on the matrix cores (rip_search_plan): out[0] = waves per
+// workgroup, then (f16, fp32) MFMA instructions per 16-candidate block of a forward / inverse pass, the adjoint of an
+// inverse pass, the adjoint of F_0, and of the prefix step per (model, observation)
+void search_split_info(int B, int N, int K, int out[9]);
+void search_phase_info(int B, int N, int K, int out[9]);
 bool search_phase_supported(const SearchArgs& a);
 size_t search_phase_scratch_bytes(int B, int N, int K);
 hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* scratch, hipStream_t s);

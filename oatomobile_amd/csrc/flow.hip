@@ -1014,6 +1014,7 @@ __global__ __launch_bounds__(NW * 64) void search_pipe_kernel(SearchArgs a) {
 constexpr int PLAN_ROWS = 30;
 constexpr int PLAN_INC = 10;
 __device__ __forceinline__ void interpolate_rows(const float* __restrict__ p, double* __restrict__ o, int lane) {
+#pragma clang fp contract(off)  // numpy rounds the product before the sum; hipcc's default would fuse them into one fma
   if (lane >= PLAN_ROWS) return;
   int hi = (lane + PLAN_INC - 1) / PLAN_INC;  // searchsorted(knots, t, 'left')
   hi = hi < 1 ? 1 : (hi > 3 ? 3 : hi);
@@ -1024,7 +1025,8 @@ __device__ __forceinline__ void interpolate_rows(const float* __restrict__ p, do
     const float ylo = p[2 * lo + d], yhi = p[2 * hi + d];
     const float diff = yhi - ylo;
     const double slope = (double)diff / (double)PLAN_INC;
-    o[lane * 3 + d] = __dadd_rn(__dmul_rn(slope, dt), (double)ylo);
+    const double prod = slope * dt;
+    o[lane * 3 + d] = prod + (double)ylo;
   }
   o[lane * 3 + 2] = 0.0;
 }

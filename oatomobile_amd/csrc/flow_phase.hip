@@ -956,25 +956,45 @@ hipError_t launch_phase_wpb(const SearchArgs& a, const float* mw_all, const floa
 }
 }  // namespace
 
+// waves per workgroup: as many as keep ~256 workgroups (one per CU: the operand buffers fill its LDS) in the launch.
+// Cost model from the measurements: an 8-wave workgroup (two waves per SIMD) takes twice as long as a 4-wave one (2.3 vs
+// 1.15 ms for 10 Adam steps at K = 4), a 2-wave one about as long as a 4-wave one (1.1 ms); a launch is
+// ceil(workgroups / CUs) rounds of that.  Ties go to the larger workgroup (fewer operand DMA streams).
+static int phase_pick_wpb(int items) {
+#ifdef RIP_FORCE_WPB  // development: pin the workgroup shape (profiling the register-tape builds at full launches)
+  return RIP_FORCE_WPB;
+#endif
+  const int cus = device_cu_count();
+  auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
+  const double c8 = 2.0 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
+  if (c8 <= c4 && c8 <= c2) return 8;
+  return c4 <= c2 ? 4 : 2;
+}
+
+// MFMA instructions (v_mfma_f32_16x16x4_f32) of a launch per 16-candidate block, same slots as search_split_info (the
+// f16 slots are 0): fwd_step_lds = 251, an adjoint step = 274 (82 at t = T-1) + 4 when its tape is read back (gi_n).
+void search_phase_info(int B, int N, int K, int out[9]) {
+  (void)K;
+  const int wpb = phase_pick_wpb(B * (N / CB));
+  const bool regtape = RIP_REGTAPE && wpb <= 4;
+  out[0] = wpb;
+  out[1] = 0, out[2] = 3 * 251;
+  out[3] = 0, out[4] = 2 * 274 + 82 + (regtape ? 0 : 2 * 4);
+  out[5] = 0, out[6] = 2 * 274 + 82 + 3 * 4;
+  out[7] = 0, out[8] = 251;
+}
+
 hipError_t launch_search_phase(const SearchArgs& a, const float* mw_all, void* scratch, hipStream_t s) {
   float* pre = reinterpret_cast<float*>(scratch);
   const size_t pre_bytes = ((size_t)a.K * a.B * PRE_FLOATS * sizeof(float) + 255) / 256 * 256;
   float4* tape = reinterpret_cast<float4*>(reinterpret_cast<char*>(scratch) + pre_bytes);
   hipLaunchKernelGGL(phase_prefix_kernel, dim3(a.B, a.K), dim3(64), 0, s, a, mw_all, pre);
   const int items = a.B * (a.N / CB);
-  // waves per workgroup: as many as keep ~256 workgroups (one per CU: the operand buffers fill its LDS) in the launch
-  const int cus = device_cu_count();
-  // cost model from the measurements: an 8-wave workgroup (two waves per SIMD) takes twice as long as a 4-wave one
-  // (2.3 vs 1.15 ms for 10 Adam steps at K = 4), a 2-wave one about as long as a 4-wave one (1.1 ms); a launch is
-  // ceil(workgroups / CUs) rounds of that.  Ties go to the larger workgroup (fewer operand DMA streams).
-#ifdef RIP_FORCE_WPB  // development: pin the workgroup shape (profiling the register-tape builds at full launches)
-  return launch_phase_wpb<RIP_FORCE_WPB>(a, mw_all, pre, tape, items, s);
-#endif
-  auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
-  const double c8 = 2.0 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
-  if (c8 <= c4 && c8 <= c2) return launch_phase_wpb<8>(a, mw_all, pre, tape, items, s);
-  if (c4 <= c2) return launch_phase_wpb<4>(a, mw_all, pre, tape, items, s);
-  return launch_phase_wpb<2>(a, mw_all, pre, tape, items, s);
+  switch (phase_pick_wpb(items)) {
+    case 8: return launch_phase_wpb<8>(a, mw_all, pre, tape, items, s);
+    case 4: return launch_phase_wpb<4>(a, mw_all, pre, tape, items, s);
+    default: return launch_phase_wpb<2>(a, mw_all, pre, tape, items, s);
+  }
 }
 
 }  // namespace rip

@@ -1,0 +1,706 @@
+// Device functions of the split-f16 plan search (flow_split.hip; also compiled into tools/micro/split_f16.hip).
+//
+// The GRU / head contractions of flow_phase.hip, moved from v_mfma_f32_16x16x4_f32 (32 cycles, K = 4) to
+// v_mfma_f32_16x16x32_f16 (16 cycles, K = 32) without giving up fp32-grade results: both operands are carried as two
+// binary16 terms, x ~= hi + lo' * 2^-11 with hi = f16(x), lo' = f16((x - hi) * 2^11), and a product is three MFMAs
+//     W x ~= Whi xhi + 2^-11 (Whi xlo' + Wlo' xhi)        (the dropped Wlo xlo term is 2^-22 relative)
+// with the two groups in separate fp32 accumulators (binary16 products are exact in fp32; accumulation is fp32).
+// 22 significant bits per operand instead of 24: the teacher-forced 1e-4 tests are the gate (tests/test_gpu_parity.py).
+// The weights are split on the host (flow_split_pack.h); activations / gradients are split here, per candidate:
+//   * hidden states (|h| <= max(1, |z|)) and the head's hidden layer are split as they are;
+//   * adjoint quantities (unbounded either way) are first scaled by a per-candidate power of two that puts the
+//     candidate's largest entry at 2^13, and the contraction's result is scaled back — exact, and neither overflow
+//     (binary16 max 65504) nor the subnormal range is ever reached by values that matter.
+// A 64-unit vector in the "H layout" (lane (c, q) holds units 16u + 4q + r in H[4u + r]) needs NO data movement to
+// become a B operand: K block kb of a lane = its H[8kb .. 8kb+7]; the unit permutation lives in the operand rows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "flow_math.h"
+
+namespace rip {
+namespace split {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr float LO_SCALE = 2048.0f;
+constexpr float LO_INV = 1.0f / 2048.0f;
+constexpr int T = 4;
+constexpr int CB = 16;  // candidates per wave
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfmah(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+__device__ __forceinline__ h16x8 as_h8(uint4 u) {
+  u32x4 v = {u.x, u.y, u.z, u.w};
+  return __builtin_bit_cast(h16x8, v);
+}
+__device__ __forceinline__ float4 as_f4(uint4 u) {
+  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+
+// B operands of a 64-unit vector (or of any 16 values per lane): two K blocks, two terms each
+struct BSplit {
+  h16x8 hi[2], lo[2];
+};
+
+// 8 fp32 -> (hi, lo') packed halves.  `s` = a power-of-two pre-scale (1 for bounded quantities).
+// Per pair: v_pk_mul (s), v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add, v_pk_mul (2^11), v_cvt_pk_f16_f32.
+template <bool SCALED>
+__device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8& lo) {
+  u32x4 uh, ul;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x = {v[2 * p], v[2 * p + 1]};
+    if (SCALED) x = x * f32x2{s, s};
+    const h16x2 h = __builtin_convertvector(x, h16x2);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    const f32x2 r = (x - back) * f32x2{LO_SCALE, LO_SCALE};
+    const h16x2 l = __builtin_convertvector(r, h16x2);
+    uh[p] = __builtin_bit_cast(unsigned, h);
+    ul[p] = __builtin_bit_cast(unsigned, l);
+  }
+  hi = __builtin_bit_cast(h16x8, uh);
+  lo = __builtin_bit_cast(h16x8, ul);
+}
+__device__ __forceinline__ void split16(const float (&v)[16], BSplit& b) {
+  split8<false>(&v[0], 1.f, b.hi[0], b.lo[0]);
+  split8<false>(&v[8], 1.f, b.hi[1], b.lo[1]);
+}
+
+// max |.| over the 4 q-lanes of a candidate (lanes c, c+16, c+32, c+48): two swaps on the VALU, no LDS
+__device__ __forceinline__ float qmax(float m) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+// power of two that moves `amax` (>= 0) to [2^13, 2^14), and its inverse; amax == 0 -> 1
+__device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
+  const int e = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) : 14;  // amax = f * 2^e, f in [0.5, 1)
+  s = __builtin_ldexpf(1.0f, 14 - e);
+  inv = __builtin_ldexpf(1.0f, e - 14);
+}
+
+#ifndef RIP_PRIO
+#define RIP_PRIO 1
+#endif
+#define SPLIT_PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define SPLIT_PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#ifndef RIP_ABL
+#define RIP_ABL 0  // development only: 1 = no tape loads, 3 = no tape stores (wrong results)
+#endif
+
+// Adjoint tape of one heavy step, per lane: rows 0..15 = (r, z, -, gh_n) of the 4 unit tiles (slot 2 of a tile stays
+// unused: n is recomputed), rows 16..19 = hprev (not written at t = 1: that is the prefix H1), then one dword with the
+// ReLU mask of a1 (8 bits).
+constexpr int TAPE_ROWS = 20;
+constexpr int TAPE_STEP_F4 = TAPE_ROWS * 64 + 16;
+constexpr int TAPE_SLOT_F4 = 3 * TAPE_STEP_F4;
+
+__device__ __forceinline__ void tape_st(float4* p, float a, float b, float c, float d) {
+  if (RIP_ABL != 3) *p = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ float4 tape_ld(const float4* p) {
+  if (RIP_ABL == 1) return make_float4(0.3f, 0.4f, 0.5f, 0.6f);
+  return *p;
+}
+__device__ __forceinline__ float4* trow(float4* base, int r, unsigned loff) {
+  return reinterpret_cast<float4*>(reinterpret_cast<char*>(base + r * 64) + loff);
+}
+__device__ __forceinline__ const float4* trow(const float4* base, int r, unsigned loff) {
+  return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base + r * 64) + loff);
+}
+
+struct StepTape {
+  float hp[16], r[16], z[16], n[16], gh[16];
+  unsigned mask;
+};
+enum { SAVE_NONE = 0, SAVE_TAPE = 1, SAVE_TAPE_NOHP = 2, SAVE_REGS = 3 };
+enum { MODE_FWD = 0, MODE_INV = 1 };
+
+// gate math of one unit tile (flow_phase.hip:gru_gates)
+__device__ __forceinline__ void gru_gates(const f32x4& ar, const f32x4& az, const f32x4& agn, const f32x4& ahn,
+                                          const float* Hold, float* Hn, float (&rr)[4], float (&zz)[4], float (&nn)[4]) {
+  const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+  constexpr float L2E = 1.4426950408889634f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2 pr = f32x2{ar[2 * h], ar[2 * h + 1]} * f32x2{-L2E, -L2E};
+    const f32x2 pz = f32x2{az[2 * h], az[2 * h + 1]} * f32x2{-L2E, -L2E};
+    const f32x2 er = {__builtin_amdgcn_exp2f(pr.x), __builtin_amdgcn_exp2f(pr.y)};
+    const f32x2 ez = {__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)};
+    const f32x2 dr = er + one, dz = ez + one;
+    const f32x2 r2 = {rcpf_(dr.x), rcpf_(dr.y)};
+    const f32x2 z2 = {rcpf_(dz.x), rcpf_(dz.y)};
+    const f32x2 pre = __builtin_elementwise_fma(r2, f32x2{ahn[2 * h], ahn[2 * h + 1]}, f32x2{agn[2 * h], agn[2 * h + 1]});
+    const f32x2 pn = pre * f32x2{2.0f * L2E, 2.0f * L2E};
+    const f32x2 en = {__builtin_amdgcn_exp2f(pn.x), __builtin_amdgcn_exp2f(pn.y)};
+    const f32x2 dn = en + one;
+    const f32x2 in2 = {rcpf_(dn.x), rcpf_(dn.y)};
+    const f32x2 n2 = one - two * in2;
+    const f32x2 hold = {Hold[2 * h], Hold[2 * h + 1]};
+    const f32x2 hn = __builtin_elementwise_fma(z2, hold - n2, n2);  // (1-z)*n + z*h
+    rr[2 * h] = r2.x, rr[2 * h + 1] = r2.y;
+    zz[2 * h] = z2.x, zz[2 * h + 1] = z2.y;
+    nn[2 * h] = n2.x, nn[2 * h + 1] = n2.y;
+    Hn[2 * h] = hn.x, Hn[2 * h + 1] = hn.y;
+  }
+}
+
+// One GRU + head step for 16 candidates.  `wl` = this lane's column of the forward operand rows in LDS (MHF_* in
+// flow.h); H = the hidden state (H layout), `hs` = its split B operands — both are replaced by the new state's.
+// Per unit tile: 4 fp32 MFMAs (input / bias k-steps: y is unbounded, they stay exact) + 2 K blocks x 3 gates x 3 f16
+// MFMAs; head: 2 + 12 + 9.  84 f16 + 27 fp32 MFMAs = 2208 matrix-pipe cycles (flow_phase.hip: 251 x 32 = 8032).
+template <int SAVE>
+__device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit& hs, float yp0, float yp1, int q,
+                                         unsigned lane, float4* __restrict__ tape, StepTape* tr, float (&o)[4]) {
+  const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
+  unsigned loff = lane * 16u;
+  asm volatile("" : "+v"(loff));  // flow_phase.hip: keeps the tape addressing scalar base + one lane offset
+  const float4 wxr = as_f4(wl[48 * 64]), wxz = as_f4(wl[49 * 64]), wxg = as_f4(wl[50 * 64]), wxh = as_f4(wl[51 * 64]);
+  const float wxra[4] = {wxr.x, wxr.y, wxr.z, wxr.w}, wxza[4] = {wxz.x, wxz.y, wxz.z, wxz.w};
+  const float wxga[4] = {wxg.x, wxg.y, wxg.z, wxg.w}, wxha[4] = {wxh.x, wxh.y, wxh.z, wxh.w};
+  // operand rows of group (up, kb): rows ((g * 4 + up) * 2 + kb) * 2 + term, g = 0..2 — requested one group (9 MFMAs)
+  // ahead of their use
+  uint4 cur[6], nxt[6];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    cur[2 * g] = wl[(((g * 4 + 0) * 2 + 0) * 2 + 0) * 64];
+    cur[2 * g + 1] = wl[(((g * 4 + 0) * 2 + 0) * 2 + 1) * 64];
+  }
+  float Hn[16];
+#pragma unroll
+  for (int up = 0; up < 4; ++up) {
+    f32x4 ar, az, agn, ahn, arl = zero4(), azl = zero4(), ahl = zero4();
+    SPLIT_PRIO_BURST();
+    ar = mfma4(wxra[up], bin, zero4());
+    az = mfma4(wxza[up], bin, zero4());
+    agn = mfma4(wxga[up], bin, zero4());
+    ahn = mfma4(wxha[up], bin, zero4());
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int ng = up * 2 + kb + 1;  // next group
+      if (ng < 8) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          nxt[2 * g] = wl[(((g * 4 + (ng >> 1)) * 2 + (ng & 1)) * 2 + 0) * 64];
+          nxt[2 * g + 1] = wl[(((g * 4 + (ng >> 1)) * 2 + (ng & 1)) * 2 + 1) * 64];
+        }
+      } else {  // the head's first rows (tile 0, kb 0 / 1: hi, lo')
+        nxt[0] = wl[(52 + 0) * 64], nxt[1] = wl[(52 + 1) * 64], nxt[2] = wl[(52 + 2) * 64], nxt[3] = wl[(52 + 3) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const h16x8 bh = hs.hi[kb], bl = hs.lo[kb];
+      ar = mfmah(as_h8(cur[0]), bh, ar);
+      az = mfmah(as_h8(cur[2]), bh, az);
+      ahn = mfmah(as_h8(cur[4]), bh, ahn);
+      arl = mfmah(as_h8(cur[0]), bl, arl);
+      azl = mfmah(as_h8(cur[2]), bl, azl);
+      ahl = mfmah(as_h8(cur[4]), bl, ahl);
+      arl = mfmah(as_h8(cur[1]), bh, arl);
+      azl = mfmah(as_h8(cur[3]), bh, azl);
+      ahl = mfmah(as_h8(cur[5]), bh, ahl);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) cur[i] = nxt[i];
+    }
+    SPLIT_PRIO_VALU();
+    ar = ar + arl * LO_INV;
+    az = az + azl * LO_INV;
+    ahn = ahn + ahl * LO_INV;
+    float rr[4], zz[4], nn[4];
+    gru_gates(ar, az, agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
+    if (SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) {
+      tape_st(trow(tape, up * 4 + 0, loff), rr[0], rr[1], rr[2], rr[3]);
+      tape_st(trow(tape, up * 4 + 1, loff), zz[0], zz[1], zz[2], zz[3]);
+      tape_st(trow(tape, up * 4 + 3, loff), ahn[0], ahn[1], ahn[2], ahn[3]);
+      if (SAVE == SAVE_TAPE) tape_st(trow(tape, 16 + up, loff), H[up * 4], H[up * 4 + 1], H[up * 4 + 2], H[up * 4 + 3]);
+    }
+    if (SAVE == SAVE_REGS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tr->hp[up * 4 + r] = H[up * 4 + r];
+        tr->r[up * 4 + r] = rr[r];
+        tr->z[up * 4 + r] = zz[r];
+        tr->n[up * 4 + r] = nn[r];
+        tr->gh[up * 4 + r] = ahn[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) H[i] = Hn[i];
+  split16(H, hs);  // the head's B operands == the next step's
+  // ---- head: rows 52..59 = W1 ((tile mt, kb) x (hi, lo')), 60..62 fp32: (b1 t0, b1 t1, W2 k0, k1), W2 k2..5, (k6, k7, b2) ----
+  const float bone = q == 2 ? 1.f : 0.f;
+  const float4 t60 = as_f4(wl[60 * 64]), t61 = as_f4(wl[61 * 64]), t62 = as_f4(wl[62 * 64]);
+  SPLIT_PRIO_BURST();
+  f32x4 a0 = mfma4(t60.x, bone, zero4()), a1 = mfma4(t60.y, bone, zero4()), a0l = zero4(), a1l = zero4();
+  {
+    const uint4 w4 = wl[(52 + 4) * 64], w5 = wl[(52 + 5) * 64], w6 = wl[(52 + 6) * 64], w7 = wl[(52 + 7) * 64];
+    // cur[0..3] = tile 0: (kb 0 hi, kb 0 lo', kb 1 hi, kb 1 lo'); w4..w7 = tile 1
+    a0 = mfmah(as_h8(cur[0]), hs.hi[0], a0);
+    a1 = mfmah(as_h8(w4), hs.hi[0], a1);
+    a0l = mfmah(as_h8(cur[0]), hs.lo[0], a0l);
+    a1l = mfmah(as_h8(w4), hs.lo[0], a1l);
+    a0l = mfmah(as_h8(cur[1]), hs.hi[0], a0l);
+    a1l = mfmah(as_h8(w5), hs.hi[0], a1l);
+    a0 = mfmah(as_h8(cur[2]), hs.hi[1], a0);
+    a1 = mfmah(as_h8(w6), hs.hi[1], a1);
+    a0l = mfmah(as_h8(cur[2]), hs.lo[1], a0l);
+    a1l = mfmah(as_h8(w6), hs.lo[1], a1l);
+    a0l = mfmah(as_h8(cur[3]), hs.hi[1], a0l);
+    a1l = mfmah(as_h8(w7), hs.hi[1], a1l);
+  }
+  a0 = a0 + a0l * LO_INV;
+  a1 = a1 + a1l * LO_INV;
+  if (SAVE != SAVE_NONE) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m |= a0[r] > 0.f ? (1u << r) : 0u;
+      m |= a1[r] > 0.f ? (16u << r) : 0u;
+    }
+    if (SAVE == SAVE_REGS) {
+      tr->mask = m;
+    } else if (RIP_ABL != 3) {
+      *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tape + TAPE_ROWS * 64) + (loff >> 2)) = m;
+    }
+  }
+  f32x4 oa = zero4(), ob = zero4();
+  oa = mfma4(t60.z, fmaxf(a0[0], 0.f), oa);
+  ob = mfma4(t61.z, fmaxf(a1[0], 0.f), ob);
+  oa = mfma4(t60.w, fmaxf(a0[1], 0.f), oa);
+  ob = mfma4(t61.w, fmaxf(a1[1], 0.f), ob);
+  oa = mfma4(t61.x, fmaxf(a0[2], 0.f), oa);
+  ob = mfma4(t62.x, fmaxf(a1[2], 0.f), ob);
+  oa = mfma4(t61.y, fmaxf(a0[3], 0.f), oa);
+  ob = mfma4(t62.y, fmaxf(a1[3], 0.f), ob);
+  oa = mfma4(t62.z, bone, oa);
+  SPLIT_PRIO_VALU();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = oa[r] + ob[r];
+}
+
+
+struct Prefix16 {
+  float H1[16];
+  float dloc0, dloc1, s0, s1, lad;
+};
+constexpr int PRE_FLOATS = 72;  // per (model, observation): H1[64], dloc0, dloc1, s0, s1, lad, pad
+
+__device__ __forceinline__ Prefix16 load_prefix(const float* __restrict__ p, int q) {
+  Prefix16 pre;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 16 * u + 4 * q);
+    pre.H1[u * 4 + 0] = v.x, pre.H1[u * 4 + 1] = v.y, pre.H1[u * 4 + 2] = v.z, pre.H1[u * 4 + 3] = v.w;
+  }
+  pre.dloc0 = p[64], pre.dloc1 = p[65], pre.s0 = p[66], pre.s1 = p[67], pre.lad = p[68];
+  return pre;
+}
+
+struct PassOut {
+  float lad, sq;
+};
+
+// forward (x -> y, in place in `io`) or inverse (reads y from `io`) pass of the current model for this wave's 16
+// candidates (flow_phase.hip:pass_forward with the split-f16 step).  MODE_FWD tapes all three heavy steps, MODE_INV
+// tapes steps 1, 2 and hands step 3 over in registers (`last[2]`); REGTAPE: all three in registers.
+template <int MODE, bool REGTAPE = false>
+__device__ __forceinline__ PassOut pass_forward(const uint4* wl, const Prefix16& pre, float (*io)[8], float (*st)[6][CB],
+                                                float4* __restrict__ tape, StepTape* last, int c, int q, unsigned lane) {
+  PassOut po;
+  po.lad = pre.lad;
+  po.sq = 0.f;
+  float yp0, yp1;
+  {
+    float x0, x1;
+    if (MODE == MODE_FWD) {
+      x0 = io[c][0];
+      x1 = io[c][1];
+      yp0 = pre.dloc0 + pre.s0 * x0;
+      yp1 = pre.dloc1 + pre.s1 * x1;
+      po.sq = fmaf(x0, x0, x1 * x1);
+      __builtin_amdgcn_wave_barrier();
+      if (q == 0) {
+        io[c][0] = yp0;
+        io[c][1] = yp1;
+      }
+    } else {
+      yp0 = io[c][0];
+      yp1 = io[c][1];
+      x0 = (yp0 - pre.dloc0) * rcpf_(pre.s0);
+      x1 = (yp1 - pre.dloc1) * rcpf_(pre.s1);
+      po.sq = fmaf(x0, x0, x1 * x1);
+    }
+    if (q == 0) {
+      st[0][0][c] = x0;
+      st[0][1][c] = x1;
+      st[0][2][c] = pre.s0;
+      st[0][3][c] = pre.s1;
+    }
+  }
+  float H[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) H[i] = pre.H1[i];
+  BSplit hs;
+  split16(H, hs);
+  auto coupling = [&](int t, const float (&o)[4]) __attribute__((always_inline)) {
+    const float s0 = softplusf_(o[2]) + 1e-3f;  // sequence.py:133
+    const float s1 = softplusf_(o[3]) + 1e-3f;
+    float x0, x1, y0, y1;
+    if (MODE == MODE_FWD) {
+      x0 = io[c][2 * t];
+      x1 = io[c][2 * t + 1];
+      y0 = (yp0 + o[0]) + s0 * x0;  // sequence.py:136
+      y1 = (yp1 + o[1]) + s1 * x1;
+      po.sq = fmaf(x0, x0, fmaf(x1, x1, po.sq));
+      __builtin_amdgcn_wave_barrier();
+      if (q == 0) {
+        io[c][2 * t] = y0;
+        io[c][2 * t + 1] = y1;
+      }
+    } else {
+      y0 = io[c][2 * t];
+      y1 = io[c][2 * t + 1];
+      x0 = (y0 - (yp0 + o[0])) * rcpf_(s0);  // sequence.py:196
+      x1 = (y1 - (yp1 + o[1])) * rcpf_(s1);
+      po.sq = fmaf(x0, x0, fmaf(x1, x1, po.sq));
+    }
+    po.lad += __logf(s0 * s1);
+    if (q == 0) {
+      st[t][0][c] = x0;
+      st[t][1][c] = x1;
+      st[t][2][c] = s0;
+      st[t][3][c] = s1;
+      st[t][4][c] = softplus_gradf_(o[2]);
+      st[t][5][c] = softplus_gradf_(o[3]);
+    }
+    yp0 = y0;
+    yp1 = y1;
+  };
+  // an opaque zero per step: the (loop-invariant) operand reads must not be merged across steps
+  {
+    float o[4];
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    if (REGTAPE)
+      fwd_step<SAVE_REGS>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[0], o);
+    else
+      fwd_step<SAVE_TAPE_NOHP>(wl + zero, H, hs, yp0, yp1, q, lane, tape, nullptr, o);
+    coupling(1, o);
+  }
+  {
+    float o[4];
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    if (REGTAPE)
+      fwd_step<SAVE_REGS>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[1], o);
+    else
+      fwd_step<SAVE_TAPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape + TAPE_STEP_F4, nullptr, o);
+    coupling(2, o);
+  }
+  {
+    float o[4];
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    if (MODE == MODE_FWD)
+      fwd_step<SAVE_TAPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape + 2 * TAPE_STEP_F4, nullptr, o);
+    else
+      fwd_step<SAVE_REGS>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[2], o);
+    coupling(3, o);
+  }
+  return po;
+}
+
+// Gate gradients of one adjoint step as B operands, split at ONE per-candidate power-of-two scale:
+// K blocks 0, 1 = d pre_r; 2, 3 = d pre_z (both feed W_hh^T of the next-earlier step and W_ih^T of this one);
+// gn = d gh_n (W_hh^T), and d pre_n (W_ih^T only) is split locally.  `inv` = 1 / scale.
+struct GSplit {
+  h16x8 rz_hi[4], rz_lo[4];
+  h16x8 gn_hi[2], gn_lo[2];
+  float inv;
+};
+
+__device__ __forceinline__ float amax8(const float* v, float m) {
+  m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
+  m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+  m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[4]), __builtin_fabsf(v[5])));
+  m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[6]), __builtin_fabsf(v[7])));
+  return m;
+}
+
+// One step t of the adjoint (flow_phase.hip:adj_step with split-f16 contractions).
+//   dh_t = W1^T da1_t [12 f16 MFMAs, own scale] + W_hh^T (dpr, dpz, dgh_n)_{t+1} [72 f16 MFMAs, `gs` from step t+1]
+//   du_t = W_ih^T (dpr, dpz, dpn)_t [18 f16 MFMAs, the scale of this step's gate gradients]
+// + 2 (W2^T) + 4 (gi_n) fp32 MFMAs: 1824 matrix-pipe cycles (flow_phase.hip: 278 x 32 = 8896).
+// tw: this lane's column of the transposed rows; wtab: this lane's entry (q * 2 + (c & 1)) of the W_ih^T table, one
+// group of 8 entries per (kb, term); wl: the forward rows (gi_n's k-step).  LASTSTEP (t = 1): nothing consumes the
+// gate gradients as W_hh^T operands any more.
+template <int MODE, int TS, bool FROM_REGS>
+__device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_in, const uint4* wl_in, const float (*io)[8],
+                                         const float (*gin)[8], const float (*st)[6][CB], const float4* __restrict__ tp,
+                                         const StepTape* tr, const float* hp1, int c, int q, float w0, float (&dhz)[16],
+                                         GSplit& gs, float& carry0, float& carry1, float (&res)[8]) {
+  constexpr bool FIRST = TS == T - 1;
+  constexpr bool LASTSTEP = TS == 1;
+  int zero = 0;
+  asm volatile("" : "+v"(zero));  // keeps the operand reads of this step from being merged with another step's
+  const uint4* tw = tw_in + zero;
+  const uint4* wtab = wtab_in + zero;
+  // ---- the step's tape ----
+  StepTape tl;
+  const StepTape* tv = tr;
+  if (!FROM_REGS) {
+    const unsigned lane = (unsigned)(q * 16 + c);
+    unsigned loff = lane * 16u;
+    asm volatile("" : "+v"(loff));
+    tl.mask = RIP_ABL == 1 ? 0x5au
+                           : *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(tp + TAPE_ROWS * 64) + (loff >> 2));
+#pragma unroll
+    for (int up = 0; up < 4; ++up) {
+      const float4 rr = tape_ld(trow(tp, up * 4 + 0, loff)), zz = tape_ld(trow(tp, up * 4 + 1, loff));
+      const float4 gh = tape_ld(trow(tp, up * 4 + 3, loff));
+      float4 hp;
+      if (TS == 1)
+        hp = *reinterpret_cast<const float4*>(hp1 + 16 * up + 4 * q);  // prefix H1 (global, L2)
+      else
+        hp = tape_ld(trow(tp, 16 + up, loff));
+      tl.r[up * 4 + 0] = rr.x, tl.r[up * 4 + 1] = rr.y, tl.r[up * 4 + 2] = rr.z, tl.r[up * 4 + 3] = rr.w;
+      tl.z[up * 4 + 0] = zz.x, tl.z[up * 4 + 1] = zz.y, tl.z[up * 4 + 2] = zz.z, tl.z[up * 4 + 3] = zz.w;
+      tl.gh[up * 4 + 0] = gh.x, tl.gh[up * 4 + 1] = gh.y, tl.gh[up * 4 + 2] = gh.z, tl.gh[up * 4 + 3] = gh.w;
+      tl.hp[up * 4 + 0] = hp.x, tl.hp[up * 4 + 1] = hp.y, tl.hp[up * 4 + 2] = hp.z, tl.hp[up * 4 + 3] = hp.w;
+    }
+    tv = &tl;
+    __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the contraction
+  }
+  const float x0 = st[TS][0][c], x1 = st[TS][1][c], s0 = st[TS][2][c], s1 = st[TS][3][c];
+  const float sg0 = st[TS][4][c], sg1 = st[TS][5][c];
+  float dd0, dd1, dos0, dos1, c0, c1;
+  if (MODE == MODE_INV) {
+    const float i0 = rcpf_(s0), i1 = rcpf_(s1);
+    const float xs0 = x0 * i0, xs1 = x1 * i1;
+    res[2 * TS] = carry0 - xs0;
+    res[2 * TS + 1] = carry1 - xs1;
+    c0 = xs0;
+    c1 = xs1;
+    dd0 = xs0;
+    dd1 = xs1;
+    dos0 = (x0 * x0 - 1.0f) * i0 * sg0;
+    dos1 = (x1 * x1 - 1.0f) * i1 * sg1;
+  } else {
+    const float D0 = gin[c][2 * TS] + carry0;
+    const float D1 = gin[c][2 * TS + 1] + carry1;
+    res[2 * TS] = fmaf(D0, s0, w0 * x0);
+    res[2 * TS + 1] = fmaf(D1, s1, w0 * x1);
+    c0 = D0;
+    c1 = D1;
+    dd0 = D0;
+    dd1 = D1;
+    dos0 = (D0 * x0 + w0 * rcpf_(s0)) * sg0;
+    dos1 = (D1 * x1 + w0 * rcpf_(s1)) * sg1;
+  }
+  // ---- head adjoint: da1 = relu'(a1) * W2^T do (fp32 MFMA: 4 inputs per candidate) ----
+  const float4 w2t = as_f4(tw[0]);
+  const float bdo = q == 0 ? dd0 : (q == 1 ? dd1 : (q == 2 ? dos0 : dos1));
+  const f32x4 da0 = mfma4(w2t.x, bdo, zero4());
+  const f32x4 da1 = mfma4(w2t.y, bdo, zero4());
+  const unsigned mask = tv->mask;
+  float da1r[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    da1r[r] = (mask >> r) & 1u ? da0[r] : 0.f;
+    da1r[4 + r] = (mask >> (4 + r)) & 1u ? da1[r] : 0.f;
+  }
+  // ---- dh_t, part 1: W1^T da1 at da1's own per-candidate scale ----
+  f32x4 dh[4];
+  {
+    float sa, ia;
+    pow2_scale(qmax(amax8(da1r, 0.f)), sa, ia);
+    h16x8 ah, al;
+    split8<true>(da1r, sa, ah, al);
+    SPLIT_PRIO_BURST();
+    f32x4 a[4], l[4];
+    uint4 wh[4], wo[4];
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) {
+      wh[ut] = tw[(1 + ut * 2) * 64];
+      wo[ut] = tw[(2 + ut * 2) * 64];
+    }
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(wh[ut]), ah, zero4());
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(wh[ut]), al, zero4());
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(wo[ut]), ah, l[ut]);
+    SPLIT_PRIO_VALU();
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + l[ut] * LO_INV) * ia;
+  }
+  // ---- part 2: W_hh^T (dpr, dpz, dgh_n)_{t+1}: 6 K blocks x 4 unit tiles, rows 9 + (kb * 4 + ut) * 2 + term ----
+  if (!FIRST) {
+    f32x4 a[4] = {zero4(), zero4(), zero4(), zero4()}, l[4] = {zero4(), zero4(), zero4(), zero4()};
+    SPLIT_PRIO_BURST();
+    uint4 ch[4], cl[4], nh[4], nl[4];
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) {
+      ch[ut] = tw[(9 + ut * 2) * 64];
+      cl[ut] = tw[(10 + ut * 2) * 64];
+    }
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+      if (kb < 5) {
+#pragma unroll
+        for (int ut = 0; ut < 4; ++ut) {
+          nh[ut] = tw[(9 + ((kb + 1) * 4 + ut) * 2) * 64];
+          nl[ut] = tw[(10 + ((kb + 1) * 4 + ut) * 2) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const h16x8 bh = kb < 4 ? gs.rz_hi[kb < 4 ? kb : 0] : gs.gn_hi[kb < 4 ? 0 : kb - 4];
+      const h16x8 bl = kb < 4 ? gs.rz_lo[kb < 4 ? kb : 0] : gs.gn_lo[kb < 4 ? 0 : kb - 4];
+#pragma unroll
+      for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(ch[ut]), bh, a[ut]);
+#pragma unroll
+      for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(ch[ut]), bl, l[ut]);
+#pragma unroll
+      for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(cl[ut]), bh, l[ut]);
+#pragma unroll
+      for (int ut = 0; ut < 4; ++ut) {
+        ch[ut] = nh[ut];
+        cl[ut] = nl[ut];
+      }
+    }
+    SPLIT_PRIO_VALU();
+    const float ig = gs.inv;
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) dh[ut] = dh[ut] + (a[ut] + l[ut] * LO_INV) * ig;
+  }
+  // ---- n of this step: tanh(gi_n + r gh_n), gi_n = the (W_in[.][0], W_in[.][1], b_in, 0) k-step on y_{t-1} ----
+  float nrec[16];
+  if (!FROM_REGS) {
+    const float4 wxg = as_f4((wl_in + zero)[50 * 64]);
+    const float yp0 = io[c][2 * (TS - 1)], yp1 = io[c][2 * (TS - 1) + 1];
+    const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
+    f32x4 agn_t[4];
+    agn_t[0] = mfma4(wxg.x, bin, zero4());
+    agn_t[1] = mfma4(wxg.y, bin, zero4());
+    agn_t[2] = mfma4(wxg.z, bin, zero4());
+    agn_t[3] = mfma4(wxg.w, bin, zero4());
+    constexpr float L2E = 1.4426950408889634f;
+    const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const f32x2 r2 = {tl.r[i], tl.r[i + 1]}, ghn = {tl.gh[i], tl.gh[i + 1]};
+      const f32x2 gin2 = {agn_t[i >> 2][i & 3], agn_t[i >> 2][(i & 3) + 1]};
+      const f32x2 pre = __builtin_elementwise_fma(r2, ghn, gin2);
+      const f32x2 pn = pre * f32x2{2.0f * L2E, 2.0f * L2E};
+      const f32x2 en = {__builtin_amdgcn_exp2f(pn.x), __builtin_amdgcn_exp2f(pn.y)};
+      const f32x2 dn = en + one;
+      const f32x2 in2 = {rcpf_(dn.x), rcpf_(dn.y)};
+      const f32x2 n2 = one - two * in2;
+      nrec[i] = n2.x;
+      nrec[i + 1] = n2.y;
+    }
+  }
+  // ---- GRUCell adjoint, lane-local in the H layout ----
+  float dpn[16], dgh[48];  // dgh: d pre_r (0-15), d pre_z (16-31), d gh_n (32-47)
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const f32x2 hp2 = {tv->hp[i], tv->hp[i + 1]}, rr2 = {tv->r[i], tv->r[i + 1]}, zz2 = {tv->z[i], tv->z[i + 1]};
+    const f32x2 nn2 = {FROM_REGS ? tv->n[i] : nrec[i], FROM_REGS ? tv->n[i + 1] : nrec[i + 1]}, gh2 = {tv->gh[i], tv->gh[i + 1]};
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 d = {dh[i >> 2][i & 3], dh[i >> 2][(i & 3) + 1]};
+    if (!FIRST) d = d + f32x2{dhz[i], dhz[i + 1]};
+    const f32x2 dn = d * (one - zz2);
+    const f32x2 dzg = d * (hp2 - nn2);
+    const f32x2 dhzn = d * zz2;
+    const f32x2 dp = dn * (one - nn2 * nn2);
+    const f32x2 dr = dp * gh2;
+    const f32x2 dgn = dp * rr2;
+    const f32x2 dpr = dr * rr2 * (one - rr2);
+    const f32x2 dpz = dzg * zz2 * (one - zz2);
+    dhz[i] = dhzn.x, dhz[i + 1] = dhzn.y;
+    dpn[i] = dp.x, dpn[i + 1] = dp.y;
+    dgh[32 + i] = dgn.x, dgh[33 + i] = dgn.y;
+    dgh[i] = dpr.x, dgh[1 + i] = dpr.y;
+    dgh[16 + i] = dpz.x, dgh[17 + i] = dpz.y;
+  }
+  // ---- this step's gate gradients as B operands: one per-candidate scale ----
+  float m = amax8(&dgh[0], 0.f);
+  m = amax8(&dgh[8], m);
+  m = amax8(&dgh[16], m);
+  m = amax8(&dgh[24], m);
+  if (!LASTSTEP) {
+    m = amax8(&dgh[32], m);
+    m = amax8(&dgh[40], m);
+  }
+  m = amax8(&dpn[0], m);
+  m = amax8(&dpn[8], m);
+  float sg, ig;
+  pow2_scale(qmax(m), sg, ig);
+  gs.inv = ig;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) split8<true>(&dgh[8 * kb], sg, gs.rz_hi[kb], gs.rz_lo[kb]);
+  if (!LASTSTEP) {
+    split8<true>(&dgh[32], sg, gs.gn_hi[0], gs.gn_lo[0]);
+    split8<true>(&dgh[40], sg, gs.gn_hi[1], gs.gn_lo[1]);
+  }
+  h16x8 pn_hi[2], pn_lo[2];
+  split8<true>(&dpn[0], sg, pn_hi[0], pn_lo[0]);
+  split8<true>(&dpn[8], sg, pn_hi[1], pn_lo[1]);
+  // ---- du = W_ih^T (dpr, dpz, dpn): 6 K blocks, one 16-row tile whose rows m hold input dim m & 1 ----
+  f32x4 ua = zero4(), ul = zero4(), ub = zero4();
+  SPLIT_PRIO_BURST();
+#pragma unroll
+  for (int kb = 0; kb < 6; ++kb) {
+    const h16x8 wh = as_h8(wtab[(kb * 2 + 0) * 8]), wo = as_h8(wtab[(kb * 2 + 1) * 8]);
+    const h16x8 bh = kb < 4 ? gs.rz_hi[kb < 4 ? kb : 0] : pn_hi[kb < 4 ? 0 : kb - 4];
+    const h16x8 bl = kb < 4 ? gs.rz_lo[kb < 4 ? kb : 0] : pn_lo[kb < 4 ? 0 : kb - 4];
+    ua = mfmah(wh, bh, ua);
+    ul = mfmah(wh, bl, ul);
+    ub = mfmah(wo, bh, ub);
+  }
+  SPLIT_PRIO_VALU();
+  carry0 = c0 + (ua[0] + (ul[0] + ub[0]) * LO_INV) * ig;
+  carry1 = c1 + (ua[1] + (ul[1] + ub[1]) * LO_INV) * ig;
+}
+
+// adjoint pass of the current model (flow_phase.hip:pass_backward)
+template <int MODE, bool REGTAPE = false>
+__device__ __forceinline__ void pass_backward(const uint4* tw, const uint4* wtab, const uint4* wl, const float (*io)[8],
+                                              const float (*gin)[8], const float (*st)[6][CB], const float4* __restrict__ tape,
+                                              const StepTape* last, const float* hp1, int c, int q, float (&res)[8], float w0) {
+  float dhz[16];
+  GSplit gs;
+  float carry0 = 0.f, carry1 = 0.f;
+  if (MODE == MODE_INV)
+    adj_step<MODE, 3, true>(tw, wtab, wl, io, gin, st, nullptr, &last[2], hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+  else
+    adj_step<MODE, 3, false>(tw, wtab, wl, io, gin, st, tape + 2 * TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+  if (REGTAPE) {
+    adj_step<MODE, 2, true>(tw, wtab, wl, io, gin, st, nullptr, &last[1], hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+    adj_step<MODE, 1, true>(tw, wtab, wl, io, gin, st, nullptr, &last[0], hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+  } else {
+    adj_step<MODE, 2, false>(tw, wtab, wl, io, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+    adj_step<MODE, 1, false>(tw, wtab, wl, io, gin, st, tape, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+  }
+  const float x0 = st[0][0][c], x1 = st[0][1][c], s0 = st[0][2][c], s1 = st[0][3][c];
+  if (MODE == MODE_INV) {
+    res[0] = carry0 - x0 * rcpf_(s0);
+    res[1] = carry1 - x1 * rcpf_(s1);
+  } else {
+    res[0] = fmaf(gin[c][0] + carry0, s0, w0 * x0);
+    res[1] = fmaf(gin[c][1] + carry1, s1, w0 * x1);
+  }
+}
+
+}  // namespace split
+}  // namespace rip

@@ -1,0 +1,91 @@
+// Host-side operand packing of the split-f16 plan-search kernel (flow_split.hip).
+//
+// Every fp32 weight w of the GRU / head contractions is stored as TWO binary16 terms
+//     w ~= hi + lo' * 2^-11,   hi = f16(w),  lo' = f16((w - hi) * 2^11)
+// (22 significant bits; the 2^11 keeps the residual in the normal range of binary16, so nothing depends on how the
+// matrix cores treat subnormal inputs).  An operand row is 64 lanes x 16 bytes = 8 halves per lane = one A operand of
+// v_mfma_f32_16x16x32_f16; the hi and lo' rows of a tile are separate rows.  Unit order inside a K block follows the
+// "H layout" of flow_phase.hip / flow_mfma.hip: lane (m = lane & 15, q = lane >> 4), half i <-> hidden unit
+// 16 * (2 kb + (i >> 2)) + 4 q + (i & 3), so the 16 fp32 values a lane holds of a 64-unit vector ARE its two B operands.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "flow.h"
+
+namespace rip {
+
+constexpr float SPLIT_LO_SCALE = 2048.0f;          // 2^11
+constexpr float SPLIT_LO_INV = 1.0f / 2048.0f;
+
+inline uint16_t split_f16_bits(float v) {
+  const _Float16 h = (_Float16)v;  // round to nearest even
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+inline void split_f16(float w, uint16_t* hi, uint16_t* lo) {
+  const _Float16 h = (_Float16)w;
+  const float r = (w - (float)h) * SPLIT_LO_SCALE;  // exact: w - h has at most 13 significant bits
+  *hi = split_f16_bits((float)h);
+  *lo = split_f16_bits(r);
+}
+
+// `mw` = the fp32 operand blob of the MFMA kernels (MW_SIZE floats, fold_and_pack): its fp32 rows (input / bias
+// k-steps, b1, W2, b2, W2^T) are reused as they are.  Reference tensors as in fold_and_pack.  Output: MH_SIZE dwords.
+inline void pack_split_operands(const float* mw, const float* wih, const float* whh, const float* w1,
+                                std::vector<uint32_t>& out) {
+  out.assign(MH_SIZE, 0u);
+  auto put = [&](size_t row_base_dw, int lane, int i, uint16_t v) {  // half i of the lane's 16-byte entry
+    uint32_t& d = out[row_base_dw + (size_t)lane * 4 + (i >> 1)];
+    d = (i & 1) ? ((d & 0x0000ffffu) | ((uint32_t)v << 16)) : ((d & 0xffff0000u) | v);
+  };
+  auto put2 = [&](size_t row_hi, int lane, int i, float w) {  // hi row at row_hi, lo' row right behind it
+    uint16_t h, l;
+    split_f16(w, &h, &l);
+    put(row_hi * 256, lane, i, h);
+    put((row_hi + 1) * 256, lane, i, l);
+  };
+  auto unit = [](int kb, int i, int q) { return 16 * (2 * kb + (i >> 2)) + 4 * q + (i & 3); };
+  auto gate_row = [](int s, int q) { return (s >> 4) * 64 + 16 * ((s >> 2) & 3) + 4 * q + (s & 3); };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, q = lane >> 4;
+    // ---- forward rows ----
+    for (int g = 0; g < 3; ++g)
+      for (int up = 0; up < 4; ++up)
+        for (int kb = 0; kb < 2; ++kb)
+          for (int i = 0; i < 8; ++i)
+            put2(MHF_WHH + ((g * 4 + up) * 2 + kb) * 2, lane, i, whh[(size_t)(g * 64 + 16 * up + m) * 64 + unit(kb, i, q)]);
+    for (int mt = 0; mt < 2; ++mt)
+      for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < 8; ++i) put2(MHF_W1 + (mt * 2 + kb) * 2, lane, i, w1[(16 * mt + m) * 64 + unit(kb, i, q)]);
+    // ---- transposed rows ----
+    for (int ut = 0; ut < 4; ++ut)
+      for (int i = 0; i < 8; ++i) put2(MHF_ROWS + MHT_W1T + ut * 2, lane, i, w1[(16 * (i >> 2) + 4 * q + (i & 3)) * 64 + 16 * ut + m]);
+    for (int kb = 0; kb < 6; ++kb)
+      for (int ut = 0; ut < 4; ++ut)
+        for (int i = 0; i < 8; ++i)
+          put2(MHF_ROWS + MHT_WHHT + (kb * 4 + ut) * 2, lane, i, whh[(size_t)gate_row(8 * kb + i, q) * 64 + 16 * ut + m]);
+  }
+  // fp32 rows shared with the fp32 kernels' blob: forward rows 48..51 and 60..62, transposed row 0
+  for (int r : {48, 49, 50, 51, 60, 61, 62}) std::memcpy(&out[(size_t)r * 256], mw + (size_t)r * 256, 1024);
+  std::memcpy(&out[(size_t)(MHF_ROWS + 0) * 256], mw + MWF_FLOATS, 1024);
+  // W_ih^T table for du = W_ih^T (dpr, dpz, dpn): entry ((kb * 2 + term) * 8 + q * 2 + parity), 8 halves each
+  const size_t tab = (size_t)(MHF_ROWS + MHT_ROWS) * 256;
+  for (int kb = 0; kb < 6; ++kb)
+    for (int q = 0; q < 4; ++q)
+      for (int par = 0; par < 2; ++par)
+        for (int i = 0; i < 8; ++i) {
+          uint16_t h, l;
+          split_f16(wih[gate_row(8 * kb + i, q) * 2 + par], &h, &l);
+          const size_t e_hi = tab + (size_t)((kb * 2 + 0) * 8 + q * 2 + par) * 4;
+          const size_t e_lo = tab + (size_t)((kb * 2 + 1) * 8 + q * 2 + par) * 4;
+          uint32_t& dh = out[e_hi + (i >> 1)];
+          uint32_t& dl = out[e_lo + (i >> 1)];
+          dh = (i & 1) ? ((dh & 0xffffu) | ((uint32_t)h << 16)) : ((dh & 0xffff0000u) | h);
+          dl = (i & 1) ? ((dl & 0xffffu) | ((uint32_t)l << 16)) : ((dl & 0xffff0000u) | l);
+        }
+}
+
+}  // namespace rip

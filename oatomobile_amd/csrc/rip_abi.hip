@@ -28,10 +28,12 @@ struct rip_handle {
   float* enc_w = nullptr;   // [K][plan.blob_floats]
   unsigned short* enc_wh = nullptr;  // [K][plan.blob_floats] bf16 copy of the folded blob (bf16 encoder)
   float* flow_w = nullptr;  // [K][FW_SIZE]
-  float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the MFMA search kernel
+  float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the fp32 MFMA search kernels
+  uint32_t* split_w = nullptr;  // [K][MH_SIZE] operands of the split-f16 search kernel
   void* tape = nullptr;     // scratch of the MFMA search kernel
   size_t tape_bytes = 0;
-  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA wave-per-model pipeline, 3 MFMA phase-sequential
+  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA wave-per-model pipeline, 3 fp32-MFMA phase-sequential,
+                            // 4 split-f16 phase-sequential
   int encoder_fused = -1;   // leading inverted-residual blocks run fused (0 = none, 17 = all); -1 = auto by batch
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
@@ -158,6 +160,11 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
   }
   ALLOC(h->flow_w, (size_t)K * FW_SIZE);
   ALLOC(h->mfma_w, (size_t)K * MW_SIZE);
+  {
+    float* tmp = nullptr;
+    ALLOC(tmp, (size_t)K * MH_SIZE);
+    h->split_w = reinterpret_cast<uint32_t*>(tmp);
+  }
   for (int i = 0; i < 4; ++i) ALLOC(h->bufs[i], h->buf_floats);
   ALLOC(h->visual, (size_t)max_batch * in_channels * 100 * 100);
   ALLOC(h->z, (size_t)K * max_batch * 64);
@@ -170,6 +177,8 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
   h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
   if (search_phase_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
     h->tape_bytes = search_phase_scratch_bytes(max_batch, max_candidates, K);
+  if (search_split_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
+    h->tape_bytes = search_split_scratch_bytes(max_batch, max_candidates, K);
   if (h->tape_bytes > 0) {
     float* tmp = nullptr;
     ALLOC(tmp, (h->tape_bytes + 3) / 4);
@@ -185,7 +194,7 @@ int rip_destroy(rip_handle* h) {
   DeviceScope scope(h->device);
   if (h->order != nullptr) (void)hipEventDestroy(h->order);
   if (h->tape != nullptr) (void)hipFree(h->tape);
-  float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
@@ -197,7 +206,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
   REQUIRE(h != nullptr, "handle is NULL");
   switch (option) {
     case RIP_OPT_SEARCH_KERNEL:
-      REQUIRE(value >= 0 && value <= 3, "search kernel %d not in {0 auto, 1 wave-per-chain, 2 mfma, 3 phase}", value);
+      REQUIRE(value >= 0 && value <= 4, "search kernel %d not in {0 auto, 1 wave-per-chain, 2 mfma, 3 phase, 4 split}", value);
       h->search_mode = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_FUSED:
@@ -218,8 +227,9 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
   REQUIRE(h != nullptr && packed_host != nullptr, "NULL argument");
   REQUIRE(k >= 0 && k < h->K, "model index %d outside [0,%d)", k, h->K);
   std::vector<float> enc, flow, mw;
+  std::vector<uint32_t> mh;
   const char* err = "";
-  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
+  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, mh, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
   DeviceScope scope(h->device);
   if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(scope.err));
   // setup call: synchronous copies; make sure no kernel of an earlier call still reads the old weights
@@ -236,6 +246,7 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
   }
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->split_w + (size_t)k * MH_SIZE, mh.data(), mh.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   h->loaded[k] = true;
   return RIP_OK;
 }
@@ -355,6 +366,15 @@ int rip_cil_decode(const float* feat_dev, const float* vec_dev, const float* wei
 
 int rip_cil_blob_floats(void) { return cil_blob_floats(); }
 
+// kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
+// wave-per-chain kernel has the lower latency for a single observation.  1 = wave-per-chain, 2 = fp32-MFMA wave-per-model
+// pipeline, 3 = fp32-MFMA phase-sequential, 4 = split-f16 phase-sequential (the default of large launches).
+static int pick_search_kernel(const rip_handle* h, int B, int N) {
+  if (h->search_mode != 0) return h->search_mode;
+  const bool big = (size_t)B * N >= 2304;
+  return big && N % 16 == 0 && h->K <= RIP_MAX_MODELS ? 4 : 1;
+}
+
 static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
                        int algorithm, int num_steps, float lr, float epsilon, float* plan_dev, float* plans_dev,
                        float* loss_best_dev, int32_t* best_index_dev, float* trace_post_dev, float* trace_x_dev,
@@ -404,20 +424,20 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
   // one (operands in LDS, two waves per SIMD, any K) is the default; mode 2 keeps the wave-per-model pipeline.
   // crossover measured at K = 4, N = 128: the chain kernel costs 64 us per observation, the phase kernel 1.1 ms per
   // launch up to one workgroup per CU (B = 16: 1.02 vs 1.11 ms, B = 32: 2.03 vs 1.11 ms)
-  const bool big = (size_t)B * N >= 2304;
-  int kernel = 1;
-  if (h->search_mode == 3 || (h->search_mode == 0 && big && search_phase_supported(a))) kernel = 3;
-  if (h->search_mode == 2) kernel = 2;
-  if (kernel == 3 && !search_phase_supported(a))
+  const int kernel = pick_search_kernel(h, B, N);
+  if ((kernel == 3 && !search_phase_supported(a)) || (kernel == 4 && !search_split_supported(a)))
     return fail(RIP_EINVAL, "phase-sequential MFMA search needs N%%16==0 and K<=%d (K=%d N=%d)", RIP_MAX_MODELS, h->K, N);
   if (kernel == 2 && !search_mfma_supported(a))
     return fail(RIP_EINVAL, "MFMA search kernel needs K<=4 and N%%16==0 (N%%32==0 with trace outputs) (K=%d N=%d)", h->K, N);
   if (kernel != 1) {
-    const size_t need = kernel == 3 ? search_phase_scratch_bytes(B, N, h->K) : search_mfma_tape_bytes(B, N, h->K);
+    const size_t need = kernel == 4 ? search_split_scratch_bytes(B, N, h->K)
+                                    : (kernel == 3 ? search_phase_scratch_bytes(B, N, h->K) : search_mfma_tape_bytes(B, N, h->K));
     if (need > h->tape_bytes)
       return fail(RIP_ESTATE, "MFMA search scratch for B=%d N=%d needs %zu B, rip_create sized %zu B (max_batch=%d x "
                   "max_candidates=%d)", B, N, need, h->tape_bytes, h->max_batch, h->max_candidates);
-    if (kernel == 3)
+    if (kernel == 4)
+      HIP_TRY(launch_search_split(a, h->split_w, h->tape, (hipStream_t)stream));
+    else if (kernel == 3)
       HIP_TRY(launch_search_phase(a, h->mfma_w, h->tape, (hipStream_t)stream));
     else
       HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));
@@ -435,6 +455,17 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
                float* trace_grad_dev, rip_stream_t stream) {
   return search_impl(h, z_dev, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, plans_dev,
                      loss_best_dev, best_index_dev, trace_post_dev, trace_x_dev, trace_grad_dev, nullptr, stream);
+}
+
+int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out) {
+  REQUIRE(h != nullptr && out != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && N >= 1 && n_out >= 10, "bad arguments B=%d N=%d n_out=%d (needs 10 slots)", B, N, n_out);
+  for (int i = 0; i < n_out; ++i) out[i] = 0;
+  const int kernel = pick_search_kernel(h, B, N);
+  out[0] = kernel;
+  if (kernel == 3 && N % 16 == 0) search_phase_info(B, N, h->K, out + 1);
+  if (kernel == 4 && N % 16 == 0) search_split_info(B, N, h->K, out + 1);
+  return RIP_OK;
 }
 
 int rip_interpolate_plans(const float* plan_dev, int B, double* out_dev, rip_stream_t stream) {

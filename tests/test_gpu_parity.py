@@ -330,7 +330,7 @@ def test_g6_rip_reference_recipe(golden, dev, algo):
     np.testing.assert_allclose(out, g["out30_" + tag], atol=TOL)
 
 
-@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase"])
+@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase", "split"])
 @pytest.mark.parametrize("algo", ["WCM", "MA", "BCM"])
 def test_g6_search_traces(golden, dev, algo, kernel):
   """Per-step posteriors, latents, best loss and plan of BOTH search kernels vs the instrumented reference loop
@@ -365,7 +365,7 @@ def test_g6_search_traces(golden, dev, algo, kernel):
     assert torch.isfinite(tg).all()
 
 
-@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase"])
+@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase", "split"])
 @pytest.mark.parametrize("algo,K", [("WCM", 4), ("MA", 3), ("BCM", 2)])
 def test_teacher_forced_steps_vs_oracle(dev, kernel, algo, K):
   """Removes trajectory amplification from the kernel-vs-oracle comparison: every Adam step of the ORACLE's
@@ -457,7 +457,9 @@ def test_g8_scores(golden, dev):
                                              ("mfma", "WCM", 4, 128), ("mfma", "MA", 3, 16), ("mfma", "BCM", 2, 32),
                                              ("mfma", "WCM", 1, 16),
                                              ("phase", "WCM", 4, 128), ("phase", "MA", 3, 16), ("phase", "BCM", 2, 48),
-                                             ("phase", "WCM", 1, 16), ("phase", "WCM", 8, 32), ("phase", "MA", 5, 16)])
+                                             ("phase", "WCM", 1, 16), ("phase", "WCM", 8, 32), ("phase", "MA", 5, 16),
+                                             ("split", "WCM", 4, 128), ("split", "MA", 3, 16), ("split", "BCM", 2, 48),
+                                             ("split", "WCM", 1, 16), ("split", "WCM", 8, 32), ("split", "MA", 5, 16)])
 def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
   """N candidates (BASELINE config 3 = K4/N128): every candidate's best loss and plan vs the oracle."""
   from oatomobile_amd import RIPAgent
@@ -499,11 +501,11 @@ def test_mfma_kernel_matches_chain_kernel(dev):
   vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
   goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
   out = {}
-  for kern in ("chain", "mfma", "phase"):
+  for kern in ("chain", "mfma", "phase", "split"):
     agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=32, max_batch=3, seed=9, search_kernel=kern)
     plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
     out[kern] = (plan.cpu().numpy(), loss.cpu().numpy())
-  for kern in ("mfma", "phase"):
+  for kern in ("mfma", "phase", "split"):
     close = np.abs(out["chain"][1] - out[kern][1]) <= 1e-3 + 1e-4 * np.abs(out["chain"][1])
     print("%s vs chain: %.4f of %d candidates within tolerance" % (kern, close.mean(), close.size))
     assert close.mean() >= 0.99, kern
@@ -1139,7 +1141,7 @@ def test_config4_k8_n512_on_the_mfma_kernel(dev):
   K, N, B = 8, 512, 4
   models = [hip_model(500 + k, dev) for k in range(K)]
   refs = [oracle_model(500 + k) for k in range(K)]
-  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=3, search_kernel="phase")
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=3, search_kernel="split")
   obs = [synth_observation(np.random.default_rng(120 + i)) for i in range(B)]
   lidar = torch.stack([torch.from_numpy(o["lidar"]) for o in obs]).to(dev)
   vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)

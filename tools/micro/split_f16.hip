@@ -1,0 +1,317 @@
+// Micro-benchmark 4: the split-f16 forward step of the plan search (oatomobile_amd/csrc/flow_split_dev.h: fwd_step)
+// against the fp32-MFMA step of flow_phase.hip (tools/micro/dual_block.hip's copy of its instruction mix).
+//   1. numerics: both steps on the same random GRU / head weights and states vs a float64 host reference;
+//   2. does the f16 matrix pipe flush subnormal inputs?  (informational: the split scheme never relies on them);
+//   3. throughput: cycles per step and wave at 1 / 2 / 3 waves per SIMD, operands in LDS, with the gate math, the
+//      hidden-state split and the coupling dependency in the loop.
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form -Ioatomobile_amd/csrc tools/micro/split_f16.hip -o /tmp/split_f16
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <vector>
+
+#include "flow_split_dev.h"
+#include "flow_split_pack.h"
+
+using namespace rip;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---- fp32 step (dual_block.hip, NB = 1) ----
+__device__ __forceinline__ void step_f32(const float4* wl, float (&H)[16], float yp0, float yp1, int q, float (&o)[4]) {
+  auto mfma = [](float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); };
+  float Hn[16];
+  const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
+  const float4 wxr = wl[48 * 64], wxz = wl[49 * 64], wxg = wl[50 * 64], wxh = wl[51 * 64];
+  const float wxra[4] = {wxr.x, wxr.y, wxr.z, wxr.w}, wxza[4] = {wxz.x, wxz.y, wxz.z, wxz.w};
+  const float wxga[4] = {wxg.x, wxg.y, wxg.z, wxg.w}, wxha[4] = {wxh.x, wxh.y, wxh.z, wxh.w};
+  constexpr float L2E = 1.4426950408889634f;
+#pragma unroll
+  for (int up = 0; up < 4; ++up) {
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, agn = ar, ahn = ar;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 wr = wl[((0 * 4 + up) * 4 + j) * 64], wz = wl[((1 * 4 + up) * 4 + j) * 64], wh = wl[((2 * 4 + up) * 4 + j) * 64];
+      const float wra[4] = {wr.x, wr.y, wr.z, wr.w}, wza[4] = {wz.x, wz.y, wz.z, wz.w}, wha[4] = {wh.x, wh.y, wh.z, wh.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ar = mfma(wra[e], H[4 * j + e], ar);
+        az = mfma(wza[e], H[4 * j + e], az);
+        ahn = mfma(wha[e], H[4 * j + e], ahn);
+      }
+    }
+    ar = mfma(wxra[up], bin, ar);
+    az = mfma(wxza[up], bin, az);
+    agn = mfma(wxga[up], bin, agn);
+    ahn = mfma(wxha[up], bin, ahn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float rr = rcpf_(__builtin_amdgcn_exp2f(-L2E * ar[r]) + 1.0f);
+      const float zz = rcpf_(__builtin_amdgcn_exp2f(-L2E * az[r]) + 1.0f);
+      const float pre = fmaf(rr, ahn[r], agn[r]);
+      const float nn = 1.0f - 2.0f * rcpf_(__builtin_amdgcn_exp2f(2.0f * L2E * pre) + 1.0f);
+      Hn[up * 4 + r] = fmaf(zz, H[up * 4 + r] - nn, nn);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) H[i] = Hn[i];
+  const float bone = q == 2 ? 1.f : 0.f;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 wa = wl[(52 + j) * 64], wb = wl[(56 + j) * 64];
+    const float waa[4] = {wa.x, wa.y, wa.z, wa.w}, wba[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a0 = mfma(waa[e], H[4 * j + e], a0);
+      a1 = mfma(wba[e], H[4 * j + e], a1);
+    }
+  }
+  const float4 t60 = wl[60 * 64], t61 = wl[61 * 64], t62 = wl[62 * 64];
+  a0 = mfma(t60.x, bone, a0);
+  a1 = mfma(t60.y, bone, a1);
+  f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = oa;
+  oa = mfma(t60.z, fmaxf(a0[0], 0.f), oa);
+  ob = mfma(t61.z, fmaxf(a1[0], 0.f), ob);
+  oa = mfma(t60.w, fmaxf(a0[1], 0.f), oa);
+  ob = mfma(t61.w, fmaxf(a1[1], 0.f), ob);
+  oa = mfma(t61.x, fmaxf(a0[2], 0.f), oa);
+  ob = mfma(t62.x, fmaxf(a1[2], 0.f), ob);
+  oa = mfma(t61.y, fmaxf(a0[3], 0.f), oa);
+  ob = mfma(t62.y, fmaxf(a1[3], 0.f), ob);
+  oa = mfma(t62.z, bone, oa);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = oa[r] + ob[r];
+}
+
+// ---- numerics: one step per wave on given H [blocks][16 cand][64], y [blocks][16][2] ----
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void one_step_kernel(const uint4* w, const float* Hin, const float* yin, float* Hout, float* oout) {
+  extern __shared__ uint4 fbuf[];
+  for (int i = threadIdx.x; i < 63 * 64; i += 64) fbuf[i] = w[i];
+  __syncthreads();
+  const int lane = threadIdx.x, c = lane & 15, q = lane >> 4, blk = blockIdx.x;
+  float H[16], o[4];
+  for (int u = 0; u < 4; ++u)
+    for (int r = 0; r < 4; ++r) H[u * 4 + r] = Hin[((size_t)blk * 16 + c) * 64 + 16 * u + 4 * q + r];
+  const float y0 = yin[(blk * 16 + c) * 2], y1 = yin[(blk * 16 + c) * 2 + 1];
+  if (SPLIT) {
+    split::BSplit hs;
+    split::split16(H, hs);
+    split::fwd_step<split::SAVE_NONE>(fbuf + lane, H, hs, y0, y1, q, (unsigned)lane, nullptr, nullptr, o);
+  } else {
+    step_f32(reinterpret_cast<const float4*>(fbuf) + lane, H, y0, y1, q, o);
+  }
+  for (int u = 0; u < 4; ++u)
+    for (int r = 0; r < 4; ++r) Hout[((size_t)blk * 16 + c) * 64 + 16 * u + 4 * q + r] = H[u * 4 + r];
+  if (q == 0)
+    for (int r = 0; r < 4; ++r) oout[(blk * 16 + c) * 4 + r] = o[r];
+}
+
+__global__ void denorm_kernel(float* out, float bval) {
+  using h8 = split::h16x8;
+  h8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (_Float16)1.0f;
+    b[i] = (_Float16)bval;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+// ---- throughput ----
+template <bool SPLIT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bench_kernel(const uint4* w, float* out, long long* cyc, int steps) {
+  extern __shared__ uint4 fbuf[];
+  for (int i = threadIdx.x; i < 63 * 64; i += WAVES * 64) fbuf[i] = w[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  float H[16], o[4], yp0 = 0.1f, yp1 = 0.2f;
+  for (int i = 0; i < 16; ++i) H[i] = 0.01f * (i + lane % 7);
+  split::BSplit hs;
+  split::split16(H, hs);
+  const long long t0 = clock64();
+#pragma unroll 1
+  for (int s = 0; s < steps; ++s) {
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    if (SPLIT)
+      split::fwd_step<split::SAVE_NONE>(fbuf + lane + zero, H, hs, yp0, yp1, q, (unsigned)lane, nullptr, nullptr, o);
+    else
+      step_f32(reinterpret_cast<const float4*>(fbuf) + lane + zero, H, yp0, yp1, q, o);
+    const float s0 = __logf(1.0f + __expf(o[2])) + 1e-3f, s1 = __logf(1.0f + __expf(o[3])) + 1e-3f;
+    yp0 = (yp0 + o[0]) + s0 * 0.3f;
+    yp1 = (yp1 + o[1]) + s1 * 0.3f;
+    yp0 = fminf(fmaxf(yp0, -40.f), 40.f);
+    yp1 = fminf(fmaxf(yp1, -40.f), 40.f);
+  }
+  const long long t1 = clock64();
+  float acc = yp0 + yp1;
+  for (int i = 0; i < 16; ++i) acc += H[i];
+  out[blockIdx.x * WAVES * 64 + threadIdx.x] = acc;
+  if (lane == 0) cyc[blockIdx.x * WAVES + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <bool SPLIT, int WAVES>
+void run(const uint4* w, float* out, long long* cyc, const char* name) {
+  const int steps = 300, blocks = 256;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel<SPLIT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((bench_kernel<SPLIT, WAVES>), dim3(blocks), dim3(WAVES * 64), 150 * 1024, 0, w, out, cyc, steps);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((bench_kernel<SPLIT, WAVES>), dim3(blocks), dim3(WAVES * 64), 150 * 1024, 0, w, out, cyc, steps);
+  hipEventRecord(e1, 0);
+  hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<long long> h(blocks * WAVES);
+  hipMemcpy(h.data(), cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (long long v : h) mean += (double)v;
+  mean /= h.size();
+  const double cps = mean / steps, wps = WAVES / 4.0;
+  const double pipe = SPLIT ? (84.0 * 16.0 + 27.0 * 32.0) : 251.0 * 32.0;
+  printf("%-52s %7.0f cycles/step/wave = %6.0f per block-step per SIMD  (matrix pipe busy %.1f %%, %.3f ms)\n", name, cps,
+         cps / wps, 100.0 * pipe * wps / cps, ms);
+}
+
+int main() {
+  // ---- weights: GRUCell(2 -> 64) + Linear(64, 32) + Linear(32, 4), PyTorch-style uniform init ----
+  std::vector<float> wih(192 * 2), whh(192 * 64), bih(192), bhh(192), w1(32 * 64), b1(32), w2(4 * 32), b2(4);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() {
+    st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+    return (double)(st >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+  };
+  for (auto& v : wih) v = 0.125f * (float)rnd();
+  for (auto& v : whh) v = 0.125f * (float)rnd();
+  for (auto& v : bih) v = 0.125f * (float)rnd();
+  for (auto& v : bhh) v = 0.125f * (float)rnd();
+  for (auto& v : w1) v = 0.125f * (float)rnd();
+  for (auto& v : b1) v = 0.125f * (float)rnd();
+  for (auto& v : w2) v = 0.177f * (float)rnd();
+  for (auto& v : b2) v = 0.177f * (float)rnd();
+  // fp32 forward blob, as encoder.hip:fold_and_pack lays it out
+  std::vector<float> mw(MW_SIZE, 0.f);
+  auto F = [&](int idx, int lane) -> float& { return mw[(size_t)(idx / 4) * 256 + lane * 4 + (idx & 3)]; };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, q = lane >> 4;
+    for (int g = 0; g < 3; ++g)
+      for (int up = 0; up < 4; ++up)
+        for (int u = 0; u < 4; ++u)
+          for (int r = 0; r < 4; ++r) F((g * 4 + up) * 16 + u * 4 + r, lane) = whh[(size_t)(g * 64 + 16 * up + m) * 64 + 16 * u + 4 * q + r];
+    for (int up = 0; up < 4; ++up) {
+      const int j = 16 * up + m;
+      for (int a = 0; a < 4; ++a) {
+        const int g = a < 2 ? a : 2;
+        float v = 0.f;
+        if (a < 3) {
+          if (q < 2) v = wih[(g * 64 + j) * 2 + q];
+          if (q == 2) v = a < 2 ? bih[g * 64 + j] + bhh[g * 64 + j] : bih[g * 64 + j];
+        } else if (q == 2) {
+          v = bhh[128 + j];
+        }
+        F(192 + a * 4 + up, lane) = v;
+      }
+    }
+    for (int mt = 0; mt < 2; ++mt) {
+      for (int u = 0; u < 4; ++u)
+        for (int r = 0; r < 4; ++r) F(208 + mt * 16 + u * 4 + r, lane) = w1[(16 * mt + m) * 64 + 16 * u + 4 * q + r];
+      F(240 + mt, lane) = q == 2 ? b1[16 * mt + m] : 0.f;
+      for (int r = 0; r < 4; ++r) F(242 + mt * 4 + r, lane) = w2[(m & 3) * 32 + 16 * mt + 4 * q + r];
+    }
+    F(250, lane) = q == 2 ? b2[m & 3] : 0.f;
+  }
+  std::vector<uint32_t> mh;
+  pack_split_operands(mw.data(), wih.data(), whh.data(), w1.data(), mh);
+  uint4 *w32, *w16;
+  hipMalloc(&w32, 63 * 1024);
+  hipMalloc(&w16, 63 * 1024);
+  hipMemcpy(w32, mw.data(), 63 * 1024, hipMemcpyHostToDevice);
+  hipMemcpy(w16, mh.data(), 63 * 1024, hipMemcpyHostToDevice);
+
+  // ---- 1. numerics ----
+  const int NBLK = 64, NC = NBLK * 16;
+  for (int pass = 0; pass < 2; ++pass) {
+    const double hscale = pass == 0 ? 1.0 : 2.5;  // pass 1: a z-like start state (|h0| up to 2.5)
+    std::vector<float> Hin((size_t)NC * 64), yin(NC * 2);
+    for (auto& v : Hin) v = (float)(hscale * rnd());
+    for (auto& v : yin) v = (float)(30.0 * rnd());
+    float *dH, *dy, *dHo, *doo;
+    hipMalloc(&dH, Hin.size() * 4), hipMalloc(&dy, yin.size() * 4), hipMalloc(&dHo, Hin.size() * 4), hipMalloc(&doo, NC * 16);
+    hipMemcpy(dH, Hin.data(), Hin.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dy, yin.data(), yin.size() * 4, hipMemcpyHostToDevice);
+    // float64 reference
+    std::vector<double> Href((size_t)NC * 64), oref(NC * 4);
+    for (int n = 0; n < NC; ++n) {
+      const float* h = &Hin[(size_t)n * 64];
+      double hn[64];
+      for (int j = 0; j < 64; ++j) {
+        double gi[3], gh[3];
+        for (int g = 0; g < 3; ++g) {
+          gi[g] = (double)bih[g * 64 + j] + (double)wih[(g * 64 + j) * 2] * yin[n * 2] + (double)wih[(g * 64 + j) * 2 + 1] * yin[n * 2 + 1];
+          gh[g] = bhh[g * 64 + j];
+          for (int i = 0; i < 64; ++i) gh[g] += (double)whh[(size_t)(g * 64 + j) * 64 + i] * h[i];
+        }
+        const double r = 1.0 / (1.0 + exp(-(gi[0] + gh[0]))), z = 1.0 / (1.0 + exp(-(gi[1] + gh[1])));
+        const double nn = tanh(gi[2] + r * gh[2]);
+        hn[j] = (1.0 - z) * nn + z * h[j];
+        Href[(size_t)n * 64 + j] = hn[j];
+      }
+      double a[32];
+      for (int k = 0; k < 32; ++k) {
+        a[k] = b1[k];
+        for (int i = 0; i < 64; ++i) a[k] += (double)w1[k * 64 + i] * hn[i];
+        a[k] = a[k] > 0 ? a[k] : 0;
+      }
+      for (int c4 = 0; c4 < 4; ++c4) {
+        double v = b2[c4];
+        for (int k = 0; k < 32; ++k) v += (double)w2[c4 * 32 + k] * a[k];
+        oref[n * 4 + c4] = v;
+      }
+    }
+    for (int variant = 0; variant < 2; ++variant) {
+      if (variant == 0)
+        hipLaunchKernelGGL(one_step_kernel<false>, dim3(NBLK), dim3(64), 63 * 1024, 0, w32, dH, dy, dHo, doo);
+      else
+        hipLaunchKernelGGL(one_step_kernel<true>, dim3(NBLK), dim3(64), 63 * 1024, 0, w16, dH, dy, dHo, doo);
+      std::vector<float> Ho(Hin.size()), oo(NC * 4);
+      hipMemcpy(Ho.data(), dHo, Ho.size() * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(oo.data(), doo, oo.size() * 4, hipMemcpyDeviceToHost);
+      double eh = 0, eo = 0, rmsh = 0;
+      for (size_t i = 0; i < Ho.size(); ++i) {
+        const double d = fabs((double)Ho[i] - Href[i]);
+        eh = fmax(eh, d), rmsh += d * d;
+      }
+      for (size_t i = 0; i < oo.size(); ++i) eo = fmax(eo, fabs((double)oo[i] - oref[i]));
+      printf("numerics (|h| <= %.1f) %-22s max |dH| = %.3g (rms %.3g)   max |d head out| = %.3g\n", hscale,
+             variant == 0 ? "fp32 MFMA step:" : "split-f16 step:", eh, sqrt(rmsh / Ho.size()), eo);
+    }
+    hipFree(dH), hipFree(dy), hipFree(dHo), hipFree(doo);
+  }
+
+  // ---- 2. subnormal inputs on the f16 matrix pipe ----
+  float* dd;
+  hipMalloc(&dd, 16);
+  for (float v : {6.103515625e-05f /* 2^-14, smallest normal */, 3.0517578125e-05f /* 2^-15 */, 5.9604644775390625e-08f /* 2^-24 */}) {
+    hipLaunchKernelGGL(denorm_kernel, dim3(1), dim3(64), 0, 0, dd, v);
+    float r = 0.f;
+    hipMemcpy(&r, dd, 4, hipMemcpyDeviceToHost);
+    printf("f16 MFMA, A = 1, B = %.3g x 32: result %.6g (expected %.6g)%s\n", v, r, 32.0 * v, r == 0.f ? "  -> FLUSHED" : "");
+  }
+
+  // ---- 3. throughput ----
+  float* out;
+  long long* cyc;
+  hipMalloc(&out, 256 * 1024 * sizeof(float));
+  hipMalloc(&cyc, 256 * 16 * sizeof(long long));
+  run<false, 4>(w32, out, cyc, "fp32 MFMA step, 1 wave per SIMD");
+  run<false, 8>(w32, out, cyc, "fp32 MFMA step, 2 waves per SIMD");
+  run<true, 4>(w16, out, cyc, "split-f16 step, 1 wave per SIMD");
+  run<true, 8>(w16, out, cyc, "split-f16 step, 2 waves per SIMD");
+  run<true, 12>(w16, out, cyc, "split-f16 step, 3 waves per SIMD");
+  run<true, 16>(w16, out, cyc, "split-f16 step, 4 waves per SIMD");
+  return 0;
+}

@@ -10,7 +10,7 @@ BENCH="python bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 3"
 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- $BENCH > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv 2>/dev/null
 # 2. SQ counters of the plan-search kernel
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-include-regex search_phase -d $O/sq --output-format csv -- $BENCH > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-include-regex 'search_split|search_phase' -d $O/sq --output-format csv -- $BENCH > $O/sq.log 2>&1
 # 3. / 4. memory-side traffic of every kernel of the step (separate passes: FETCH_SIZE and WRITE_SIZE do not fit together)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- $BENCH > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- $BENCH > $O/write.log 2>&1
@@ -34,4 +34,7 @@ with open(os.path.join(O, "pmc_summary.csv"), "w") as out:
       w.writerow([k, c, "%.6g" % (sum(v) / len(v)), len(v), "%.6g" % sum(v)])
 print(open(os.path.join(O, "pmc_summary.csv")).read()[:6000])
 PY
+# HBM-side bytes per launch in the form bench.py reads (copy to profiles/measured.json with the summary it condenses)
+python tools/pmc_measured.py $O/pmc_summary.csv "profiles/r3/pmc_summary_${1:-vN}.csv" > $O/measured.json
+cat $O/measured.json
 head -40 $O/bench_kernel_stats.csv
