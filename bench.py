@@ -662,8 +662,37 @@ def _bench_replay(args, agent, dev, B, C):
       else:
         n_done += lid.shape[0]
     el = time.perf_counter() - t0
+    # BASELINE configs[4] at its size from the packed cache (replay.pack_cache: uint8 codes + float table, expanded in
+    # the transform kernel): the 256 datums packed once, tiled to 10 000 observations, replayed with the [30,3] plans
+    t0 = time.perf_counter()
+    small = replay.pack_cache(ep.files(), os.path.join(tmp, "cache256"))
+    pack_rate = nfiles / (time.perf_counter() - t0)
+    n10k = 10000
+    big_dir = os.path.join(tmp, "cache10k")
+    os.makedirs(big_dir)
+    idx = np.arange(n10k) % nfiles
+    codes = np.lib.format.open_memmap(os.path.join(big_dir, "codes.npy"), mode="w+", dtype=np.uint8,
+                                      shape=(n10k,) + small.codes.shape[1:])
+    for i0 in range(0, n10k, nfiles):
+      codes[i0:i0 + nfiles] = small.codes[:min(nfiles, n10k - i0)]
+    codes.flush()
+    del codes
+    np.save(os.path.join(big_dir, "lut.npy"), small.lut)
+    np.save(os.path.join(big_dir, "vec.npy"), small.vec[idx])
+    np.save(os.path.join(big_dir, "goal.npy"), small.goal[idx])
+    cache = replay.PackedCache(big_dir)
+    replay.replay_cache(agent, cache, B, interpolate=True, end=2 * B)  # warm-up (page cache, pinned buffers)
+    t0 = time.perf_counter()
+    plans = replay.replay_cache(agent, cache, B, interpolate=True)
+    cache_el = time.perf_counter() - t0
+    same = bool(np.array_equal(plans[:nfiles], plans[nfiles:2 * nfiles]))  # the tiling repeats: so must the plans
+    cache_line = {"observations_per_s": n10k / cache_el, "observations": n10k, "batch": B, "seconds": cache_el,
+                  "bytes_per_observation": int(np.prod(cache.codes.shape[1:])) + 4 * (5 + 2 * cache.goal.shape[1]),
+                  "pack_datums_per_s": pack_rate, "repeats_consistent": same,
+                  "note": "10 000 observations from the packed cache -> pinned staging -> H2D -> rip_encode_raw_u8 + search "
+                          "+ R11 -> [30,3] float64 plans on the host; one process, no decode workers"}
     return {"observations_per_s": n_done / el, "decode_processes": workers, "files": len(files), "batch": B,
-            "inline_decode_per_s": inline_rate,
+            "inline_decode_per_s": inline_rate, "packed_cache": cache_line,
             "note": "np.load (zipfile + zlib) of compressed 200x200x%d datums in %d worker processes -> shared-memory "
                     "batch -> H2D -> act(); one process decodes %.0f datums/s, which is what bounds a single-process "
                     "replay; this process may use %d CPUs (affinity / cgroup quota) of the host's %d" %

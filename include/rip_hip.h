@@ -110,6 +110,14 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
 int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev,
                    int B, int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream);
 
+/* rip_encode_raw on a CODED BEV (the replay cache of oatomobile_amd/replay.py): codes_dev
+ * [B,H,W,C] uint8 (sensor layout), every cell an index into lut_dev [256] float32 = the distinct values of the float32
+ * BEV it was packed from (the CARLA LIDAR histogram has six: k/5, utils/carla.py:225-233).  The table is applied while
+ * the transform stages its input, so z is bit-identical to rip_encode_raw on the float32 BEV at a quarter of the
+ * H2D / HBM bytes.  C <= 3 and a down-sampling factor <= 2 (200 x 200 -> 100 x 100). */
+int rip_encode_raw_u8(rip_handle* h, const uint8_t* codes_dev, const float* lut_dev, int H, int W, const float* vec_dev,
+                      int B, int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream);
+
 /* R6 — AutoregressiveFlow._forward of model k (sequence.py:95-151).
  * x_dev [N,4,2]; z_dev [z_rows,64] with z_rows == N or 1 (broadcast);
  * y_dev [N,4,2]; logabsdet_dev [N] (NULL to skip). */

@@ -203,6 +203,7 @@ class RIPAgent(SetPointAgent):
     x0[0] = 0.0  # base distribution mean (rip/agent.py:85)
     self._x0_rows = torch.from_numpy(x0).to(self._device)
     self._x0_cache = {}
+    self._coded_z = {}  # batch -> (z, plan) scratch of plan_batch_coded
     self._use_graph = bool(graph) and os.environ.get("RIP_NO_GRAPH", "0") != "1"
     self._online = {}  # (H, W, G) -> captured one-observation pipeline
 
@@ -267,6 +268,46 @@ class RIPAgent(SetPointAgent):
     else:
       self._launch_act(lidar, vec, goal, out, loss)
     return (out, loss) if return_loss else out
+
+  def plan_batch_coded(self, codes: torch.Tensor, lut: torch.Tensor, vec: torch.Tensor, goal: torch.Tensor,
+                       interpolate: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`plan_batch` on a CODED BEV (the replay cache, `replay.PackedCache`): codes [B,H,W,C] uint8 indices into
+    lut [256] float32 — the distinct float32 values of the BEV the cache was packed from — vec [B,5], goal [B,G,2].
+    The table is applied inside the transform kernel (`rip_encode_raw_u8`), so the plans are bit-identical to
+    `plan_batch` on the float32 BEV while a quarter of its bytes cross PCIe and HBM."""
+    dev = self._device
+    if not (isinstance(codes, torch.Tensor) and codes.is_cuda and codes.device == dev and codes.dtype == torch.uint8):
+      raise ValueError("plan_batch_coded: `codes` must be a uint8 tensor on %s" % (dev,))
+    _lib.expect_shape(codes, (None, None, None, self._in_channels), "codes")
+    b = codes.shape[0]
+    if b < 1 or b > self._max_batch:
+      raise ValueError("plan_batch_coded: batch %d outside [1, max_batch=%d]" % (b, self._max_batch))
+    _lib.expect_shape(lut, (256,), "lut")
+    _lib.expect_shape(vec, (b, 5), "vec")
+    _lib.expect_shape(goal, (b, None, 2), "goal")
+    if self._sync_weights():
+      self._online = {}
+    codes, vec, goal = codes.contiguous(), vec.contiguous(), goal.contiguous()
+    shape, dtype = ((b, PLAN_ROWS, 3), torch.float64) if interpolate else ((b, arch.T, 2), torch.float32)
+    if out is None:
+      out = torch.empty(shape, device=dev, dtype=dtype)
+    elif tuple(out.shape) != shape or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+      raise ValueError("plan_batch_coded: `out` must be a contiguous %s tensor of shape %s on %s" % (dtype, shape, dev))
+    K, N = len(self._models), self._num_candidates
+    lib, st = _lib.load(), self._handle.stream()
+    z = self._coded_z.get(b)
+    if z is None:
+      z = self._coded_z[b] = (torch.empty(K, b, 64, device=dev), torch.empty(b, arch.T, 2, device=dev))
+    z, plan4 = z
+    _lib.check(lib.rip_encode_raw_u8(self._handle.raw, _lib.ptr(codes, torch.uint8), _lib.ptr(lut), codes.shape[1], codes.shape[2],
+                                     _lib.ptr(vec), b, 0, K, self._enc_dtype, _lib.ptr(z), st))
+    target = plan4 if interpolate else out
+    _lib.check(lib.rip_search(self._handle.raw, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(self._x0(b)), b, N, goal.shape[1],
+                              _lib.ALGORITHMS[self._algorithm], self._num_steps, self._lr, self._epsilon, _lib.ptr(target),
+                              None, None, None, None, None, None, st))
+    if interpolate:
+      _lib.check(lib.rip_interpolate_plans(_lib.ptr(plan4), b, _lib.ptr(out, torch.float64), st))
+    return out
 
   def _launch_act(self, lidar, vec, goal, plan, loss, plan_interp=None) -> None:
     b = lidar.shape[0]

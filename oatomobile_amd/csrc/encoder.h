@@ -48,6 +48,9 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
                    std::vector<float>& flow_blob, std::vector<float>& mfma_blob, std::vector<uint32_t>& split_blob,
                    const char** err);
 
+bool transform_coded_supported(int C, int H, int W, int out_hw);
+hipError_t launch_transform_coded(const uint8_t* in, const float* lut /*[256]*/, int B, int C, int H, int W, int out_hw,
+                                  float* out, hipStream_t s);
 hipError_t launch_transform(const float* in, int B, int C, int H, int W, int channels_last, int out_hw, float* out,
                             hipStream_t s);
 

@@ -53,9 +53,12 @@ __device__ __forceinline__ float bilerp_fetch(const float* __restrict__ in, int 
 // patch with coalesced row reads, then every thread interpolates from LDS and writes NCHW rows coalesced.
 constexpr int TR_T = 32;            // output tile edge
 constexpr int TR_P = 2 * TR_T + 4;  // input patch edge bound for scale <= 2.02 (200 -> 100)
-template <int C, bool CL>
-__global__ __launch_bounds__(256) void transform_kernel(const float* __restrict__ in, int H, int W, int O,
-                                                         float* __restrict__ out) {
+// TIN = float: the sensor's float32 BEV.  TIN = uint8_t: a CODED BEV (replay cache, oatomobile_amd/replay.py): every
+// cell holds an index into `lut` (256 float32 values, the distinct values of the float BEV it was packed from), looked
+// up while the patch is staged — a quarter of the bytes, the same float32 values, hence bit-identical outputs.
+template <int C, bool CL, typename TIN = float>
+__global__ __launch_bounds__(256) void transform_kernel(const TIN* __restrict__ in, const float* __restrict__ lut, int H,
+                                                         int W, int O, float* __restrict__ out) {
   // The patch keeps the memory order of the input; all staging loads of a thread are issued before the first LDS
   // write (the kernel is pure latency otherwise), and the row pitch is odd so the interpolation reads (consecutive
   // lanes sit two patch rows apart) spread over the banks.
@@ -65,6 +68,9 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
   constexpr int TOTAL = ROW * NROWS;
   constexpr int ITER = (TOTAL + 255) / 256;
   extern __shared__ float patch[];
+  constexpr bool CODED = sizeof(TIN) == 1;
+  float* lut_s = patch + PITCH * NROWS;  // CODED: the table, behind the patch
+  if (CODED) lut_s[threadIdx.x] = lut[threadIdx.x];
   const float sh = O > 1 ? (float)(H - 1) / (float)(O - 1) : 0.f;
   const float sw = O > 1 ? (float)(W - 1) / (float)(O - 1) : 0.f;
   const int b = blockIdx.z, ti = blockIdx.y, tj = blockIdx.x;  // ti: output rows i (input x), tj: output cols j (input y)
@@ -72,12 +78,12 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
   const int y0 = (int)(sh * (float)j0), x0 = (int)(sw * (float)i0);
   const int py = min(TR_P, H - y0), px = min(TR_P, W - x0);
   const int tid = threadIdx.x;
-  float v[ITER];
+  TIN v[ITER];
 #pragma unroll
   for (int k = 0; k < ITER; ++k) {
     const int e = tid + 256 * k, r = e / ROW, t = e - r * ROW;
     bool ok;
-    const float* src;
+    const TIN* src;
     if (CL) {
       ok = r < py && t < px * C;
       src = in + (((size_t)b * H + y0 + r) * W + x0) * C + t;
@@ -86,12 +92,20 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
       ok = c < C && y < py && t < px;
       src = in + (((size_t)b * C + c) * H + y0 + y) * W + x0 + t;
     }
-    v[k] = ok ? *src : 0.f;
+    v[k] = ok ? *src : (TIN)0;
   }
+  if (CODED) __syncthreads();  // the table is in LDS
 #pragma unroll
   for (int k = 0; k < ITER; ++k) {
     const int e = tid + 256 * k, r = e / ROW, t = e - r * ROW;
-    if (e < TOTAL) patch[r * PITCH + t] = v[k];
+    if (e < TOTAL) {
+      if constexpr (CODED) {
+        const bool ok = CL ? (r < py && t < px * C) : ((r / TR_P) < C && (r % TR_P) < py && t < px);
+        patch[r * PITCH + t] = ok ? lut_s[v[k]] : 0.f;  // cells outside the image stay 0, whatever code 0 means
+      } else {
+        patch[r * PITCH + t] = v[k];
+      }
+    }
   }
   __syncthreads();
   constexpr int XS = CL ? C : 1;  // element stride along x
@@ -113,13 +127,13 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
   }
 }
 
-template <int C, bool CL>
-void launch_transform_tiled(const float* in, int B, int H, int W, int O, float* out, hipStream_t s) {
+template <int C, bool CL, typename TIN = float>
+void launch_transform_tiled(const TIN* in, const float* lut, int B, int H, int W, int O, float* out, hipStream_t s) {
   constexpr int ROW = CL ? TR_P * C : TR_P;
   constexpr int NROWS = CL ? TR_P : TR_P * C;
   const int tiles = (O + TR_T - 1) / TR_T;
-  hipLaunchKernelGGL((transform_kernel<C, CL>), dim3(tiles, tiles, B), dim3(256), (size_t)(ROW + 1) * NROWS * sizeof(float),
-                     s, in, H, W, O, out);
+  const size_t lds = ((size_t)(ROW + 1) * NROWS + (sizeof(TIN) == 1 ? 256 : 0)) * sizeof(float);
+  hipLaunchKernelGGL((transform_kernel<C, CL, TIN>), dim3(tiles, tiles, B), dim3(256), lds, s, in, lut, H, W, O, out);
 }
 
 // generic fallback (any scale): one thread per output element
@@ -775,19 +789,32 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
   const float scale = out_hw > 1 ? (float)((H > W ? H : W) - 1) / (float)(out_hw - 1) : 0.f;
   const bool tiled = scale * (TR_T - 1) + 3.f <= (float)TR_P && C >= 1 && C <= 3;
   if (tiled && channels_last) {
-    if (C == 1) launch_transform_tiled<1, true>(in, B, H, W, out_hw, out, s);
-    if (C == 2) launch_transform_tiled<2, true>(in, B, H, W, out_hw, out, s);
-    if (C == 3) launch_transform_tiled<3, true>(in, B, H, W, out_hw, out, s);
+    if (C == 1) launch_transform_tiled<1, true>(in, nullptr, B, H, W, out_hw, out, s);
+    if (C == 2) launch_transform_tiled<2, true>(in, nullptr, B, H, W, out_hw, out, s);
+    if (C == 3) launch_transform_tiled<3, true>(in, nullptr, B, H, W, out_hw, out, s);
   } else if (tiled) {
-    if (C == 1) launch_transform_tiled<1, false>(in, B, H, W, out_hw, out, s);
-    if (C == 2) launch_transform_tiled<2, false>(in, B, H, W, out_hw, out, s);
-    if (C == 3) launch_transform_tiled<3, false>(in, B, H, W, out_hw, out, s);
+    if (C == 1) launch_transform_tiled<1, false>(in, nullptr, B, H, W, out_hw, out, s);
+    if (C == 2) launch_transform_tiled<2, false>(in, nullptr, B, H, W, out_hw, out, s);
+    if (C == 3) launch_transform_tiled<3, false>(in, nullptr, B, H, W, out_hw, out, s);
   } else {
     const int total = B * C * out_hw * out_hw;
     int grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(transform_generic_kernel, dim3(grid), dim3(256), 0, s, in, B, C, H, W, channels_last, out_hw, out);
   }
+  return hipGetLastError();
+}
+
+// coded BEV (uint8 indices into a 256-entry float table), channels-last, the tiled kernel's shapes only
+bool transform_coded_supported(int C, int H, int W, int out_hw) {
+  const float scale = out_hw > 1 ? (float)((H > W ? H : W) - 1) / (float)(out_hw - 1) : 0.f;
+  return scale * (TR_T - 1) + 3.f <= (float)TR_P && C >= 1 && C <= 3;
+}
+hipError_t launch_transform_coded(const uint8_t* in, const float* lut, int B, int C, int H, int W, int out_hw, float* out,
+                                  hipStream_t s) {
+  if (C == 1) launch_transform_tiled<1, true, uint8_t>(in, lut, B, H, W, out_hw, out, s);
+  if (C == 2) launch_transform_tiled<2, true, uint8_t>(in, lut, B, H, W, out_hw, out, s);
+  if (C == 3) launch_transform_tiled<3, true, uint8_t>(in, lut, B, H, W, out_hw, out, s);
   return hipGetLastError();
 }
 

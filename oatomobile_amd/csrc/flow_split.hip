@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     {
       const Prefix16 pre = load_prefix(pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, q);
       TK_START();
-      const PassOut po = pass_forward<MODE_FWD>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
+      const PassOut po = pass_forward<MODE_FWD, false, (WPB <= 4)>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
       TK_STOP(1);
       __builtin_amdgcn_wave_barrier();
       if (final_pass) break;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       const Prefix16 pre = load_prefix(pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, q);
       constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
       StepTape last[3];
-      const PassOut po = pass_forward<MODE_INV, REGTAPE>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
+      const PassOut po = pass_forward<MODE_INV, REGTAPE, (WPB <= 4)>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
       TK_STOP(4);
       const float qk = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
       if (TRACE && a.trace_post != nullptr && q == 0 && active)

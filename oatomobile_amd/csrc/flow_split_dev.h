@@ -94,6 +94,9 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
 #endif
 #define SPLIT_PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define SPLIT_PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#ifndef RIP_PIPE_VALU
+#define RIP_PIPE_VALU 5  // vector instructions scheduled behind each matrix instruction in the one-wave-per-SIMD build
+#endif
 #ifndef RIP_ABL
 #define RIP_ABL 0  // development only: 1 = no tape loads, 3 = no tape stores (wrong results)
 #endif
@@ -159,7 +162,7 @@ __device__ __forceinline__ void gru_gates(const f32x4& ar, const f32x4& az, cons
 // flow.h); H = the hidden state (H layout), `hs` = its split B operands — both are replaced by the new state's.
 // Per unit tile: 4 fp32 MFMAs (input / bias k-steps: y is unbounded, they stay exact) + 2 K blocks x 3 gates x 3 f16
 // MFMAs; head: 2 + 12 + 9.  84 f16 + 27 fp32 MFMAs = 2208 matrix-pipe cycles (flow_phase.hip: 251 x 32 = 8032).
-template <int SAVE>
+template <int SAVE, bool PIPE = false>
 __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit& hs, float yp0, float yp1, int q,
                                          unsigned lane, float4* __restrict__ tape, StepTape* tr, float (&o)[4]) {
   const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
@@ -168,55 +171,61 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
   const float4 wxr = as_f4(wl[48 * 64]), wxz = as_f4(wl[49 * 64]), wxg = as_f4(wl[50 * 64]), wxh = as_f4(wl[51 * 64]);
   const float wxra[4] = {wxr.x, wxr.y, wxr.z, wxr.w}, wxza[4] = {wxz.x, wxz.y, wxz.z, wxz.w};
   const float wxga[4] = {wxg.x, wxg.y, wxg.z, wxg.w}, wxha[4] = {wxh.x, wxh.y, wxh.z, wxh.w};
-  // operand rows of group (up, kb): rows ((g * 4 + up) * 2 + kb) * 2 + term, g = 0..2 — requested one group (9 MFMAs)
-  // ahead of their use
-  uint4 cur[6], nxt[6];
+  // operand rows of item (up, kb, g): hi row ((g * 4 + up) * 2 + kb) * 2, lo' row behind it.  An item is 3 MFMAs into
+  // three DIFFERENT accumulators (Whi xhi -> a, Whi xlo' -> l1, Wlo' xhi -> l2: no back-to-back dependency), its two
+  // rows are requested PF items (3 PF MFMAs) ahead of their use; head rows follow the last item.
+  constexpr int PF = 3, NIT = 24;
+  auto row_of = [](int it, int term) {  // it = (up * 2 + kb) * 3 + g
+    const int g = it % 3, kb = (it / 3) & 1, up = it / 6;
+    return (((g * 4 + up) * 2 + kb) * 2 + term) * 64;
+  };
+  uint4 rh[PF], rl[PF];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    cur[2 * g] = wl[(((g * 4 + 0) * 2 + 0) * 2 + 0) * 64];
-    cur[2 * g + 1] = wl[(((g * 4 + 0) * 2 + 0) * 2 + 1) * 64];
+  for (int e = 0; e < PF; ++e) {
+    rh[e] = wl[row_of(e, 0)];
+    rl[e] = wl[row_of(e, 1)];
   }
   float Hn[16];
-#pragma unroll
-  for (int up = 0; up < 4; ++up) {
-    f32x4 ar, az, agn, ahn, arl = zero4(), azl = zero4(), ahl = zero4();
+  // Accumulators of one unit tile: three gates x (Whi xhi | Whi xlo' | Wlo' xhi) + gi_n.
+  struct TileAcc {
+    f32x4 a[3], l1[3], l2[3], agn;
+  };
+  auto issue = [&](int up, TileAcc& t) __attribute__((always_inline)) {
     SPLIT_PRIO_BURST();
-    ar = mfma4(wxra[up], bin, zero4());
-    az = mfma4(wxza[up], bin, zero4());
-    agn = mfma4(wxga[up], bin, zero4());
-    ahn = mfma4(wxha[up], bin, zero4());
+    t.a[0] = mfma4(wxra[up], bin, zero4());
+    t.a[1] = mfma4(wxza[up], bin, zero4());
+    t.agn = mfma4(wxga[up], bin, zero4());
+    t.a[2] = mfma4(wxha[up], bin, zero4());
+#pragma unroll
+    for (int g = 0; g < 3; ++g) t.l1[g] = t.l2[g] = zero4();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const int ng = up * 2 + kb + 1;  // next group
-      if (ng < 8) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          nxt[2 * g] = wl[(((g * 4 + (ng >> 1)) * 2 + (ng & 1)) * 2 + 0) * 64];
-          nxt[2 * g + 1] = wl[(((g * 4 + (ng >> 1)) * 2 + (ng & 1)) * 2 + 1) * 64];
-        }
-      } else {  // the head's first rows (tile 0, kb 0 / 1: hi, lo')
-        nxt[0] = wl[(52 + 0) * 64], nxt[1] = wl[(52 + 1) * 64], nxt[2] = wl[(52 + 2) * 64], nxt[3] = wl[(52 + 3) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
       const h16x8 bh = hs.hi[kb], bl = hs.lo[kb];
-      ar = mfmah(as_h8(cur[0]), bh, ar);
-      az = mfmah(as_h8(cur[2]), bh, az);
-      ahn = mfmah(as_h8(cur[4]), bh, ahn);
-      arl = mfmah(as_h8(cur[0]), bl, arl);
-      azl = mfmah(as_h8(cur[2]), bl, azl);
-      ahl = mfmah(as_h8(cur[4]), bl, ahl);
-      arl = mfmah(as_h8(cur[1]), bh, arl);
-      azl = mfmah(as_h8(cur[3]), bh, azl);
-      ahl = mfmah(as_h8(cur[5]), bh, ahl);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) cur[i] = nxt[i];
+      for (int g = 0; g < 3; ++g) {
+        const int it = (up * 2 + kb) * 3 + g;
+        const uint4 wh = rh[it % PF], wo = rl[it % PF];
+        if (it + PF < NIT) {
+          rh[it % PF] = wl[row_of(it + PF, 0)];
+          rl[it % PF] = wl[row_of(it + PF, 1)];
+          if (!PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
+        t.a[g] = mfmah(as_h8(wh), bh, t.a[g]);
+        t.l1[g] = mfmah(as_h8(wh), bl, t.l1[g]);
+        t.l2[g] = mfmah(as_h8(wo), bh, t.l2[g]);
+      }
     }
     SPLIT_PRIO_VALU();
-    ar = ar + arl * LO_INV;
-    az = az + azl * LO_INV;
-    ahn = ahn + ahl * LO_INV;
+  };
+  auto finish = [&](int up, const TileAcc& t) __attribute__((always_inline)) {
+    const f32x4 ar = t.a[0] + (t.l1[0] + t.l2[0]) * LO_INV;
+    const f32x4 az = t.a[1] + (t.l1[1] + t.l2[1]) * LO_INV;
+    const f32x4 ahn = t.a[2] + (t.l1[2] + t.l2[2]) * LO_INV;
     float rr[4], zz[4], nn[4];
-    gru_gates(ar, az, agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
+    gru_gates(ar, az, t.agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
+    // pin the tile's gate math HERE: it has no side effect, and left alone it sinks below the MFMAs of ALL later tiles
+    // (to its first use), which keeps four tiles of accumulators alive (160 registers)
+    asm volatile("" : "+v"(Hn[up * 4]), "+v"(Hn[up * 4 + 1]), "+v"(Hn[up * 4 + 2]), "+v"(Hn[up * 4 + 3]));
     if (SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) {
       tape_st(trow(tape, up * 4 + 0, loff), rr[0], rr[1], rr[2], rr[3]);
       tape_st(trow(tape, up * 4 + 1, loff), zz[0], zz[1], zz[2], zz[3]);
@@ -233,6 +242,42 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
         tr->gh[up * 4 + r] = ahn[r];
       }
     }
+  };
+  if (PIPE) {
+    // one wave per SIMD: tile up+1's MFMAs are issued before tile up's gate math, so that the VALU work of a tile can run
+    // in the shadow of the next tile's matrix instructions (two tiles of accumulators live)
+    TileAcc t[2];
+    issue(0, t[0]);
+#pragma unroll
+    for (int up = 0; up < 4; ++up) {
+      if (up < 3) issue(up + 1, t[(up + 1) & 1]);
+      finish(up, t[up & 1]);
+      if (up < 3) {
+        // the region's schedule: behind every matrix instruction of tile up+1, RIP_PIPE_VALU vector instructions of tile
+        // up's gate math (and the operand reads of the tile after) — the VALU work issues while the matrix pipe runs
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // a DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, RIP_PIPE_VALU, 0);  // VALU
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, RIP_PIPE_VALU, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // two waves per SIMD (256 registers each): tile by tile — the partner wave's MFMAs cover this wave's gate math
+#pragma unroll
+    for (int up = 0; up < 4; ++up) {
+      TileAcc t;
+      issue(up, t);
+      finish(up, t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) H[i] = Hn[i];
@@ -241,25 +286,24 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
   const float bone = q == 2 ? 1.f : 0.f;
   const float4 t60 = as_f4(wl[60 * 64]), t61 = as_f4(wl[61 * 64]), t62 = as_f4(wl[62 * 64]);
   SPLIT_PRIO_BURST();
-  f32x4 a0 = mfma4(t60.x, bone, zero4()), a1 = mfma4(t60.y, bone, zero4()), a0l = zero4(), a1l = zero4();
+  f32x4 a0 = mfma4(t60.x, bone, zero4()), a1 = mfma4(t60.y, bone, zero4());
   {
-    const uint4 w4 = wl[(52 + 4) * 64], w5 = wl[(52 + 5) * 64], w6 = wl[(52 + 6) * 64], w7 = wl[(52 + 7) * 64];
-    // cur[0..3] = tile 0: (kb 0 hi, kb 0 lo', kb 1 hi, kb 1 lo'); w4..w7 = tile 1
-    a0 = mfmah(as_h8(cur[0]), hs.hi[0], a0);
-    a1 = mfmah(as_h8(w4), hs.hi[0], a1);
-    a0l = mfmah(as_h8(cur[0]), hs.lo[0], a0l);
-    a1l = mfmah(as_h8(w4), hs.lo[0], a1l);
-    a0l = mfmah(as_h8(cur[1]), hs.hi[0], a0l);
-    a1l = mfmah(as_h8(w5), hs.hi[0], a1l);
-    a0 = mfmah(as_h8(cur[2]), hs.hi[1], a0);
-    a1 = mfmah(as_h8(w6), hs.hi[1], a1);
-    a0l = mfmah(as_h8(cur[2]), hs.lo[1], a0l);
-    a1l = mfmah(as_h8(w6), hs.lo[1], a1l);
-    a0l = mfmah(as_h8(cur[3]), hs.hi[1], a0l);
-    a1l = mfmah(as_h8(w7), hs.hi[1], a1l);
+    // rows 52 + (mt * 2 + kb) * 2 + term; 12 MFMAs into six accumulators
+    f32x4 a0l = zero4(), a1l = zero4(), a0m = zero4(), a1m = zero4();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const uint4 w0h = wl[(52 + kb * 2) * 64], w0l = wl[(53 + kb * 2) * 64];
+      const uint4 w1h = wl[(56 + kb * 2) * 64], w1l = wl[(57 + kb * 2) * 64];
+      a0 = mfmah(as_h8(w0h), hs.hi[kb], a0);
+      a1 = mfmah(as_h8(w1h), hs.hi[kb], a1);
+      a0l = mfmah(as_h8(w0h), hs.lo[kb], a0l);
+      a1l = mfmah(as_h8(w1h), hs.lo[kb], a1l);
+      a0m = mfmah(as_h8(w0l), hs.hi[kb], a0m);
+      a1m = mfmah(as_h8(w1l), hs.hi[kb], a1m);
+    }
+    a0 = a0 + (a0l + a0m) * LO_INV;
+    a1 = a1 + (a1l + a1m) * LO_INV;
   }
-  a0 = a0 + a0l * LO_INV;
-  a1 = a1 + a1l * LO_INV;
   if (SAVE != SAVE_NONE) {
     unsigned m = 0;
 #pragma unroll
@@ -313,7 +357,7 @@ struct PassOut {
 // forward (x -> y, in place in `io`) or inverse (reads y from `io`) pass of the current model for this wave's 16
 // candidates (flow_phase.hip:pass_forward with the split-f16 step).  MODE_FWD tapes all three heavy steps, MODE_INV
 // tapes steps 1, 2 and hands step 3 over in registers (`last[2]`); REGTAPE: all three in registers.
-template <int MODE, bool REGTAPE = false>
+template <int MODE, bool REGTAPE = false, bool PIPE = false>
 __device__ __forceinline__ PassOut pass_forward(const uint4* wl, const Prefix16& pre, float (*io)[8], float (*st)[6][CB],
                                                 float4* __restrict__ tape, StepTape* last, int c, int q, unsigned lane) {
   PassOut po;
@@ -392,9 +436,9 @@ __device__ __forceinline__ PassOut pass_forward(const uint4* wl, const Prefix16&
     int zero = 0;
     asm volatile("" : "+v"(zero));
     if (REGTAPE)
-      fwd_step<SAVE_REGS>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[0], o);
+      fwd_step<SAVE_REGS, PIPE>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[0], o);
     else
-      fwd_step<SAVE_TAPE_NOHP>(wl + zero, H, hs, yp0, yp1, q, lane, tape, nullptr, o);
+      fwd_step<SAVE_TAPE_NOHP, PIPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape, nullptr, o);
     coupling(1, o);
   }
   {
@@ -402,9 +446,9 @@ __device__ __forceinline__ PassOut pass_forward(const uint4* wl, const Prefix16&
     int zero = 0;
     asm volatile("" : "+v"(zero));
     if (REGTAPE)
-      fwd_step<SAVE_REGS>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[1], o);
+      fwd_step<SAVE_REGS, PIPE>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[1], o);
     else
-      fwd_step<SAVE_TAPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape + TAPE_STEP_F4, nullptr, o);
+      fwd_step<SAVE_TAPE, PIPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape + TAPE_STEP_F4, nullptr, o);
     coupling(2, o);
   }
   {
@@ -412,9 +456,9 @@ __device__ __forceinline__ PassOut pass_forward(const uint4* wl, const Prefix16&
     int zero = 0;
     asm volatile("" : "+v"(zero));
     if (MODE == MODE_FWD)
-      fwd_step<SAVE_TAPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape + 2 * TAPE_STEP_F4, nullptr, o);
+      fwd_step<SAVE_TAPE, PIPE>(wl + zero, H, hs, yp0, yp1, q, lane, tape + 2 * TAPE_STEP_F4, nullptr, o);
     else
-      fwd_step<SAVE_REGS>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[2], o);
+      fwd_step<SAVE_REGS, PIPE>(wl + zero, H, hs, yp0, yp1, q, lane, nullptr, &last[2], o);
     coupling(3, o);
   }
   return po;
@@ -527,61 +571,64 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     h16x8 ah, al;
     split8<true>(da1r, sa, ah, al);
     SPLIT_PRIO_BURST();
-    f32x4 a[4], l[4];
-    uint4 wh[4], wo[4];
+    f32x4 a[4], l1[4], l2[4];
 #pragma unroll
     for (int ut = 0; ut < 4; ++ut) {
-      wh[ut] = tw[(1 + ut * 2) * 64];
-      wo[ut] = tw[(2 + ut * 2) * 64];
+      const uint4 wh = tw[(1 + ut * 2) * 64], wo = tw[(2 + ut * 2) * 64];
+      a[ut] = mfmah(as_h8(wh), ah, zero4());
+      l1[ut] = mfmah(as_h8(wh), al, zero4());
+      l2[ut] = mfmah(as_h8(wo), ah, zero4());
     }
-#pragma unroll
-    for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(wh[ut]), ah, zero4());
-#pragma unroll
-    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(wh[ut]), al, zero4());
-#pragma unroll
-    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(wo[ut]), ah, l[ut]);
     SPLIT_PRIO_VALU();
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + l[ut] * LO_INV) * ia;
+    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + (l1[ut] + l2[ut]) * LO_INV) * ia;
   }
   // ---- part 2: W_hh^T (dpr, dpz, dgh_n)_{t+1}: 6 K blocks x 4 unit tiles, rows 9 + (kb * 4 + ut) * 2 + term ----
   if (!FIRST) {
-    f32x4 a[4] = {zero4(), zero4(), zero4(), zero4()}, l[4] = {zero4(), zero4(), zero4(), zero4()};
-    SPLIT_PRIO_BURST();
-    uint4 ch[4], cl[4], nh[4], nl[4];
+    // dh'_{t+1} z_{t+1} joins here, before the big contraction, so that its 16 registers are free during it
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) {
-      ch[ut] = tw[(9 + ut * 2) * 64];
-      cl[ut] = tw[(10 + ut * 2) * 64];
+    for (int i = 0; i < 16; ++i) dh[i >> 2][i & 3] += dhz[i];
+    // item (half, kb, u): unit tile ut = 2 half + u, hi row 9 + (kb * 4 + ut) * 2, lo' row behind it; 3 MFMAs into three
+    // different accumulators; two unit tiles at a time (24 accumulator registers instead of 48); rows requested PF
+    // items ahead
+    constexpr int PF = 3, NIT = 24;
+    auto row_of = [](int it, int term) {
+      const int u = it & 1, kb = (it >> 1) % 6, half = it / 12;
+      return (9 + (kb * 4 + 2 * half + u) * 2 + term) * 64;
+    };
+    const float ig = gs.inv;
+    uint4 rh[PF], rl[PF];
+    SPLIT_PRIO_BURST();
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+      rh[e] = tw[row_of(e, 0)];
+      rl[e] = tw[row_of(e, 1)];
     }
 #pragma unroll
-    for (int kb = 0; kb < 6; ++kb) {
-      if (kb < 5) {
+    for (int half = 0; half < 2; ++half) {
+      f32x4 a[2] = {zero4(), zero4()}, l1[2] = {zero4(), zero4()}, l2[2] = {zero4(), zero4()};
 #pragma unroll
-        for (int ut = 0; ut < 4; ++ut) {
-          nh[ut] = tw[(9 + ((kb + 1) * 4 + ut) * 2) * 64];
-          nl[ut] = tw[(10 + ((kb + 1) * 4 + ut) * 2) * 64];
+      for (int kb = 0; kb < 6; ++kb) {
+        const h16x8 bh = kb < 4 ? gs.rz_hi[kb < 4 ? kb : 0] : gs.gn_hi[kb < 4 ? 0 : kb - 4];
+        const h16x8 bl = kb < 4 ? gs.rz_lo[kb < 4 ? kb : 0] : gs.gn_lo[kb < 4 ? 0 : kb - 4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int it = (half * 6 + kb) * 2 + u;
+          const uint4 wh = rh[it % PF], wo = rl[it % PF];
+          if (it + PF < NIT) {
+            rh[it % PF] = tw[row_of(it + PF, 0)];
+            rl[it % PF] = tw[row_of(it + PF, 1)];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          a[u] = mfmah(as_h8(wh), bh, a[u]);
+          l1[u] = mfmah(as_h8(wh), bl, l1[u]);
+          l2[u] = mfmah(as_h8(wo), bh, l2[u]);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      const h16x8 bh = kb < 4 ? gs.rz_hi[kb < 4 ? kb : 0] : gs.gn_hi[kb < 4 ? 0 : kb - 4];
-      const h16x8 bl = kb < 4 ? gs.rz_lo[kb < 4 ? kb : 0] : gs.gn_lo[kb < 4 ? 0 : kb - 4];
 #pragma unroll
-      for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(ch[ut]), bh, a[ut]);
-#pragma unroll
-      for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(ch[ut]), bl, l[ut]);
-#pragma unroll
-      for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(cl[ut]), bh, l[ut]);
-#pragma unroll
-      for (int ut = 0; ut < 4; ++ut) {
-        ch[ut] = nh[ut];
-        cl[ut] = nl[ut];
-      }
+      for (int u = 0; u < 2; ++u) dh[2 * half + u] = dh[2 * half + u] + (a[u] + (l1[u] + l2[u]) * LO_INV) * ig;
     }
     SPLIT_PRIO_VALU();
-    const float ig = gs.inv;
-#pragma unroll
-    for (int ut = 0; ut < 4; ++ut) dh[ut] = dh[ut] + (a[ut] + l[ut] * LO_INV) * ig;
   }
   // ---- n of this step: tanh(gi_n + r gh_n), gi_n = the (W_in[.][0], W_in[.][1], b_in, 0) k-step on y_{t-1} ----
   float nrec[16];
@@ -617,8 +664,7 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     const f32x2 hp2 = {tv->hp[i], tv->hp[i + 1]}, rr2 = {tv->r[i], tv->r[i + 1]}, zz2 = {tv->z[i], tv->z[i + 1]};
     const f32x2 nn2 = {FROM_REGS ? tv->n[i] : nrec[i], FROM_REGS ? tv->n[i + 1] : nrec[i + 1]}, gh2 = {tv->gh[i], tv->gh[i + 1]};
     const f32x2 one = {1.0f, 1.0f};
-    f32x2 d = {dh[i >> 2][i & 3], dh[i >> 2][(i & 3) + 1]};
-    if (!FIRST) d = d + f32x2{dhz[i], dhz[i + 1]};
+    const f32x2 d = {dh[i >> 2][i & 3], dh[i >> 2][(i & 3) + 1]};  // (dh'_{t+1} z_{t+1} already added)
     const f32x2 dn = d * (one - zz2);
     const f32x2 dzg = d * (hp2 - nn2);
     const f32x2 dhzn = d * zz2;

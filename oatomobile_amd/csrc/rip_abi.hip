@@ -291,6 +291,22 @@ int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, int
   return rip_encode(h, h->visual, vec_dev, B, k_begin, k_count, enc_dtype, z_dev, nullptr, stream);
 }
 
+int rip_encode_raw_u8(rip_handle* h, const uint8_t* codes_dev, const float* lut_dev, int H, int W, const float* vec_dev,
+                      int B, int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream) {
+  int rc = check_models(h, k_begin, k_count);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(codes_dev != nullptr && lut_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
+  REQUIRE(H >= 1 && W >= 1, "bad BEV size H=%d W=%d", H, W);
+  REQUIRE(transform_coded_supported(h->C, H, W, 100), "coded BEV: C=%d H=%d W=%d not supported (C <= 3, down-sampling by <= 2)",
+          h->C, H, W);
+  {
+    ENTER(h, stream);
+    HIP_TRY(launch_transform_coded(codes_dev, lut_dev, B, h->C, H, W, 100, h->visual, (hipStream_t)stream));
+  }
+  return rip_encode(h, h->visual, vec_dev, B, k_begin, k_count, enc_dtype, z_dev, nullptr, stream);
+}
+
 int rip_flow_forward(rip_handle* h, int k, const float* x_dev, const float* z_dev, int N, int z_rows, float* y_dev,
                      float* logabsdet_dev, rip_stream_t stream) {
   int rc = check_models(h, k, 1);

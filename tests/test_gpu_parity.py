@@ -1451,3 +1451,40 @@ def test_train_clip_is_applied_after_the_reduction(dev):
   l1 = float(tr.train_step(batch_of(1)))
   assert np.isfinite(l1) and torch.isfinite(tr.params).all()
   tr.close()
+
+
+def test_packed_cache_replay_bit_identical(dev, tmp_path):
+  """SURVEY §8f N1 / BASELINE configs[4]: the packed replay cache (uint8 codes + a 256-entry float table, expanded inside
+  the transform kernel: `rip_encode_raw_u8`) against the `.npz` replay of the same datums — z, [4,2] plans and the
+  [30,3] float64 plans are BIT-identical, for batches that do and do not divide the file count."""
+  from oatomobile_amd import RIPAgent, _lib, replay
+  models = [hip_model(100 + k, dev) for k in range(3)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=32, max_batch=16, seed=4, encoder_dtype="bf16")
+  ep = replay.Episode(str(tmp_path), "ep")
+  rng = np.random.default_rng(5)
+  for i in range(37):
+    o = synth_observation(np.random.default_rng(2200 + i))
+    fut = np.cumsum(np.abs(rng.normal(size=(80, 3))) * 0.4, axis=0).astype(np.float32)
+    ep.append("f%02d" % i, lidar=o["lidar"], velocity=o["velocity"], is_at_traffic_light=o["is_at_traffic_light"],
+              traffic_light_state=o["traffic_light_state"], player_future=fut)
+  files = ep.files()
+  cache = replay.pack_cache(files, str(tmp_path / "cache"))
+  ref4 = replay.replay(agent, files, batch_size=16)
+  ref30 = replay.replay(agent, files, batch_size=16, interpolate=True)
+  for bs in (16, 5):
+    np.testing.assert_array_equal(replay.replay_cache(agent, cache, bs), ref4)
+  np.testing.assert_array_equal(replay.replay_cache(agent, cache, 16, interpolate=True), ref30)
+  np.testing.assert_array_equal(replay.replay_cache(agent, cache, 16, begin=10, end=29), ref4[10:29])  # a rank's share
+  # the encoder output itself, coded vs float32 BEV (fp32 encoder)
+  lib, h = _lib.load(), agent._handle.raw
+  codes = torch.from_numpy(np.asarray(cache.codes[:8])).to(dev)
+  lut = torch.from_numpy(cache.lut).to(dev)
+  lidar = torch.from_numpy(cache.lut[np.asarray(cache.codes[:8])]).to(dev)
+  vec = torch.from_numpy(cache.vec[:8].copy()).to(dev)
+  za, zb = torch.empty(3, 8, 64, device=dev), torch.empty(3, 8, 64, device=dev)
+  _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, 200, 200, _lib.ptr(vec), 8, 0, 3, 0, _lib.ptr(za), agent._handle.stream()))
+  _lib.check(lib.rip_encode_raw_u8(h, _lib.ptr(codes, torch.uint8), _lib.ptr(lut), 200, 200, _lib.ptr(vec), 8, 0, 3, 0, _lib.ptr(zb),
+                                   agent._handle.stream()))
+  assert torch.equal(za, zb)
+  with pytest.raises(ValueError):
+    agent.plan_batch_coded(codes.float(), lut, vec, torch.zeros(8, 10, 2, device=dev))

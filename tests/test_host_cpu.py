@@ -63,7 +63,7 @@ def test_library_exports_every_declared_symbol():
   """include/rip_hip.h <-> librip_hip.so <-> _lib.SIGNATURES agree (no compute calls: no GPU here)."""
   from oatomobile_amd import _lib
   header = open(os.path.join(ROOT, "include", "rip_hip.h")).read()
-  declared = set(re.findall(r"\b(rip_[a-z_]+)\s*\(", header))
+  declared = set(re.findall(r"\b(rip_[a-z0-9_]+)\s*\(", header))
   lib = _lib.load()
   bound = {name for name, _, _ in _lib.SIGNATURES}
   assert declared == bound, declared ^ bound
@@ -349,3 +349,40 @@ def test_effective_cpus_is_positive_and_bounded():
   from oatomobile_amd import replay
   n = replay.effective_cpus()
   assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_packed_replay_cache_round_trip(tmp_path):
+  """`replay.pack_cache`: `lut[codes]` reproduces `load_datum(...)["lidar"]` bit for bit, goals / vectors as the
+  `.npz` replay derives them, a value that first appears in a LATER chunk re-codes the rows packed before it, and data
+  with more than 256 distinct values is refused (the `.npz` files stay the source of truth)."""
+  from oatomobile_amd import replay
+  from tests.helpers import synth_observation
+  ep = replay.Episode(str(tmp_path), "ep")
+  rng = np.random.default_rng(0)
+  for i in range(7):
+    o = synth_observation(np.random.default_rng(100 + i))
+    lidar = o["lidar"].copy()
+    if i < 3:
+      lidar[lidar > 0.9] = 0.8  # the level 1.0 first appears in the second chunk
+    fut = np.cumsum(np.abs(rng.normal(size=(80, 3))), axis=0).astype(np.float32)
+    ep.append("t%d" % i, lidar=lidar, velocity=o["velocity"], is_at_traffic_light=o["is_at_traffic_light"],
+              traffic_light_state=o["traffic_light_state"], player_future=fut)
+  files = ep.files()
+  cache = replay.pack_cache(files, str(tmp_path / "cache"), chunk=3)
+  assert len(cache) == 7 and cache.channels == 2 and cache.codes.dtype == np.uint8
+  assert np.isnan(cache.lut[6:]).all() and np.array_equal(cache.lut[:6], np.float32(np.arange(6) / 5.0))
+  for i, f in enumerate(files):
+    d = replay.load_datum(f)
+    np.testing.assert_array_equal(cache.lidar(i), d["lidar"])
+    np.testing.assert_array_equal(cache.goal[i], replay.goal_from_future(d["player_future"]))
+    np.testing.assert_array_equal(cache.vec[i, :3], d["velocity"].reshape(3))
+  got = [(c.shape[0], tuple(v.shape), tuple(g.shape)) for c, v, g in cache.batches(4)]
+  assert got == [(4, (4, 5), (4, 10, 2)), (3, (3, 5), (3, 10, 2))]
+  reopened = replay.PackedCache(str(tmp_path / "cache"))
+  np.testing.assert_array_equal(np.asarray(reopened.codes), np.asarray(cache.codes))
+  ep2 = replay.Episode(str(tmp_path), "noisy")
+  ep2.append("n0", lidar=rng.random((200, 200, 2)).astype(np.float32), velocity=np.zeros(3, np.float32),
+             is_at_traffic_light=np.zeros(1, np.float32), traffic_light_state=np.zeros(1, np.float32),
+             player_future=np.zeros((80, 3), np.float32))
+  with pytest.raises(ValueError, match="256 distinct"):
+    replay.pack_cache(ep2.files(), str(tmp_path / "cache2"))

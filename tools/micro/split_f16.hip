@@ -120,7 +120,7 @@ __global__ void denorm_kernel(float* out, float bval) {
 }
 
 // ---- throughput ----
-template <bool SPLIT, int WAVES>
+template <bool SPLIT, int WAVES, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void bench_kernel(const uint4* w, float* out, long long* cyc, int steps) {
   extern __shared__ uint4 fbuf[];
   for (int i = threadIdx.x; i < 63 * 64; i += WAVES * 64) fbuf[i] = w[i];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WAVES * 64) void bench_kernel(const uint4* w, float
     int zero = 0;
     asm volatile("" : "+v"(zero));
     if (SPLIT)
-      split::fwd_step<split::SAVE_NONE>(fbuf + lane + zero, H, hs, yp0, yp1, q, (unsigned)lane, nullptr, nullptr, o);
+      split::fwd_step<split::SAVE_NONE, PIPE>(fbuf + lane + zero, H, hs, yp0, yp1, q, (unsigned)lane, nullptr, nullptr, o);
     else
       step_f32(reinterpret_cast<const float4*>(fbuf) + lane + zero, H, yp0, yp1, q, o);
     const float s0 = __logf(1.0f + __expf(o[2])) + 1e-3f, s1 = __logf(1.0f + __expf(o[3])) + 1e-3f;
@@ -152,16 +152,16 @@ __global__ __launch_bounds__(WAVES * 64) void bench_kernel(const uint4* w, float
   if (lane == 0) cyc[blockIdx.x * WAVES + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <bool SPLIT, int WAVES>
+template <bool SPLIT, int WAVES, bool PIPE = false>
 void run(const uint4* w, float* out, long long* cyc, const char* name) {
   const int steps = 300, blocks = 256;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel<SPLIT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel<SPLIT, WAVES, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((bench_kernel<SPLIT, WAVES>), dim3(blocks), dim3(WAVES * 64), 150 * 1024, 0, w, out, cyc, steps);
+  hipLaunchKernelGGL((bench_kernel<SPLIT, WAVES, PIPE>), dim3(blocks), dim3(WAVES * 64), 150 * 1024, 0, w, out, cyc, steps);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((bench_kernel<SPLIT, WAVES>), dim3(blocks), dim3(WAVES * 64), 150 * 1024, 0, w, out, cyc, steps);
+  hipLaunchKernelGGL((bench_kernel<SPLIT, WAVES, PIPE>), dim3(blocks), dim3(WAVES * 64), 150 * 1024, 0, w, out, cyc, steps);
   hipEventRecord(e1, 0);
   hipDeviceSynchronize();
   float ms = 0.f;
@@ -310,6 +310,8 @@ int main() {
   run<false, 4>(w32, out, cyc, "fp32 MFMA step, 1 wave per SIMD");
   run<false, 8>(w32, out, cyc, "fp32 MFMA step, 2 waves per SIMD");
   run<true, 4>(w16, out, cyc, "split-f16 step, 1 wave per SIMD");
+  run<true, 4, true>(w16, out, cyc, "split-f16 step, 1 wave per SIMD, pipelined tiles");
+  run<true, 8, true>(w16, out, cyc, "split-f16 step, 2 waves per SIMD, pipelined tiles");
   run<true, 8>(w16, out, cyc, "split-f16 step, 2 waves per SIMD");
   run<true, 12>(w16, out, cyc, "split-f16 step, 3 waves per SIMD");
   run<true, 16>(w16, out, cyc, "split-f16 step, 4 waves per SIMD");
