@@ -27,10 +27,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int WPB_MAX = 8;
+constexpr int PARK_F4 = 3 * 64;  // per 16-candidate block: the Adam state of the 8-wave build between its uses
 constexpr int F_ROWS = MHF_ROWS;
 constexpr int T_ROWS = MHT_ROWS;
 #ifndef RIP_REGTAPE
 #define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
+#endif
+#ifndef RIP_SPLIT_PIPE
+#define RIP_SPLIT_PIPE 0  // 1 = 4- / 2-wave workgroups issue tile up+1's MFMAs ahead of tile up's gate math (measured: 2.82 vs 2.75 ms)
 #endif
 
 template <int WPB>
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(64) void split_prefix_kernel(SearchArgs a, const ui
 template <bool TRACE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, const uint32_t* __restrict__ mh_all,
                                                                 const float* __restrict__ pre_all,
-                                                                float4* __restrict__ tape_all) {
+                                                                float4* __restrict__ tape_all, float4* __restrict__ park_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   PShared<WPB>& sh = *reinterpret_cast<PShared<WPB>*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +141,8 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
   // wave-uniform tape bases (scalar registers): lanes add their own 16-byte column at each access
   float4* tapeF = tape_all + ((size_t)item * 2 + (RIP_ABL == 4 ? 1 : 0)) * TAPE_SLOT_F4;  // ABL 4: aliased tapes
   float4* tapeI = tape_all + ((size_t)item * 2 + 1) * TAPE_SLOT_F4;
+  constexpr bool PARK = WPB == 8;
+  float4* park = park_all + (size_t)item * PARK_F4;  // PARK: 3 lane-major rows per block
 
   // Adam state: lane (c, q) owns latent coordinates 2q, 2q+1 of candidate c
   float xv0 = a.x0[row * 8 + 2 * q], xv1 = a.x0[row * 8 + 2 * q + 1];
@@ -157,16 +163,24 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     // ================= F_0: x -> y (F-buf = model 0) =================
     io[c][2 * q] = final_pass ? xb0 : xv0;
     io[c][2 * q + 1] = final_pass ? xb1 : xv1;
+    if (PARK) {
+      // two waves per SIMD have 256 registers each and the passes need all of them: the Adam state (used once per step,
+      // at its end) waits in global memory instead of being spilled piecemeal around the hot loops
+      volatile f32x4* ps = reinterpret_cast<volatile f32x4*>(park) + lane;
+      ps[0] = f32x4{xv0, xv1, am0, am1};
+      ps[64] = f32x4{av0, av1, xb0, xb1};
+      ps[128] = f32x4{lbest, 0.f, 0.f, 0.f};
+    }
     TK_START();
     __syncthreads();  // F-buf (and, at step 0, T-buf) landed; io visible within the wave
     TK_STOP(0);
     float q_sel, gl = 0.f, gg0 = 0.f, gg1 = 0.f, w0;
     int ksel = 0;
-    float gsel[8];
+    float gsa = 0.f, gsb = 0.f;  // sum_k w_k dq_k/dy, coordinates 2q and 2q+1 of this lane's candidate
     {
       const Prefix16 pre = load_prefix(pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, q);
       TK_START();
-      const PassOut po = pass_forward<MODE_FWD, false, (WPB <= 4)>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
+      const PassOut po = pass_forward<MODE_FWD, false, (WPB <= 4 && RIP_SPLIT_PIPE)>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
       TK_STOP(1);
       __builtin_amdgcn_wave_barrier();
       if (final_pass) break;
@@ -175,8 +189,6 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       if (TRACE && a.trace_post != nullptr && q == 0 && active)
         a.trace_post[(((size_t)step * K + 0) * a.B + b) * a.N + n0 + c] = q_sel + gl;
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gsel[i] = 0.f;
     float q_sum = q_sel;
     // ================= models 1..K-1: inverse, adjoint, streaming aggregation =================
 #pragma unroll 1
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       const Prefix16 pre = load_prefix(pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, q);
       constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
       StepTape last[3];
-      const PassOut po = pass_forward<MODE_INV, REGTAPE, (WPB <= 4)>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
+      const PassOut po = pass_forward<MODE_INV, REGTAPE, (WPB <= 4 && RIP_SPLIT_PIPE)>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
       TK_STOP(4);
       const float qk = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
       if (TRACE && a.trace_post != nullptr && q == 0 && active)
@@ -208,15 +220,17 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
         __builtin_amdgcn_wave_barrier();
         float res[8];
         TK_START();
-        pass_backward<MODE_INV, REGTAPE>(tw, wq4, wl, io, nullptr, stI, tapeI, last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
+        pass_backward<MODE_INV, REGTAPE, (WPB <= 4)>(tw, wq4, wl, io, nullptr, stI, tapeI, last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
                                 res, 0.f);
         TK_STOP(5);
+        const float ra = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
+        const float rb = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
         if (mean_mode) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) gsel[i] += inv_k * res[i];
+          gsa += inv_k * ra;
+          gsb += inv_k * rb;
         } else if (take) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) gsel[i] = res[i];
+          gsa = ra;
+          gsb = rb;
         }
       }
       if (!mean_mode && take) {
@@ -238,8 +252,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     }
     // dLoss/dy = -(sum_k w_k dq_k/dy + d gl/dy_T): lane (c, q) fills coordinates 2q, 2q+1
     {
-      float ga = q == 0 ? gsel[0] : q == 1 ? gsel[2] : q == 2 ? gsel[4] : gsel[6];
-      float gb = q == 0 ? gsel[1] : q == 1 ? gsel[3] : q == 2 ? gsel[5] : gsel[7];
+      float ga = gsa, gb = gsb;
       if (q == 3) {
         ga += gg0;
         gb += gg1;
@@ -253,11 +266,18 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     __builtin_amdgcn_wave_barrier();
     float res[8];
     TK_START();
-    pass_backward<MODE_FWD>(tw, wq4, wl, io, gy, stF, tapeF, nullptr, pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, c, q, res, w0);
+    pass_backward<MODE_FWD, false, (WPB <= 4)>(tw, wq4, wl, io, gy, stF, tapeF, nullptr, pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, c, q, res, w0);
     TK_STOP(8);
     const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
     const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
     // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
+    if (PARK) {
+      const volatile f32x4* ps = reinterpret_cast<const volatile f32x4*>(park) + lane;
+      const f32x4 s0 = ps[0], s1 = ps[64], s2 = ps[128];
+      xv0 = s0.x, xv1 = s0.y, am0 = s0.z, am1 = s0.w;
+      av0 = s1.x, av1 = s1.y, xb0 = s1.z, xb1 = s1.w;
+      lbest = s2.x;
+    }
     b1p *= 0.9;
     b2p *= 0.999;
     const float step_size = (float)((double)a.lr / (1.0 - b1p));
@@ -320,21 +340,21 @@ size_t search_split_scratch_bytes(int B, int N, int K) {
   if (N < CB) return 0;
   const size_t pre = ((size_t)K * B * PRE_FLOATS * sizeof(float) + 255) / 256 * 256;
   const size_t items = ((size_t)B * (N / CB) + WPB_MAX - 1) / WPB_MAX * WPB_MAX;
-  return pre + items * 2 * TAPE_SLOT_F4 * sizeof(float4);
+  return pre + items * (2 * TAPE_SLOT_F4 + PARK_F4) * sizeof(float4);
 }
 
 namespace {
 template <int WPB>
-hipError_t launch_split_wpb(const SearchArgs& a, const uint32_t* mh_all, const float* pre, float4* tape, int items, hipStream_t s) {
+hipError_t launch_split_wpb(const SearchArgs& a, const uint32_t* mh_all, const float* pre, float4* tape, float4* park, int items, hipStream_t s) {
   hipError_t e = allow_lds(reinterpret_cast<const void*>(search_split_kernel<false, WPB>));
   if (e != hipSuccess) return e;
   e = allow_lds(reinterpret_cast<const void*>(search_split_kernel<true, WPB>));
   if (e != hipSuccess) return e;
   const dim3 grid((items + WPB - 1) / WPB);
   if (wants_trace(a))
-    hipLaunchKernelGGL((search_split_kernel<true, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape);
+    hipLaunchKernelGGL((search_split_kernel<true, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape, park);
   else
-    hipLaunchKernelGGL((search_split_kernel<false, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape);
+    hipLaunchKernelGGL((search_split_kernel<false, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape, park);
   return hipGetLastError();
 }
 }  // namespace
@@ -342,8 +362,9 @@ hipError_t launch_split_wpb(const SearchArgs& a, const uint32_t* mh_all, const f
 // waves per workgroup of a launch over `items` 16-candidate blocks.  Cost model from the measurements (B = 512, K = 4,
 // N = 128, 10 Adam steps): the 4-wave workgroup (one wave per SIMD, the whole register file, the inverse passes' tape in
 // registers) takes 0.69 ms, the 2-wave one about as long for half the blocks (5.28 vs 2.75 ms per launch), and the
-// 8-wave build — whose two waves per SIMD get 256 registers each and spill ~320 of them — 2.16 ms (4.33 ms per
-// launch): 3.1x, so it only wins when it saves rounds.  A launch is ceil(workgroups / CUs) rounds of that.
+// 8-wave build — two waves per SIMD with 256 registers each: late tape loads, the Adam state parked in global memory,
+// every inverse step but the last on the global tape (3x the tape bytes) — 1.53 ms (3.06 ms per launch): 2.2x, so it
+// only wins when it saves rounds.  A launch is ceil(workgroups / CUs) rounds of that.
 // development: RIP_SPLIT_WPB=8|4|2 in the environment pins the shape (A/B on full launches, one process each).
 static int split_pick_wpb(int items) {
   static const int forced = [] {
@@ -353,7 +374,7 @@ static int split_pick_wpb(int items) {
   if (forced == 8 || forced == 4 || forced == 2) return forced;
   const int cus = device_cu_count();
   auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
-  const double c8 = 3.1 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
+  const double c8 = 2.2 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
   if (c8 <= c4 && c8 <= c2) return 8;
   return c4 <= c2 ? 4 : 2;
 }
@@ -380,10 +401,12 @@ hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void
   float4* tape = reinterpret_cast<float4*>(reinterpret_cast<char*>(scratch) + pre_bytes);
   hipLaunchKernelGGL(split_prefix_kernel, dim3(a.B, a.K), dim3(64), 0, s, a, mh_all, pre);
   const int items = a.B * (a.N / CB);
+  const size_t items_pad = ((size_t)items + WPB_MAX - 1) / WPB_MAX * WPB_MAX;
+  float4* park = tape + items_pad * 2 * TAPE_SLOT_F4;
   switch (split_pick_wpb(items)) {
-    case 8: return launch_split_wpb<8>(a, mh_all, pre, tape, items, s);
-    case 4: return launch_split_wpb<4>(a, mh_all, pre, tape, items, s);
-    default: return launch_split_wpb<2>(a, mh_all, pre, tape, items, s);
+    case 8: return launch_split_wpb<8>(a, mh_all, pre, tape, park, items, s);
+    case 4: return launch_split_wpb<4>(a, mh_all, pre, tape, park, items, s);
+    default: return launch_split_wpb<2>(a, mh_all, pre, tape, park, items, s);
   }
 }
 

@@ -488,7 +488,7 @@ __device__ __forceinline__ float amax8(const float* v, float m) {
 // tw: this lane's column of the transposed rows; wtab: this lane's entry (q * 2 + (c & 1)) of the W_ih^T table, one
 // group of 8 entries per (kb, term); wl: the forward rows (gi_n's k-step).  LASTSTEP (t = 1): nothing consumes the
 // gate gradients as W_hh^T operands any more.
-template <int MODE, int TS, bool FROM_REGS>
+template <int MODE, int TS, bool FROM_REGS, bool TAPE_EARLY = true>
 __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_in, const uint4* wl_in, const float (*io)[8],
                                          const float (*gin)[8], const float (*st)[6][CB], const float4* __restrict__ tp,
                                          const StepTape* tr, const float* hp1, int c, int q, float w0, float (&dhz)[16],
@@ -500,31 +500,38 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
   const uint4* tw = tw_in + zero;
   const uint4* wtab = wtab_in + zero;
   // ---- the step's tape ----
+  // TAPE_EARLY: all rows are requested BEFORE the contraction (their latency hides under its MFMAs; 64 more live
+  // registers during it: the one-wave-per-SIMD builds).  Otherwise only the ReLU mask comes first and the rows are
+  // requested after the contraction (two waves per SIMD: 256 registers each, the partner wave covers the latency).
   StepTape tl;
   const StepTape* tv = tr;
+  unsigned tape_loff = 0;
   if (!FROM_REGS) {
     const unsigned lane = (unsigned)(q * 16 + c);
-    unsigned loff = lane * 16u;
-    asm volatile("" : "+v"(loff));
+    tape_loff = lane * 16u;
+    asm volatile("" : "+v"(tape_loff));
     tl.mask = RIP_ABL == 1 ? 0x5au
-                           : *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(tp + TAPE_ROWS * 64) + (loff >> 2));
+                           : *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(tp + TAPE_ROWS * 64) + (tape_loff >> 2));
+    tv = &tl;
+  }
+  auto load_tape_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int up = 0; up < 4; ++up) {
-      const float4 rr = tape_ld(trow(tp, up * 4 + 0, loff)), zz = tape_ld(trow(tp, up * 4 + 1, loff));
-      const float4 gh = tape_ld(trow(tp, up * 4 + 3, loff));
+      const float4 rr = tape_ld(trow(tp, up * 4 + 0, tape_loff)), zz = tape_ld(trow(tp, up * 4 + 1, tape_loff));
+      const float4 gh = tape_ld(trow(tp, up * 4 + 3, tape_loff));
       float4 hp;
       if (TS == 1)
         hp = *reinterpret_cast<const float4*>(hp1 + 16 * up + 4 * q);  // prefix H1 (global, L2)
       else
-        hp = tape_ld(trow(tp, 16 + up, loff));
+        hp = tape_ld(trow(tp, 16 + up, tape_loff));
       tl.r[up * 4 + 0] = rr.x, tl.r[up * 4 + 1] = rr.y, tl.r[up * 4 + 2] = rr.z, tl.r[up * 4 + 3] = rr.w;
       tl.z[up * 4 + 0] = zz.x, tl.z[up * 4 + 1] = zz.y, tl.z[up * 4 + 2] = zz.z, tl.z[up * 4 + 3] = zz.w;
       tl.gh[up * 4 + 0] = gh.x, tl.gh[up * 4 + 1] = gh.y, tl.gh[up * 4 + 2] = gh.z, tl.gh[up * 4 + 3] = gh.w;
       tl.hp[up * 4 + 0] = hp.x, tl.hp[up * 4 + 1] = hp.y, tl.hp[up * 4 + 2] = hp.z, tl.hp[up * 4 + 3] = hp.w;
     }
-    tv = &tl;
-    __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the contraction
-  }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (!FROM_REGS && TAPE_EARLY) load_tape_rows();
   const float x0 = st[TS][0][c], x1 = st[TS][1][c], s0 = st[TS][2][c], s1 = st[TS][3][c];
   const float sg0 = st[TS][4][c], sg1 = st[TS][5][c];
   float dd0, dd1, dos0, dos1, c0, c1;
@@ -630,6 +637,10 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     }
     SPLIT_PRIO_VALU();
   }
+  if (!FROM_REGS && !TAPE_EARLY) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_tape_rows();
+  }
   // ---- n of this step: tanh(gi_n + r gh_n), gi_n = the (W_in[.][0], W_in[.][1], b_in, 0) k-step on y_{t-1} ----
   float nrec[16];
   if (!FROM_REGS) {
@@ -720,7 +731,7 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
 }
 
 // adjoint pass of the current model (flow_phase.hip:pass_backward)
-template <int MODE, bool REGTAPE = false>
+template <int MODE, bool REGTAPE = false, bool TAPE_EARLY = true>
 __device__ __forceinline__ void pass_backward(const uint4* tw, const uint4* wtab, const uint4* wl, const float (*io)[8],
                                               const float (*gin)[8], const float (*st)[6][CB], const float4* __restrict__ tape,
                                               const StepTape* last, const float* hp1, int c, int q, float (&res)[8], float w0) {
@@ -730,13 +741,13 @@ __device__ __forceinline__ void pass_backward(const uint4* tw, const uint4* wtab
   if (MODE == MODE_INV)
     adj_step<MODE, 3, true>(tw, wtab, wl, io, gin, st, nullptr, &last[2], hp1, c, q, w0, dhz, gs, carry0, carry1, res);
   else
-    adj_step<MODE, 3, false>(tw, wtab, wl, io, gin, st, tape + 2 * TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+    adj_step<MODE, 3, false, TAPE_EARLY>(tw, wtab, wl, io, gin, st, tape + 2 * TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
   if (REGTAPE) {
     adj_step<MODE, 2, true>(tw, wtab, wl, io, gin, st, nullptr, &last[1], hp1, c, q, w0, dhz, gs, carry0, carry1, res);
     adj_step<MODE, 1, true>(tw, wtab, wl, io, gin, st, nullptr, &last[0], hp1, c, q, w0, dhz, gs, carry0, carry1, res);
   } else {
-    adj_step<MODE, 2, false>(tw, wtab, wl, io, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
-    adj_step<MODE, 1, false>(tw, wtab, wl, io, gin, st, tape, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+    adj_step<MODE, 2, false, TAPE_EARLY>(tw, wtab, wl, io, gin, st, tape + TAPE_STEP_F4, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
+    adj_step<MODE, 1, false, TAPE_EARLY>(tw, wtab, wl, io, gin, st, tape, nullptr, hp1, c, q, w0, dhz, gs, carry0, carry1, res);
   }
   const float x0 = st[0][0][c], x1 = st[0][1][c], s0 = st[0][2][c], s1 = st[0][3][c];
   if (MODE == MODE_INV) {
