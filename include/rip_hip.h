@@ -302,6 +302,12 @@ int rip_set_option(rip_handle* h, int option, int value);
  * out[6,7] the adjoint of F_0, out[8,9] the prefix step per (model, observation).  n_out >= 10. */
 int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out);
 
+/* Tracing hook: with RIP_ROCTX=1 in the environment rip_encode / rip_search / rip_train_* wrap their
+ * launches in rocTX ranges (`rocprofv3 --marker-trace`); these two let the host layers (the collectives of
+ * oatomobile_amd/distributed.py, replay batches) mark theirs through the same library.  No-ops otherwise. */
+int rip_trace_push(const char* name);
+int rip_trace_pop(void);
+
 /* Introspection used by bench.py / tests. */
 int rip_num_models(const rip_handle* h);
 int rip_in_channels(const rip_handle* h);

@@ -54,6 +54,8 @@ SIGNATURES = [
     ]),
     ("rip_interpolate_plans", c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     ("rip_search_plan", c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
+    ("rip_trace_push", c_int, [c_char_p]),
+    ("rip_trace_pop", c_int, []),
     ("rip_set_option", c_int, [c_void_p, c_int, c_int]),
     ("rip_num_models", c_int, [c_void_p]),
     ("rip_in_channels", c_int, [c_void_p]),
@@ -178,3 +180,19 @@ class Handle:
       self.close()
     except Exception:  # interpreter shutdown
       pass
+
+
+class trace_range:
+  """`with trace_range("name"):` — a rocTX range through librip_hip.so's tracing hook (RIP_ROCTX=1; a no-op
+  otherwise): the host-side counterpart of the ranges rip_encode / rip_search open."""
+
+  def __init__(self, name: str) -> None:
+    self._name = name.encode()
+
+  def __enter__(self):
+    load().rip_trace_push(self._name)
+    return self
+
+  def __exit__(self, *exc):
+    load().rip_trace_pop()
+    return False

@@ -204,6 +204,7 @@ class RIPAgent(SetPointAgent):
     self._x0_rows = torch.from_numpy(x0).to(self._device)
     self._x0_cache = {}
     self._coded_z = {}  # batch -> (z, plan) scratch of plan_batch_coded
+    self._eager_pending = False  # plan_batch* work launched on torch's current stream since the last __call__
     self._use_graph = bool(graph) and os.environ.get("RIP_NO_GRAPH", "0") != "1"
     self._online = {}  # (H, W, G) -> captured one-observation pipeline
 
@@ -263,6 +264,7 @@ class RIPAgent(SetPointAgent):
     elif tuple(out.shape) != shape or out.dtype != dtype or out.device != self._device or not out.is_contiguous():
       raise ValueError("plan_batch: `out` must be a contiguous %s tensor of shape %s on %s" % (dtype, shape, self._device))
     loss = torch.empty(b, self._num_candidates, device=self._device, dtype=torch.float32) if return_loss else None
+    self._eager_pending = True
     if interpolate:
       self._launch_act(lidar, vec, goal, None, loss, out)
     else:
@@ -295,6 +297,7 @@ class RIPAgent(SetPointAgent):
       raise ValueError("plan_batch_coded: `out` must be a contiguous %s tensor of shape %s on %s" % (dtype, shape, dev))
     K, N = len(self._models), self._num_candidates
     lib, st = _lib.load(), self._handle.stream()
+    self._eager_pending = True
     z = self._coded_z.get(b)
     if z is None:
       z = self._coded_z[b] = (torch.empty(K, b, 64, device=dev), torch.empty(b, arch.T, 2, device=dev))
@@ -374,14 +377,32 @@ class RIPAgent(SetPointAgent):
     np.copyto(st["lidar_np"][0], lidar)
     np.copyto(st["vec_np"][0], vec)
     np.copyto(st["goal_np"][0], goal)
-    with torch.cuda.device(self._device):
-      st["stream"].wait_stream(torch.cuda.current_stream(self._device))  # earlier eager work on this handle
-      with torch.cuda.stream(st["stream"]):
-        if st["graph"] is not None:
-          st["graph"].replay()
-        else:
-          st["pipeline"]()
-      st["stream"].synchronize()
+    # ~45 us of every call are host time; the stream / device context managers of the generic path cost ~15 of them, so
+    # the common case (the agent's device is current) skips them and only orders the replay behind eager work this
+    # agent itself launched (`_eager_pending`; callers that drive the C ABI on the handle directly and then call the
+    # agent synchronise themselves, like any two users of one stream-ordered scratch)
+    stream = st["stream"]
+    if st["graph"] is not None and torch.cuda.current_device() == self._device.index:
+      prev = torch.cuda.current_stream(self._device)
+      if self._eager_pending:
+        stream.wait_stream(prev)  # plan_batch* work of this agent still in flight on the caller's stream
+        self._eager_pending = False
+      torch.cuda.set_stream(stream)
+      try:
+        st["graph"].replay()
+      finally:
+        torch.cuda.set_stream(prev)
+      stream.synchronize()
+    else:
+      with torch.cuda.device(self._device):
+        stream.wait_stream(torch.cuda.current_stream(self._device))  # earlier eager work on this handle
+        with torch.cuda.stream(stream):
+          if st["graph"] is not None:
+            st["graph"].replay()
+          else:
+            st["pipeline"]()
+        stream.synchronize()
+      self._eager_pending = False
     return st["plan_h"].numpy()[0].copy()  # [30, 3] float64: R11 ran in the selection kernel
 
 

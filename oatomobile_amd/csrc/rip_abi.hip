@@ -4,8 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -84,6 +87,40 @@ static hipError_t enter_stream(rip_handle* h, hipStream_t s) {
 
 
 static thread_local char g_err[512] = "";
+
+// ---- tracing hook: rocTX ranges around encode / search / train / collectives, visible in
+// `rocprofv3 --marker-trace`.  Off unless RIP_ROCTX=1 is in the environment: then librocprofiler-sdk-roctx (or the
+// roctracer-era libroctx64) is dlopen'ed once; without the library the ranges are no-ops.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+static const Roctx& roctx() {
+  static const Roctx r = [] {
+    Roctx x;
+    const char* e = getenv("RIP_ROCTX");
+    if (e == nullptr || e[0] != '1') return x;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL)) {
+        x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (x.push != nullptr && x.pop != nullptr) return x;
+        x = Roctx();
+      }
+    }
+    return x;
+  }();
+  return r;
+}
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~TraceRange() {
+    if (on) roctx().pop();
+  }
+};
 
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -267,6 +304,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
   REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
   ENTER(h, stream);
+  TraceRange range_(enc_dtype == RIP_ENC_BF16 ? "rip_encode (bf16)" : "rip_encode (fp32)");
   if (enc_dtype == RIP_ENC_BF16) {
     HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
                                 feat_dev, h->encoder_fused, (hipStream_t)stream));
@@ -414,6 +452,7 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
     if (lbest == nullptr) lbest = h->loss_best;
   }
   ENTER(h, stream);
+  TraceRange range_("rip_search");
   SearchArgs a;
   a.flow_w = h->flow_w;
   a.k0 = 0;
@@ -471,6 +510,15 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
                float* trace_grad_dev, rip_stream_t stream) {
   return search_impl(h, z_dev, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, plans_dev,
                      loss_best_dev, best_index_dev, trace_post_dev, trace_x_dev, trace_grad_dev, nullptr, stream);
+}
+
+int rip_trace_push(const char* name) {
+  if (name != nullptr && roctx().push != nullptr) roctx().push(name);
+  return RIP_OK;
+}
+int rip_trace_pop(void) {
+  if (roctx().pop != nullptr) roctx().pop();
+  return RIP_OK;
 }
 
 int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out) {
@@ -647,6 +695,7 @@ int rip_train_forward_backward(rip_trainer* t, float* params_dev, float* grads_d
   REQUIRE(B >= 1 && B <= trainer_max_batch(tr), "B=%d outside [1,max_batch=%d]", B, trainer_max_batch(tr));
   DeviceScope scope(trainer_device(tr));
   if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice failed: %s", hipGetErrorString(scope.err));
+  TraceRange range_(grads_dev != nullptr ? "rip_train_forward_backward" : "rip_train_forward");
   HIP_TRY(trainer_step(tr, params_dev, grads_dev, visual_dev, vec_dev, y_dev, dropout_mask_dev, B, batch_stats, loss_dev,
                        z_dev, (hipStream_t)stream));
   return RIP_OK;

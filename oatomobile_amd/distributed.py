@@ -54,12 +54,14 @@ def _all_gather_into(flat: torch.Tensor, block: torch.Tensor, group=None) -> Non
   """`dist.all_gather_into_tensor`; on the gloo backend device tensors are staged through the host (gloo has no
   device all-gather) — that combination only occurs in the one-GPU tests of the multi-rank paths, RCCL takes the
   device tensors as they are."""
-  if block.is_cuda and dist.get_backend(group) == "gloo":
-    host = torch.empty(flat.shape, dtype=flat.dtype)
-    dist.all_gather_into_tensor(host, block.detach().cpu().contiguous(), group=group)
-    flat.copy_(host)
-    return
-  dist.all_gather_into_tensor(flat, block.contiguous(), group=group)
+  from oatomobile_amd import _lib
+  with _lib.trace_range("rip all_gather (%d B)" % (flat.numel() * flat.element_size())):
+    if block.is_cuda and dist.get_backend(group) == "gloo":
+      host = torch.empty(flat.shape, dtype=flat.dtype)
+      dist.all_gather_into_tensor(host, block.detach().cpu().contiguous(), group=group)
+      flat.copy_(host)
+      return
+    dist.all_gather_into_tensor(flat, block.contiguous(), group=group)
 
 def all_gather_scores(local_scores: torch.Tensor, num_models: int, group=None) -> torch.Tensor:
   """Model-parallel exchange: `local_scores [K_local, B, N]` (this rank's models, in `shard_range` order) ->

@@ -112,7 +112,8 @@ class DIMTrainer:
     if self._group is None:
       return
     dist = torch.distributed
-    dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._group)
+    with _lib.trace_range("rip all_reduce gradients (%d B)" % (self.grads.numel() * 4)):
+      dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._group)
     world = dist.get_world_size(self._group)
     if world > 1:
       self.grads /= world

@@ -1490,3 +1490,24 @@ def test_packed_cache_replay_bit_identical(dev, tmp_path):
   assert torch.equal(za, zb)
   with pytest.raises(ValueError):
     agent.plan_batch_coded(codes.float(), lut, vec, torch.zeros(8, 10, 2, device=dev))
+
+
+def test_roctx_ranges_are_opt_in():
+  """SURVEY §5 tracing hook: with RIP_ROCTX=1 the entry points open rocTX ranges (the roctx library gets loaded and a
+  whole act() + an all-gather-free plan_batch run through them); without it the library is not touched."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ("import numpy as np, torch, sys\n"
+          "sys.path.insert(0, %r)\n"
+          "from oatomobile_amd import ImitativeModel, RIPAgent, _lib\n"
+          "from tests.helpers import synth_observation\n"
+          "a = RIPAgent(None, algorithm='WCM', models=[ImitativeModel.synthetic(100), ImitativeModel.synthetic(101)], num_candidates=4)\n"
+          "with _lib.trace_range('test range'):\n"
+          "  out = a(dict(synth_observation(np.random.default_rng(60))))\n"
+          "assert out.shape == (30, 3)\n"
+          "print('ROCTX_MAPPED', 'roctx' in open('/proc/self/maps').read())\n") % root
+  for flag, want in (("1", "ROCTX_MAPPED True"), ("0", "ROCTX_MAPPED False")):
+    env = dict(os.environ, RIP_ROCTX=flag)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert want in out.stdout, (flag, out.stdout[-500:])
