@@ -304,7 +304,8 @@ int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out);
 
 /* Tracing hook: with RIP_ROCTX=1 in the environment rip_encode / rip_search / rip_train_* wrap their
  * launches in rocTX ranges (`rocprofv3 --marker-trace`); these two let the host layers (the collectives of
- * oatomobile_amd/distributed.py, replay batches) mark theirs through the same library.  No-ops otherwise. */
+ * oatomobile_amd/distributed.py, replay batches) mark theirs through the same library.  They return 1 when tracing
+ * is on (a range was opened / closed) and 0 when it is off (no-ops). */
 int rip_trace_push(const char* name);
 int rip_trace_pop(void);
 

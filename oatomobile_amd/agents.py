@@ -375,13 +375,27 @@ class RIPAgent(SetPointAgent):
 
   def __call__(self, observation: Mapping[str, np.ndarray]) -> np.ndarray:
     """Returns the imitative-prior plan [30, 3] in ego coordinates (rip/agent.py:52-151)."""
-    lidar, vec, goal = _prepare_observation(observation, self._in_channels)
+    # rip/agent.py:59-69 straight into the pinned staging buffer (float32 casts happen in the assignments; shapes that
+    # the kernels cannot take raise ValueError like `_prepare_observation`)
+    lidar = observation["lidar"]
+    goal = observation["goal"]
+    if not isinstance(lidar, np.ndarray):
+      lidar = np.asarray(lidar, dtype=np.float32)
+    if not isinstance(goal, np.ndarray):
+      goal = np.asarray(goal, dtype=np.float32)
+    if getattr(lidar, "ndim", 0) != 3 or lidar.shape[-1] != self._in_channels or lidar.shape[0] < 1 or lidar.shape[1] < 1:
+      raise ValueError("observation['lidar'] must be [H,W,%d], got %s" % (self._in_channels, np.shape(lidar)))
+    if getattr(goal, "ndim", 0) != 2 or goal.shape[0] < 1 or goal.shape[1] < 2:
+      raise ValueError("observation['goal'] must be [G,>=2], got %s" % (np.shape(goal),))
     if self._sync_weights():
       self._online = {}
     st = self._online_state(lidar.shape[0], lidar.shape[1], goal.shape[0])
-    np.copyto(st["lidar_np"][0], lidar)
-    np.copyto(st["vec_np"][0], vec)
-    np.copyto(st["goal_np"][0], goal)
+    np.copyto(st["lidar_np"][0], lidar, casting="unsafe")
+    vec = st["vec_np"][0]
+    vec[:3] = np.reshape(observation["velocity"], 3)
+    vec[3] = np.reshape(observation["is_at_traffic_light"], -1)[0]
+    vec[4] = np.reshape(observation["traffic_light_state"], -1)[0]
+    np.copyto(st["goal_np"][0], goal[:, :2], casting="unsafe")
     # ~45 us of every call are host time; the stream / device context managers of the generic path cost ~15 of them, so
     # the common case (the agent's device is current) skips them and only orders the replay behind eager work this
     # agent itself launched (`_eager_pending`; callers that drive the C ABI on the handle directly and then call the
@@ -397,7 +411,7 @@ class RIPAgent(SetPointAgent):
         st["graph"].replay()
       finally:
         torch.cuda.set_stream(prev)
-      stream.synchronize()
+      stream.synchronize()  # (polling stream.query() instead measured no faster: 457.7 vs 456.3 us p50)
     else:
       with torch.cuda.device(self._device):
         stream.wait_stream(torch.cuda.current_stream(self._device))  # earlier eager work on this handle

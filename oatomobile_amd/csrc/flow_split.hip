@@ -33,6 +33,9 @@ constexpr int T_ROWS = MHT_ROWS;
 #ifndef RIP_REGTAPE
 #define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
 #endif
+#ifndef RIP_SPLIT_OVERLAP
+#define RIP_SPLIT_OVERLAP 0  // 1 = register-tape builds request the next model's operands under the current adjoint (measured: 2.81 vs 2.77 ms)
+#endif
 #ifndef RIP_SPLIT_PIPE
 #define RIP_SPLIT_PIPE 0  // 1 = 4- / 2-wave workgroups issue tile up+1's MFMAs ahead of tile up's gate math (measured: 2.82 vs 2.75 ms)
 #endif
@@ -193,20 +196,29 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     // ================= models 1..K-1: inverse, adjoint, streaming aggregation =================
 #pragma unroll 1
     for (int k = 1; k < K; ++k) {
-      TK_START();
-      __syncthreads();  // every wave is done with the F-buf (F_0 or inverse_{k-1}) and the T-buf (adjoint_{k-1})
-      TK_STOP(2);
-      TK_START();
+      constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
+      // OVERLAP (development switch, off; register-tape builds: the adjoint of an inverse pass never reads the F-buf):
+      // model k+1's forward operands are requested as soon as every wave has finished inverse_k and land under
+      // adjoint_k; its transposed ones are requested once adjoint_k is done and land under inverse_{k+1}.  Same two
+      // barriers per model and nobody waits on a DMA (2.5 k cycles per model: tools/search_ticks.py "barrier-dma"),
+      // yet the launch got SLOWER (2.81 vs 2.77 ms): the waves now wait at barriers placed where their pass lengths
+      // differ most (right behind the data-dependent adjoint) instead of where the DMA wait absorbed that skew.
+      constexpr bool OVERLAP = REGTAPE && RIP_SPLIT_OVERLAP;
       const uint32_t* mhk = mh_all + (size_t)(a.k0 + k) * MH_SIZE;
-      if (RIP_ABL != 2) {
-        load_fbuf(sh, mhk, wave, lane);
-        if (k > 1) load_tbuf(sh, mhk, wave, lane, tid);  // (model 1's T-buf was requested under F_0)
+      if (!OVERLAP || k == 1) {
+        TK_START();
+        __syncthreads();  // every wave is done with the F-buf (F_0 or inverse_{k-1}) and the T-buf (adjoint_{k-1})
+        TK_STOP(2);
+        TK_START();
+        if (RIP_ABL != 2) {
+          load_fbuf(sh, mhk, wave, lane);
+          if (k > 1) load_tbuf(sh, mhk, wave, lane, tid);  // (model 1's T-buf was requested under F_0)
+        }
+        __syncthreads();  // operands of model k landed
+        TK_STOP(3);
       }
-      __syncthreads();  // operands of model k landed
-      TK_STOP(3);
       TK_START();
       const Prefix16 pre = load_prefix(pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, q);
-      constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
       StepTape last[3];
       const PassOut po = pass_forward<MODE_INV, REGTAPE, (WPB <= 4 && RIP_SPLIT_PIPE)>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
       TK_STOP(4);
@@ -216,6 +228,12 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       q_sum += qk;
       // rip/agent.py:121-127 as coded: WCM = min_k(-q) = the largest posterior, BCM = the smallest (first on ties)
       const bool take = a.algorithm == ALGO_WCM ? (qk > q_sel) : (qk < q_sel);
+      if (OVERLAP) {
+        TK_START();
+        __syncthreads();  // every wave is done with F-buf(k); T-buf(k) (requested behind adjoint_{k-1}) has landed
+        TK_STOP(2);
+        if (RIP_ABL != 2) load_fbuf(sh, k + 1 < K ? mhk + MH_SIZE : mh0, wave, lane);  // next model's, or next step's F_0
+      }
       if (mean_mode || __any(take)) {
         __builtin_amdgcn_wave_barrier();
         float res[8];
@@ -237,6 +255,12 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
         q_sel = qk;
         ksel = k;
       }
+      if (OVERLAP && k + 1 < K) {
+        TK_START();
+        __syncthreads();  // every wave is done with T-buf(k); F-buf(k+1) has landed
+        TK_STOP(3);
+        if (RIP_ABL != 2) load_tbuf(sh, mhk + MH_SIZE, wave, lane, tid);
+      }
     }
     const float loss = -((mean_mode ? q_sum * inv_k : q_sel) + gl);
     w0 = (mean_mode ? inv_k : (ksel == 0 ? 1.0f : 0.0f)) * a.grad_scale;
@@ -247,7 +271,8 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       TK_STOP(6);
       if (RIP_ABL != 2) {
         load_tbuf(sh, mh0, wave, lane, tid);
-        load_fbuf(sh, mh0, wave, lane);  // next step's F_0
+        constexpr bool F0_IN_FLIGHT = RIP_REGTAPE && WPB <= 4 && RIP_SPLIT_OVERLAP;  // requested behind inverse_{K-1}
+        if (!F0_IN_FLIGHT) load_fbuf(sh, mh0, wave, lane);  // next step's F_0
       }
     }
     // dLoss/dy = -(sum_k w_k dq_k/dy + d gl/dy_T): lane (c, q) fills coordinates 2q, 2q+1

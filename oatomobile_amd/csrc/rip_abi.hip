@@ -513,12 +513,14 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
 }
 
 int rip_trace_push(const char* name) {
-  if (name != nullptr && roctx().push != nullptr) roctx().push(name);
-  return RIP_OK;
+  if (name == nullptr || roctx().push == nullptr) return 0;
+  roctx().push(name);
+  return 1;
 }
 int rip_trace_pop(void) {
-  if (roctx().pop != nullptr) roctx().pop();
-  return RIP_OK;
+  if (roctx().pop == nullptr) return 0;
+  roctx().pop();
+  return 1;
 }
 
 int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out) {
