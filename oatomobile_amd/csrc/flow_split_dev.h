@@ -94,6 +94,9 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
 #endif
 #define SPLIT_PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define SPLIT_PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#ifndef RIP_SPLIT_MERGE_LO
+#define RIP_SPLIT_MERGE_LO 1  // both lo' products of a tile share one accumulator (0: one each, as first built)
+#endif
 #ifndef RIP_PIPE_VALU
 #define RIP_PIPE_VALU 5  // vector instructions scheduled behind each matrix instruction in the one-wave-per-SIMD build
 #endif
@@ -188,7 +191,7 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
   float Hn[16];
   // Accumulators of one unit tile: three gates x (Whi xhi | Whi xlo' | Wlo' xhi) + gi_n.
   struct TileAcc {
-    f32x4 a[3], l1[3], l2[3], agn;
+    f32x4 a[3], l1[3], l2[3], agn;  // (RIP_SPLIT_MERGE_LO: l2 unused, both lo' products accumulate into l1)
   };
   auto issue = [&](int up, TileAcc& t) __attribute__((always_inline)) {
     SPLIT_PRIO_BURST();
@@ -212,15 +215,18 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
         }
         t.a[g] = mfmah(as_h8(wh), bh, t.a[g]);
         t.l1[g] = mfmah(as_h8(wh), bl, t.l1[g]);
-        t.l2[g] = mfmah(as_h8(wo), bh, t.l2[g]);
+        if (RIP_SPLIT_MERGE_LO)
+          t.l1[g] = mfmah(as_h8(wo), bh, t.l1[g]);
+        else
+          t.l2[g] = mfmah(as_h8(wo), bh, t.l2[g]);
       }
     }
     SPLIT_PRIO_VALU();
   };
   auto finish = [&](int up, const TileAcc& t) __attribute__((always_inline)) {
-    const f32x4 ar = t.a[0] + (t.l1[0] + t.l2[0]) * LO_INV;
-    const f32x4 az = t.a[1] + (t.l1[1] + t.l2[1]) * LO_INV;
-    const f32x4 ahn = t.a[2] + (t.l1[2] + t.l2[2]) * LO_INV;
+    const f32x4 ar = t.a[0] + (RIP_SPLIT_MERGE_LO ? t.l1[0] : t.l1[0] + t.l2[0]) * LO_INV;
+    const f32x4 az = t.a[1] + (RIP_SPLIT_MERGE_LO ? t.l1[1] : t.l1[1] + t.l2[1]) * LO_INV;
+    const f32x4 ahn = t.a[2] + (RIP_SPLIT_MERGE_LO ? t.l1[2] : t.l1[2] + t.l2[2]) * LO_INV;
     float rr[4], zz[4], nn[4];
     gru_gates(ar, az, t.agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
     // pin the tile's gate math HERE: it has no side effect, and left alone it sinks below the MFMAs of ALL later tiles
@@ -584,11 +590,14 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
       const uint4 wh = tw[(1 + ut * 2) * 64], wo = tw[(2 + ut * 2) * 64];
       a[ut] = mfmah(as_h8(wh), ah, zero4());
       l1[ut] = mfmah(as_h8(wh), al, zero4());
-      l2[ut] = mfmah(as_h8(wo), ah, zero4());
+      if (RIP_SPLIT_MERGE_LO)
+        l1[ut] = mfmah(as_h8(wo), ah, l1[ut]);
+      else
+        l2[ut] = mfmah(as_h8(wo), ah, zero4());
     }
     SPLIT_PRIO_VALU();
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + (l1[ut] + l2[ut]) * LO_INV) * ia;
+    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + (RIP_SPLIT_MERGE_LO ? l1[ut] : l1[ut] + l2[ut]) * LO_INV) * ia;
   }
   // ---- part 2: W_hh^T (dpr, dpz, dgh_n)_{t+1}: 6 K blocks x 4 unit tiles, rows 9 + (kb * 4 + ut) * 2 + term ----
   if (!FIRST) {
@@ -629,11 +638,15 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
           }
           a[u] = mfmah(as_h8(wh), bh, a[u]);
           l1[u] = mfmah(as_h8(wh), bl, l1[u]);
-          l2[u] = mfmah(as_h8(wo), bh, l2[u]);
+          if (RIP_SPLIT_MERGE_LO)
+            l1[u] = mfmah(as_h8(wo), bh, l1[u]);
+          else
+            l2[u] = mfmah(as_h8(wo), bh, l2[u]);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) dh[2 * half + u] = dh[2 * half + u] + (a[u] + (l1[u] + l2[u]) * LO_INV) * ig;
+      for (int u = 0; u < 2; ++u)
+        dh[2 * half + u] = dh[2 * half + u] + (a[u] + (RIP_SPLIT_MERGE_LO ? l1[u] : l1[u] + l2[u]) * LO_INV) * ig;
     }
     SPLIT_PRIO_VALU();
   }
