@@ -438,11 +438,22 @@ def main():
     blocks16 = B * N / 16.0
     if args.algorithm == "MA" or K == 1:
       adj_passes = float(S * (K - 1) * blocks16)
+      laid_out = adj_passes
     else:
       sign = 1.0 if args.algorithm == "WCM" else -1.0
       run = (sign * tp).cummax(dim=1).values  # running best over models 0..k
       take = (sign * tp[:, 1:]) > run[:, :-1]  # [S,K-1,B,N]: strictly better than every earlier model
-      adj_passes = float(take.view(S, K - 1, B, N // 16, 16).any(-1).sum().item())
+      laid_out = float(take.view(S, K - 1, B, N // 16, 16).any(-1).sum().item())  # with the candidates as laid out
+      # what the timed (trace-free) launch really executes: the kernel regroups a workgroup's candidates by selected
+      # model between Adam steps, so the count comes from its own counter (rip_search_stats)
+      import ctypes
+      cnt = ctypes.c_uint64(0)
+      _lib.check(lib.rip_search_stats(h, None, 1))
+      _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x0), B, N, G, algo, S, 0.1, 1.0, _lib.ptr(plan), None,
+                                _lib.ptr(loss), None, None, None, None, _lib.current_stream(dev)))
+      _lib.check(lib.rip_search_stats(h, ctypes.byref(cnt), 1))
+      adj_passes = float(cnt.value)
+    extras["adjoint_inverse_passes_as_laid_out"] = laid_out
     def count(info):  # (f16, fp32) MFMA instructions of the whole launch
       return tuple(blocks16 * ((S + 1) * info["pass"][i] + S * info["adj_f0"][i] + S * (K - 1) * info["pass"][i]) +
                    adj_passes * info["adj_inv"][i] + B * K * info["prefix"][i] for i in (0, 1))

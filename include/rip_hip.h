@@ -290,8 +290,14 @@ int rip_train_num_layers(const rip_trainer* t);
  *     bf16 encoder: count >= 1 fuses the stem with features.1 (one kernel), blocks 1..6 of the count are the
  *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
  *     features.17 / 18 always run layer by layer.  auto = everything, the tile kernel only when the call carries
- *     >= 64 (model, observation) pairs (an explicit count uses it regardless). */
-enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1 };
+ *     >= 64 (model, observation) pairs (an explicit count uses it regardless).
+ *   RIP_OPT_SEARCH_REGROUP (default 0): 1 = the split-f16 kernel regroups the candidates of a workgroup by the ensemble
+ *     member they selected after every Adam step (WCM / BCM, trace-free launches whose workgroups stay inside one
+ *     observation), so that a 16-candidate block mostly needs ONE inverse pass's adjoint (1.6 instead of 2.7 per block
+ *     and step); a candidate's arithmetic does not depend on its lane, so 0 and 1 give bit-identical plans and best
+ *     losses.  Off by default: the workgroup walks the model phases in lockstep, so the launch is no faster (measured
+ *     2.82 vs 2.73 ms). */
+enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2 };
 int rip_set_option(rip_handle* h, int option, int value);
 
 /* What rip_search would launch for B observations x N candidates under the handle's current options, and what that
@@ -301,6 +307,12 @@ int rip_set_option(rip_handle* h, int option, int value);
  * instructions per 16-candidate block of out[2,3] one forward / inverse pass, out[4,5] the adjoint of an inverse pass,
  * out[6,7] the adjoint of F_0, out[8,9] the prefix step per (model, observation).  n_out >= 10. */
 int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out);
+
+/* Diagnostic (synchronises the device): the number of inverse-pass ADJOINTS the phase-sequential search kernels have
+ * executed on this handle since the last reset — one per 16-candidate block, Adam step and ensemble member whose
+ * adjoint some candidate of the block needed (rip/agent.py:121-129 back-propagates through the selected member only).
+ * With rip_search_plan's per-pass instruction counts this is bench.py's executed-flops figure. */
+int rip_search_stats(rip_handle* h, uint64_t* adjoint_passes, int reset);
 
 /* Tracing hook: with RIP_ROCTX=1 in the environment rip_encode / rip_search / rip_train_* wrap their
  * launches in rocTX ranges (`rocprofv3 --marker-trace`); these two let the host layers (the collectives of

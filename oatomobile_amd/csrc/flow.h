@@ -52,6 +52,8 @@ struct SearchArgs {
   float* trace_x;        // [steps][B][N][8] or nullptr
   float* trace_loss;     // [steps][B][N] or nullptr
   float* trace_grad;     // [steps][B][N][8] dLoss/dx of every Adam step, or nullptr
+  int regroup = 0;       // split kernel: regroup a workgroup's candidates by selected model between Adam steps (RIP_OPT_SEARCH_REGROUP)
+  unsigned long long* stats = nullptr;  // device counter: += executed inverse-pass adjoints (phase-sequential kernels), or nullptr
 };
 
 // Gradient-mode model-parallel search: one Adam step split at the exchange point.

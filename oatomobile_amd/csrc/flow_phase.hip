@@ -827,6 +827,7 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
         TK_START();
         pass_backward<MODE_INV, REGTAPE>(tw, wq4, wl, io, nullptr, stI, tapeI, last, pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, c, q,
                                 res, 0.f);
+        if (a.stats != nullptr && lane == 0 && active) atomicAdd(a.stats, 1ull);  // executed inverse-pass adjoints (bench.py)
         TK_STOP(5);
         if (mean_mode) {
 #pragma unroll

@@ -38,6 +38,7 @@ struct rip_handle {
   int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA wave-per-model pipeline, 3 fp32-MFMA phase-sequential,
                             // 4 split-f16 phase-sequential
   int encoder_fused = -1;   // leading inverted-residual blocks run fused (0 = none, 17 = all); -1 = auto by batch
+  int search_regroup = 0;   // split-f16 search: regroup a workgroup's candidates by selected model between Adam steps (measured: no gain)
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
   size_t buf_floats = 0;
@@ -48,6 +49,7 @@ struct rip_handle {
   float* loss_best = nullptr;  // [max_batch][max_candidates]
   float* trace_loss = nullptr; // [RIP_MAX_STEPS][max_batch]   (ImitativeModel.forward)
   float* trace_x = nullptr;    // [RIP_MAX_STEPS][max_batch][8]
+  unsigned long long* stats = nullptr;  // [1] executed inverse-pass adjoints of the phase-sequential kernels (rip_search_stats)
 };
 
 // Makes the handle's device current for one entry point and restores the caller's on exit.
@@ -210,6 +212,12 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
   ALLOC(h->loss_best, (size_t)max_batch * max_candidates);
   ALLOC(h->trace_loss, (size_t)RIP_MAX_STEPS * max_batch);
   ALLOC(h->trace_x, (size_t)RIP_MAX_STEPS * max_batch * 8);
+  {
+    float* tmp = nullptr;
+    ALLOC(tmp, 2);
+    h->stats = reinterpret_cast<unsigned long long*>(tmp);
+    (void)hipMemset(h->stats, 0, sizeof(unsigned long long));
+  }
   // scratch of the MFMA search kernels (adjoint tape, prefix table): 0 when neither can ever run for this handle
   h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
   if (search_phase_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
@@ -232,7 +240,7 @@ int rip_destroy(rip_handle* h) {
   if (h->order != nullptr) (void)hipEventDestroy(h->order);
   if (h->tape != nullptr) (void)hipFree(h->tape);
   float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
-                   h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x};
+                   h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x, reinterpret_cast<float*>(h->stats)};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
   delete h;
@@ -249,6 +257,10 @@ int rip_set_option(rip_handle* h, int option, int value) {
     case RIP_OPT_ENCODER_FUSED:
       REQUIRE(value >= -1 && value <= 17, "encoder_fused must be in [-1,17] (got %d)", value);
       h->encoder_fused = value;
+      return RIP_OK;
+    case RIP_OPT_SEARCH_REGROUP:
+      REQUIRE(value == 0 || value == 1, "search regroup must be 0 or 1 (got %d)", value);
+      h->search_regroup = value;
       return RIP_OK;
     default:
       return fail(RIP_EINVAL, "unknown option %d", option);
@@ -474,6 +486,8 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
   a.trace_x = trace_x_dev;
   a.trace_loss = nullptr;
   a.trace_grad = trace_grad_dev;
+  a.stats = h->stats;
+  a.regroup = h->search_regroup;
   // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
   // wave-per-chain kernel has the lower latency for a single observation.  Among the MFMA kernels the phase-sequential
   // one (operands in LDS, two waves per SIMD, any K) is the default; mode 2 keeps the wave-per-model pipeline.
@@ -510,6 +524,18 @@ int rip_search(rip_handle* h, const float* z_dev, const float* goal_dev, const f
                float* trace_grad_dev, rip_stream_t stream) {
   return search_impl(h, z_dev, goal_dev, x0_dev, B, N, G, algorithm, num_steps, lr, epsilon, plan_dev, plans_dev,
                      loss_best_dev, best_index_dev, trace_post_dev, trace_x_dev, trace_grad_dev, nullptr, stream);
+}
+
+int rip_search_stats(rip_handle* h, uint64_t* adjoint_passes, int reset) {
+  REQUIRE(h != nullptr, "handle is NULL");
+  DeviceScope scope(h->device);
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(scope.err));
+  HIP_TRY(hipDeviceSynchronize());  // diagnostic call: waits for the launches it reports on
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpy(&v, h->stats, sizeof(v), hipMemcpyDeviceToHost));
+  if (adjoint_passes != nullptr) *adjoint_passes = v;
+  if (reset) HIP_TRY(hipMemset(h->stats, 0, sizeof(v)));
+  return RIP_OK;
 }
 
 int rip_trace_push(const char* name) {
