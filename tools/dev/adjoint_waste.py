@@ -81,5 +81,59 @@ def main():
   print("oracle bound (sorted by the final selection, no intermediate records): %.2f per block-step" % (tot / blocks))
 
 
-if __name__ == "__main__":
+def wg_phases(tp, group=64, global_sort=False, reorder=False):
+  """Adjoint PHASES a 64-candidate workgroup walks through per Adam step (a phase is paid by the whole workgroup as
+  soon as one of its candidates needs that model's adjoint).  global_sort: the launch's candidates are binned by the
+  model they selected in the previous step (any observation), workgroups take 64 consecutive ones; reorder: a workgroup
+  evaluates its majority's predicted model first."""
+  S, K, B, N = tp.shape
+  q_all = tp.reshape(S, K, B * N)
+  prev = np.zeros(B * N, np.int64)
+  phases = 0
+  for s in range(S):
+    q = q_all[s]
+    perm = np.argsort(prev, kind="stable") if global_sort else np.arange(B * N)
+    qs = q[:, perm].reshape(K, -1, group)            # [K, WGs, 64]
+    pv = prev[perm].reshape(-1, group)
+    for w in range(qs.shape[1]):
+      order = list(range(1, K))
+      if reorder:
+        p = np.bincount(pv[w], minlength=K).argmax()
+        if p != 0:
+          order = [p] + [k for k in range(1, K) if k != p]
+      best = qs[0, w].copy()
+      for k in order:
+        take = qs[k, w] > best
+        if take.any():
+          phases += 1
+        best = np.maximum(best, qs[k, w])
+    prev = np.argmax(q, axis=0)
+  return phases / (S * (B * N // group))
+
+
+def main2():
+  from oatomobile_amd import ImitativeModel, RIPAgent, _lib
+  dev = torch.device("cuda", 0)
+  K, N, B, S = 4, 128, 512, 10
+  models = [ImitativeModel.synthetic(100 + k, max_batch=1) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, device=dev, encoder_dtype="bf16")
+  lib, h = _lib.load(), agent._handle.raw
+  lidar, vec, goal = (torch.from_numpy(a).to(dev) for a in synth_batch(np.random.default_rng(1000), B, 2))
+  z = torch.empty(K, B, 64, device=dev)
+  _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar), 1, 200, 200, _lib.ptr(vec), B, 0, K, 1, _lib.ptr(z), _lib.current_stream(dev)))
+  tp = torch.empty(S, K, B, N, device=dev)
+  loss = torch.empty(B, N, device=dev)
+  _lib.check(lib.rip_search(h, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(agent._x0(B)), B, N, 10, 0, S, 0.1, 1.0, None, None,
+                            _lib.ptr(loss), None, _lib.ptr(tp), None, None, _lib.current_stream(dev)))
+  tp = tp.cpu().numpy().astype(np.float64)
+  print("adjoint phases per 64-candidate workgroup and Adam step (of %d):" % (K - 1))
+  print("  as laid out                                  %.2f" % wg_phases(tp))
+  print("  globally binned by the previous selection    %.2f" % wg_phases(tp, global_sort=True))
+  print("  + predicted model evaluated first            %.2f" % wg_phases(tp, global_sort=True, reorder=True))
+
+
+if __name__ == "__main__" and os.environ.get("RIP_WASTE_WG") == "1":
+  main2()
+
+if __name__ == "__main__" and os.environ.get("RIP_WASTE_WG") != "1":
   main()
