@@ -31,6 +31,9 @@ def main():
     for c in ("SQ_INSTS_MFMA", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"):
       if c in by[k]:
         out["search"][c] = by[k][c][0]
+  once = [v["FETCH_SIZE"][1] for k, v in by.items() if k.startswith(("merger_kernel", "transform_kernel", "cls_")) and "FETCH_SIZE" in v]
+  if once:
+    steps = min(once)  # encoder steps of the run (the search kernel also runs outside the step: bench.py's trace / stats launches)
   if steps:
     fe = sum(v["FETCH_SIZE"][2] for k, v in by.items() if ENC.match(k) and "FETCH_SIZE" in v) / steps
     wr = sum(v["WRITE_SIZE"][2] for k, v in by.items() if ENC.match(k) and "WRITE_SIZE" in v) / steps
