@@ -296,9 +296,26 @@ int rip_train_num_layers(const rip_trainer* t);
  *     observation), so that a 16-candidate block mostly needs ONE inverse pass's adjoint (1.6 instead of 2.7 per block
  *     and step); a candidate's arithmetic does not depend on its lane, so 0 and 1 give bit-identical plans and best
  *     losses.  Off by default: the workgroup walks the model phases in lockstep, so the launch is no faster (measured
- *     2.82 vs 2.73 ms). */
-enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2 };
+ *     2.82 vs 2.73 ms).
+ *   RIP_OPT_ENCODER_MEGA (experimental): the fp32 encoder of a small batch as ONE persistent launch instead of 55
+ *     dependent ones (a dependent launch costs 4.4-4.8 us whatever it computes): ensemble member k runs on XCD k % 8
+ *     only — its activations stay in that XCD's L2 and the barrier between two layers is a counter in that L2 (~1 us
+ *     against 17-27 us for a device-wide one).  1 = every batch of up to 4 observations, 0 / -1 (default) = never:
+ *     a layer between two such barriers still takes 2-7 us on the 32 CUs of one XCD (251-273 us per observation
+ *     against 244 us for the launches), so the launches stay the default.  Same layer arithmetic as
+ *     the layer-wise launches (tile shapes may differ: last-bit differences).  The kernel relies on
+ *     the hardware placing workgroup i of a launch on XCD i % 8 (verified once per device at rip_create; the option is
+ *     ignored where that does not hold); every workgroup re-checks its placement and every barrier wait is bounded
+ *     (20 ms) — see rip_encoder_status. */
+enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2, RIP_OPT_ENCODER_MEGA = 3 };
 int rip_set_option(rip_handle* h, int option, int value);
+
+/* 0, or non-zero once a one-launch encoder call (RIP_OPT_ENCODER_MEGA) found a workgroup off its XCD (1) or gave up
+ * waiting at a layer barrier (2): the z of THAT call is invalid.  Read it after synchronising the stream of the call
+ * (a host word, no device access); from then on the handle uses the layer-wise launches, so repeating the call gives
+ * the valid result (oatomobile_amd/agents.py does exactly that).  A caller that never asks gets RIP_ESTATE from the
+ * first entry point it calls after the failure became visible — once, so that the failure cannot pass unnoticed. */
+int rip_encoder_status(rip_handle* h);
 
 /* What rip_search would launch for B observations x N candidates under the handle's current options, and what that
  * launch executes on the matrix cores (bench.py's executed-flops count; rocprofv3 SQ_INSTS_MFMA is the check):

@@ -55,6 +55,7 @@ SIGNATURES = [
     ("rip_interpolate_plans", c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     ("rip_search_plan", c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     ("rip_search_stats", c_int, [c_void_p, c_void_p, c_int]),
+    ("rip_encoder_status", c_int, [c_void_p]),
     ("rip_trace_push", c_int, [c_char_p]),
     ("rip_trace_pop", c_int, []),
     ("rip_set_option", c_int, [c_void_p, c_int, c_int]),
@@ -78,7 +79,7 @@ ABI_VERSION = 3
 
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
-OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED, OPT_SEARCH_REGROUP = 0, 1, 2
+OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED, OPT_SEARCH_REGROUP, OPT_ENCODER_MEGA = 0, 1, 2, 3
 SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2, "phase": 3, "split": 4}
 
 _lib = None

@@ -198,6 +198,9 @@ class RIPAgent(SetPointAgent):
       fused_encoder = int(os.environ["RIP_ENCODER_FUSED"])
     if fused_encoder is not None:
       self._handle.set_option(_lib.OPT_ENCODER_FUSED, int(fused_encoder))
+    if "RIP_ENCODER_MEGA" in os.environ:  # experimental one-launch fp32 encoder: 1 = batches of up to 4 observations, 0 / -1 never
+      self._handle.set_option(_lib.OPT_ENCODER_MEGA, int(os.environ["RIP_ENCODER_MEGA"]))
+    self._enc_status = _lib.load().rip_encoder_status
     rng = np.random.default_rng(seed)
     x0 = rng.standard_normal((self._num_candidates, arch.T, 2)).astype(np.float32)
     x0[0] = 0.0  # base distribution mean (rip/agent.py:85)
@@ -422,6 +425,11 @@ class RIPAgent(SetPointAgent):
             st["pipeline"]()
         stream.synchronize()
       self._eager_pending = False
+    if self._enc_status(self._handle.raw):
+      # the one-launch encoder found its workgroups off their XCDs or a layer barrier timed out: this call's z is
+      # invalid.  The handle has switched to the layer-wise launches; drop the captured graphs and repeat the call.
+      self._online = {}
+      return self(observation)
     return st["plan_h"].numpy()[0].copy()  # [30, 3] float64: R11 ran in the selection kernel
 
 

@@ -62,6 +62,18 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
                           hipStream_t s);
 
+// The whole fp32 encoder of a small batch as ONE persistent launch, model k on XCD k % 8 (encoder.hip:
+// encoder_mega_kernel).  arena: kc * arena_model_stride floats, arena_model_stride >= encoder_mega_arena_floats(B);
+// sync: 8 * 64 zeroed unsigned (re-armed by the kernel itself); status: pinned host word, set non-zero when the
+// placement / barrier protocol failed (results invalid: fall back to launch_encoder); ticks: nullable.
+size_t encoder_mega_arena_floats(const EncoderPlan& plan, int B);
+bool encoder_mega_supported(const EncoderPlan& plan, int B, int kc);
+bool encoder_mega_probe(int device);
+hipError_t launch_encoder_mega(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
+                               const float* vec, int B, float* arena, size_t arena_model_stride, unsigned* sync,
+                               int* status, unsigned long long* ticks, float* z, float* feat, int wgs_per_xcd,
+                               hipStream_t s);
+
 hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* act_last, int hw,
                        const float* vec, int B, float* scratch, float* z, float* feat, hipStream_t s);
 

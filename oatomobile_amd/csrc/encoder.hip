@@ -161,14 +161,15 @@ __global__ void transform_generic_kernel(const float* __restrict__ in, int B, in
 // K2: stem conv 3x3 stride 2 pad 1 (+folded BN, ReLU6).  in: [B][C][Hin][Hin] NCHW (shared by all
 // models), w: [tap][c][32], out: [K][B][Ho][Ho][32].  thread = (pixel, 4 output channels).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
-                                                    size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
-                                                    int C, int Hin, int Ho, float* __restrict__ out) {
-  const int k = blockIdx.z;
+// The layer bodies are device functions of (virtual block index, weight model k, activation slot ka): the layer-wise
+// kernels call them with their blockIdx, the one-XCD-per-model persistent kernel (encoder_mega_kernel) in a loop.
+__device__ __forceinline__ void stem_body(const float* __restrict__ in, const float* __restrict__ wbase,
+                                          size_t model_stride, int k0, size_t w_off, size_t b_off, int B, int C, int Hin,
+                                          int Ho, float* __restrict__ out, int bx, int k, int ka) {
   const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
   const int total = B * Ho * Ho * 8;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = bx * 256 + threadIdx.x;
   if (idx >= total) return;
   const int oc4 = idx & 7;
   const int pix = idx >> 3;
@@ -176,72 +177,99 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
   float4 acc = *reinterpret_cast<const float4*>(bias + oc4 * 4);
   for (int c = 0; c < C; ++c) {
     const float* ip = in + ((size_t)b * C + c) * Hin * Hin;
+    float v[9];
+    float4 wv[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int ky = 0; ky < 3; ++ky) {  // loads first (see dw_body): taps off the image count as zero
       const int iy = oy * 2 - 1 + ky;
-      if (iy < 0 || iy >= Hin) continue;
+      const int cy = min(max(iy, 0), Hin - 1);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * 2 - 1 + kx;
-        if (ix < 0 || ix >= Hin) continue;
-        const float v = ip[(size_t)iy * Hin + ix];
-        const float4 wv = *reinterpret_cast<const float4*>(w + ((ky * 3 + kx) * C + c) * 32 + oc4 * 4);
-        acc.x = fmaf(v, wv.x, acc.x);
-        acc.y = fmaf(v, wv.y, acc.y);
-        acc.z = fmaf(v, wv.z, acc.z);
-        acc.w = fmaf(v, wv.w, acc.w);
+        const int cx = min(max(ix, 0), Hin - 1);
+        const bool ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin;
+        const float t = ip[(size_t)cy * Hin + cx];
+        v[ky * 3 + kx] = ok ? t : 0.f;
+        wv[ky * 3 + kx] = *reinterpret_cast<const float4*>(w + ((ky * 3 + kx) * C + c) * 32 + oc4 * 4);
       }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc.x = fmaf(v[t], wv[t].x, acc.x);
+      acc.y = fmaf(v[t], wv[t].y, acc.y);
+      acc.z = fmaf(v[t], wv[t].z, acc.z);
+      acc.w = fmaf(v[t], wv[t].w, acc.w);
     }
   }
   acc.x = relu6f(acc.x);
   acc.y = relu6f(acc.y);
   acc.z = relu6f(acc.z);
   acc.w = relu6f(acc.w);
-  float* op = out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * 32 + oc4 * 4;
+  float* op = out + (((size_t)ka * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * 32 + oc4 * 4;
   *reinterpret_cast<float4*>(op) = acc;
+}
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                    size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
+                                                    int C, int Hin, int Ho, float* __restrict__ out) {
+  stem_body(in, wbase, model_stride, k0, w_off, b_off, B, C, Hin, Ho, out, blockIdx.x, blockIdx.z, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: depthwise 3x3 (+folded BN, ReLU6), NHWC.  w: [9][C].  thread = (output pixel, 4 channels):
 // every global access is a float4 with the channel index fastest -> fully coalesced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
-                                                  size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
-                                                  int C, int Hin, int Ho, int stride, float* __restrict__ out) {
-  const int k = blockIdx.z;
+__device__ __forceinline__ void dw_body(const float* __restrict__ in, const float* __restrict__ wbase,
+                                        size_t model_stride, int k0, size_t w_off, size_t b_off, int B, int C, int Hin,
+                                        int Ho, int stride, float* __restrict__ out, int bx, int k, int ka) {
   const float* w = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
   const int C4 = C >> 2;
   const long total = (long)B * Ho * Ho * C4;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)bx * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c4 = (int)(idx % C4);
   const long pix = idx / C4;
   const int ox = (int)(pix % Ho), oy = (int)((pix / Ho) % Ho), b = (int)(pix / ((long)Ho * Ho));
-  const float* ip = in + ((size_t)k * B + b) * Hin * Hin * C + c4 * 4;
+  const float* ip = in + ((size_t)ka * B + b) * Hin * Hin * C + c4 * 4;
   float4 acc = *reinterpret_cast<const float4*>(bias + c4 * 4);
+  // All 18 loads are issued before the first FMA (taps off the image read a clamped address and count as zero:
+  // fma(0, w, acc) == acc, so the result is the one of skipping them): one memory round trip per output instead of
+  // one per tap — what a single-observation launch, or a layer of the persistent kernel, is bound by.
+  float4 v[9], wv[9];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = oy * stride - 1 + ky;
-    if (iy < 0 || iy >= Hin) continue;
+    const int cy = min(max(iy, 0), Hin - 1);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = ox * stride - 1 + kx;
-      if (ix < 0 || ix >= Hin) continue;
-      const float4 v = *reinterpret_cast<const float4*>(ip + ((size_t)iy * Hin + ix) * C);
-      const float4 wv = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c4 * 4);
-      acc.x = fmaf(v.x, wv.x, acc.x);
-      acc.y = fmaf(v.y, wv.y, acc.y);
-      acc.z = fmaf(v.z, wv.z, acc.z);
-      acc.w = fmaf(v.w, wv.w, acc.w);
+      const int cx = min(max(ix, 0), Hin - 1);
+      const bool ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin;
+      const float4 t = *reinterpret_cast<const float4*>(ip + ((size_t)cy * Hin + cx) * C);
+      v[ky * 3 + kx] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      wv[ky * 3 + kx] = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c4 * 4);
     }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc.x = fmaf(v[t].x, wv[t].x, acc.x);
+    acc.y = fmaf(v[t].y, wv[t].y, acc.y);
+    acc.z = fmaf(v[t].z, wv[t].z, acc.z);
+    acc.w = fmaf(v[t].w, wv[t].w, acc.w);
   }
   acc.x = relu6f(acc.x);
   acc.y = relu6f(acc.y);
   acc.z = relu6f(acc.z);
   acc.w = relu6f(acc.w);
-  float* op = out + (((size_t)k * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * C + c4 * 4;
+  float* op = out + (((size_t)ka * B + b) * Ho * Ho + (size_t)oy * Ho + ox) * C + c4 * 4;
   *reinterpret_cast<float4*>(op) = acc;
+}
+
+__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                  size_t model_stride, int k0, size_t w_off, size_t b_off, int B,
+                                                  int C, int Hin, int Ho, int stride, float* __restrict__ out) {
+  dw_body(in, wbase, model_stride, k0, w_off, b_off, B, C, Hin, Ho, stride, out, blockIdx.x, blockIdx.z, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,24 +300,26 @@ __device__ __forceinline__ float row_sum16(float x) {
 // KSPLIT = 1: the block's 4 waves take 4 different pixel-tile groups.  KSPLIT = 4: they take the 4 quarters of the
 // K range of ONE (CT x PT) tile and reduce through LDS — big register tiles (little operand re-reading from L2)
 // and still enough waves when M is small (7x7 / 4x4 stages, or a single observation).
-template <int CT, int PT, int UNROLL, int KSPLIT>
-__global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
-                                                  size_t model_stride, int k0, size_t w_off, size_t b_off,
-                                                  const float* __restrict__ res, float* __restrict__ out, int M,
-                                                  int Cin, int Cout, int flags, size_t act_model_stride_in,
-                                                  size_t act_model_stride_out) {
+// `part`: [KSPLIT][CT * PT][64] float4 of LDS for the K-split reduction (unused with KSPLIT = 1)
+// HOIST: bias and residual operands are requested before the K loop instead of in the epilogue (two fewer dependent
+// memory round trips per tile; costs 4 * CT * (PT + 1) registers: the latency-bound persistent kernel only).
+template <int CT, int PT, int UNROLL, int KSPLIT, bool HOIST = false>
+__device__ __forceinline__ void pw_body(const float* __restrict__ in, const float* __restrict__ wbase,
+                                        size_t model_stride, int k0, size_t w_off, size_t b_off,
+                                        const float* __restrict__ res, float* __restrict__ out, int M, int Cin, int Cout,
+                                        int flags, size_t act_model_stride_in, size_t act_model_stride_out, int bx,
+                                        int by, int k, int ka, float4* part) {
   const int relu6 = flags & 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int k = blockIdx.z;
-  const int ptile0 = (KSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * PT;
-  const int ctile0 = blockIdx.y * CT;
+  const int ptile0 = (KSPLIT == 1 ? bx * 4 + wave : bx) * PT;
+  const int ctile0 = by * CT;
   if (KSPLIT == 1 && ptile0 * 16 >= M) return;
   const float* A = wbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
-  const float* X = in + (size_t)k * act_model_stride_in;
-  float* O = out + (size_t)k * act_model_stride_out;
-  const float* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
+  const float* X = in + (size_t)ka * act_model_stride_in;
+  float* O = out + (size_t)ka * act_model_stride_out;
+  const float* R = res != nullptr ? res + (size_t)ka * act_model_stride_out : nullptr;
 
   const float* arow[CT];
   bool aval[CT];
@@ -310,6 +340,20 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 hb[HOIST ? CT : 1], hr[HOIST ? CT : 1][HOIST ? PT : 1];
+  if (HOIST) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = (ctile0 + ct) * 16 + 4 * q;
+      hb[ct] = co < Cout ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = (ptile0 + pt) * 16 + n;
+        hr[ct][pt] = (R != nullptr && co < Cout && p < M) ? *reinterpret_cast<const float4*>(R + (size_t)p * Cout + co)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
 
   // UNROLL chunks per trip, all their loads issued before the first MFMA (chunks past Cin are predicated off)
   // K range of this wave (multiples of 16)
@@ -346,12 +390,12 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
   }
   if (KSPLIT > 1) {
     // reduce the K slices: every wave parks its partial tiles in LDS, then wave w finishes tiles t = w (mod 4)
-    __shared__ float4 part[KSPLIT][CT * PT][64];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
-        part[wave][ct * PT + pt][lane] = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
+        part[(wave * CT * PT + ct * PT + pt) * 64 + lane] =
+            make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
     __syncthreads();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -359,10 +403,10 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
       for (int pt = 0; pt < PT; ++pt) {
         const int t = ct * PT + pt;
         if ((t & (KSPLIT - 1)) == wave) {
-          float4 sum = part[0][t][lane];
+          float4 sum = part[t * 64 + lane];
 #pragma unroll
           for (int w2 = 1; w2 < KSPLIT; ++w2) {
-            const float4 o = part[w2][t][lane];
+            const float4 o = part[(w2 * CT * PT + t) * 64 + lane];
             sum.x += o.x;
             sum.y += o.y;
             sum.z += o.z;
@@ -377,7 +421,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
   for (int ct = 0; ct < CT; ++ct) {
     const int co = (ctile0 + ct) * 16 + 4 * q;
     if (co < Cout) {
-      const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+      const float4 bb = HOIST ? hb[ct] : *reinterpret_cast<const float4*>(bias + co);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
@@ -398,7 +442,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
           float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                  acc[ct][pt][3] + bb.w);
           if (R != nullptr) {
-            const float4 r = *reinterpret_cast<const float4*>(R + (size_t)p * Cout + co);
+            const float4 r = HOIST ? hr[ct][pt] : *reinterpret_cast<const float4*>(R + (size_t)p * Cout + co);
             v.x += r.x;
             v.y += r.y;
             v.z += r.z;
@@ -415,6 +459,18 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, c
       }
     }
   }
+}
+
+template <int CT, int PT, int UNROLL, int KSPLIT>
+__global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ in, const float* __restrict__ wbase,
+                                                  size_t model_stride, int k0, size_t w_off, size_t b_off,
+                                                  const float* __restrict__ res, float* __restrict__ out, int M,
+                                                  int Cin, int Cout, int flags, size_t act_model_stride_in,
+                                                  size_t act_model_stride_out) {
+  __shared__ float4 part[KSPLIT > 1 ? KSPLIT * CT * PT * 64 : 1];
+  pw_body<CT, PT, UNROLL, KSPLIT>(in, wbase, model_stride, k0, w_off, b_off, res, out, M, Cin, Cout, flags,
+                                  act_model_stride_in, act_model_stride_out, blockIdx.x, blockIdx.y, blockIdx.z,
+                                  blockIdx.z, part);
 }
 
 template <int CT, int PT, int UNROLL, int KSPLIT>
@@ -458,14 +514,12 @@ void dispatch_pw(const float* in, const float* enc_w, size_t ms, int k0, int kc,
 // ------------------------------------------------------------------------------------------------
 constexpr int CLS_GROUP = 16;
 
-__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ act, const float* __restrict__ wbase,
-                                                   size_t model_stride, int k0, size_t cls_w, size_t cls_b, int B,
-                                                   int HW, float* __restrict__ feat) {
-  __shared__ float pooled[LAST_C];
-  const int b = blockIdx.x, k = blockIdx.y, og = blockIdx.z;
+__device__ __forceinline__ void cls_body(const float* __restrict__ act, const float* __restrict__ wbase,
+                                         size_t model_stride, int k0, size_t cls_w, size_t cls_b, int B, int HW,
+                                         float* __restrict__ feat, int b, int k, int ka, int og, float* pooled) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* W = wbase + (size_t)(k0 + k) * model_stride;
-  const float* a = act + ((size_t)k * B + b) * HW * LAST_C;
+  const float* a = act + ((size_t)ka * B + b) * HW * LAST_C;
   const float inv = 1.0f / (float)HW;
   for (int c = tid; c < LAST_C; c += 256) {
     float s = 0.f;
@@ -482,8 +536,16 @@ __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ act,
     for (int i = 0; i < LAST_C / 64; ++i) s = fmaf(wr[i * 64 + lane], pooled[i * 64 + lane], s);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane == 0) feat[((size_t)k * B + b) * FEAT + o] = s + W[cls_b + o];
+    if (lane == 0) feat[((size_t)ka * B + b) * FEAT + o] = s + W[cls_b + o];
   }
+}
+
+__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ act, const float* __restrict__ wbase,
+                                                   size_t model_stride, int k0, size_t cls_w, size_t cls_b, int B,
+                                                   int HW, float* __restrict__ feat) {
+  __shared__ float pooled[LAST_C];
+  cls_body(act, wbase, model_stride, k0, cls_w, cls_b, B, HW, feat, blockIdx.x, blockIdx.y, blockIdx.y, blockIdx.z,
+           pooled);
 }
 
 // classifier on the matrix cores for already pooled features (HW == 1: the bf16 encoder's features.18 epilogue pools):
@@ -531,37 +593,232 @@ __global__ __launch_bounds__(256) void cls_mfma_kernel(const float* __restrict__
 // K6: cat(feat128, vec5) -> merger 3x(Linear+ReLU) (dim/model.py:206-217).  One wave per (obs, model):
 // lane j owns output unit j, inputs broadcast from LDS.
 // ------------------------------------------------------------------------------------------------
+// Threads 0..63 of the block work; every thread of the block reaches the barriers.  v: [FEAT + VEC + 3], hbuf: [2][HID].
+__device__ __forceinline__ void merger_body(const float* __restrict__ feat, const float* __restrict__ wbase,
+                                            size_t model_stride, int k0, size_t m0w, size_t m0b, size_t m1w, size_t m1b,
+                                            size_t m2w, size_t m2b, const float* __restrict__ vec, int B,
+                                            float* __restrict__ z, int b, int k, int kf, int kz, float* v, float* hbuf) {
+  const int tid = threadIdx.x;
+  const bool on = tid < 64;
+  const float* W = wbase + (size_t)(k0 + k) * model_stride;
+  if (on) {
+    for (int i = tid; i < FEAT; i += 64) v[i] = feat[((size_t)kf * B + b) * FEAT + i];
+    if (tid < VEC) v[FEAT + tid] = vec[(size_t)b * VEC + tid];
+  }
+  __syncthreads();
+  if (on) {
+    const float* wr = W + m0w + (size_t)tid * (FEAT + VEC);
+    float s = W[m0b + tid];
+    for (int i = 0; i < FEAT + VEC; ++i) s = fmaf(wr[i], v[i], s);
+    hbuf[tid] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  if (on) {
+    const float* wr = W + m1w + (size_t)tid * HID;
+    float s = W[m1b + tid];
+    for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[i], s);
+    hbuf[HID + tid] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  if (on) {
+    const float* wr = W + m2w + (size_t)tid * HID;
+    float s = W[m2b + tid];
+    for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[HID + i], s);
+    z[((size_t)kz * B + b) * HID + tid] = fmaxf(s, 0.f);
+  }
+}
+
 __global__ __launch_bounds__(64) void merger_kernel(const float* __restrict__ feat, const float* __restrict__ wbase,
                                                      size_t model_stride, int k0, size_t m0w, size_t m0b, size_t m1w,
                                                      size_t m1b, size_t m2w, size_t m2b,
                                                      const float* __restrict__ vec, int B, float* __restrict__ z) {
   __shared__ float v[FEAT + VEC + 3];
-  __shared__ float hbuf[2][HID];
-  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
-  const float* W = wbase + (size_t)(k0 + k) * model_stride;
-  for (int i = tid; i < FEAT; i += 64) v[i] = feat[((size_t)k * B + b) * FEAT + i];
-  if (tid < VEC) v[FEAT + tid] = vec[(size_t)b * VEC + tid];
+  __shared__ float hbuf[2 * HID];
+  merger_body(feat, wbase, model_stride, k0, m0w, m0b, m1w, m1b, m2w, m2b, vec, B, z, blockIdx.x, blockIdx.y,
+              blockIdx.y, blockIdx.y, v, hbuf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch for the whole encoder of a SMALL batch (online: one observation per call).  Layer by layer the B = 1
+// encoder is 55 dependent launches of ~1 us of work each, and a dependent launch costs ~4.8 us inside a hipGraph
+// (profiles/r3/online_trace_v1.txt): 283 us.  A persistent kernel has to replace the launch boundary by a barrier
+// among its workgroups, and a device-wide barrier is no cheaper (tools/micro/grid_barrier.hip: 17-27 us for 256
+// workgroups — every arrival is a round trip to the memory side).  But the K ensemble members are independent until
+// the plan search, the hardware places workgroup i of a launch on XCD i % 8 (tools/micro/xcd_barrier.hip), and the
+// workgroups of ONE XCD share an L2: model k runs on XCD k % 8 only, its activations never leave that L2, and the
+// barrier between two layers is an atomic counter that lives in that L2 — ~1 us per layer for 32 workgroups
+// (xcd_barrier.hip mode 1), no cache maintenance:
+//   * arrival: s_waitcnt vmcnt(0) (the TCP is write-through: the workgroup's stores are in the L2 then), one atomic add;
+//     wait: returning atomics (performed in the L2, never served by a TCP);
+//   * every layer writes its own region of the per-model arena, so no cache line that some TCP may hold is ever
+//     rewritten inside the launch (a TCP is invalidated at the launch boundary): the consumers' loads miss to the L2.
+// A workgroup that finds itself on another XCD than blockIdx % 8, or a barrier that waits longer than 20 ms, raises
+// the status word (pinned host memory) and the launch drains: the caller falls back to the layer-wise launches.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned MEGA_NONE = 0xffffffffu;
+constexpr int MEGA_MAX_LAYERS = 56;
+struct MegaLayer {
+  uint32_t w_off, b_off;    // floats into the model's blob
+  uint32_t src, dst, res;   // floats into the model's arena (src NONE: the network input; res NONE: no residual)
+  uint32_t M;               // pointwise: rows = B * h_out^2
+  uint16_t cin, cout, gx, gy;  // virtual grid of the layer body
+  uint8_t kind, variant, h_in, h_out, stride, flags, pad0, pad1;
+};
+struct MegaArgs {
+  const float* visual;
+  const float* vec;
+  const float* wbase;
+  float* arena;
+  float* z;
+  float* feat;             // nullable: classifier output for the caller
+  unsigned* sync;          // [8][2][32]: per XCD a barrier counter and an exit counter, one 128-byte line each
+  int* status;             // pinned host word
+  unsigned long long* ticks;  // nullable (development): wall clock after every layer of model 0
+  size_t model_stride, arena_model_stride;
+  size_t cls_w, cls_b, m0w, m0b, m1w, m1b, m2w, m2b;
+  uint32_t last_off, feat_off;
+  int k0, kc, B, C, last_hw, n_layers;
+  MegaLayer layers[MEGA_MAX_LAYERS];
+};
+static_assert(sizeof(MegaArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(63508) & 0xf; }  // HW_REG_XCC_ID
+
+__device__ __forceinline__ bool xcd_barrier(unsigned* ctr, unsigned target, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  {
-    const float* wr = W + m0w + (size_t)tid * (FEAT + VEC);
-    float s = W[m0b + tid];
-    for (int i = 0; i < FEAT + VEC; ++i) s = fmaf(wr[i], v[i], s);
-    hbuf[0][tid] = fmaxf(s, 0.f);
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_fetch_add(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (wall_clock64() - t0 > 2000000) {  // 20 ms of the 100 MHz wall clock
+        ok = 0;
+        break;
+      }
+    }
+    *s_flag = ok;
   }
   __syncthreads();
-  {
-    const float* wr = W + m1w + (size_t)tid * HID;
-    float s = W[m1b + tid];
-    for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[0][i], s);
-    hbuf[1][tid] = fmaxf(s, 0.f);
+  return *s_flag != 0;
+}
+
+template <int CT, int PT, int UNROLL, int KSPLIT>
+__device__ __forceinline__ void mega_pw(const MegaArgs& a, const MegaLayer& L, const float* src, const float* res,
+                                        float* dst, int k, int rank, int P, float4* part) {
+  const int nvb = (int)L.gx * L.gy;
+#pragma unroll 1
+  for (int vb = rank; vb < nvb; vb += P) {
+    const int by = vb / L.gx, bx = vb - by * L.gx;
+    pw_body<CT, PT, UNROLL, KSPLIT, true>(src, a.wbase, a.model_stride, a.k0, L.w_off, L.b_off, res, dst, (int)L.M,
+                                          L.cin, L.cout, L.flags, 0, 0, bx, by, k, 0, part);
+    if (KSPLIT > 1) __syncthreads();  // `part` is reused by the next virtual block
   }
+}
+
+constexpr int MEGA_PART_F4 = 4 * 8 * 64;  // K-split scratch of the largest pointwise variant (CT * PT = 8)
+
+__global__ __launch_bounds__(256) void encoder_mega_kernel(const MegaArgs a) {
+  __shared__ float4 part[MEGA_PART_F4];
+  __shared__ int s_flag;
+  const int P = gridDim.x >> 3, rank = blockIdx.x >> 3;
+  const unsigned x = xcc_id();
+  if (x != (blockIdx.x & 7u)) {  // not where the barrier protocol assumes this workgroup to be
+    if (threadIdx.x == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;  // the workgroups that wait for this one time out and drain
+  }
+  if ((int)x >= a.kc) return;
+  unsigned* ctr = a.sync + x * 64;
+  unsigned* done = ctr + 32;
+  unsigned epoch = 0;
+  const int B = a.B;
+#pragma unroll 1
+  for (int kr = (int)x; kr < a.kc; kr += 8) {
+    float* arena = a.arena + (size_t)kr * a.arena_model_stride;
+#pragma unroll 1
+    for (int li = 0; li < a.n_layers; ++li) {
+      const MegaLayer& L = a.layers[li];
+      // Warm the L2 with the NEXT layer's weights (one dword per 128-byte line, spread over the XCD's workgroups):
+      // they arrive from HBM / the memory-side cache while this layer computes, instead of after its barrier.
+      {
+        const bool last = li + 1 == a.n_layers;
+        const size_t w0 = last ? a.cls_w : a.layers[li + 1].w_off;
+        const size_t w1 = last ? a.m2b + HID : (size_t)a.layers[li + 1].b_off + a.layers[li + 1].cout;
+        const float* wp = a.wbase + (size_t)(a.k0 + kr) * a.model_stride;
+        for (size_t i = w0 + ((size_t)rank * 256 + threadIdx.x) * 32; i < w1; i += (size_t)P * 256 * 32) {
+          float sink;
+          asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(wp + i) : "memory");
+        }
+      }
+      const float* src = L.src == MEGA_NONE ? a.visual : arena + L.src;
+      const float* res = L.res == MEGA_NONE ? nullptr : arena + L.res;
+      float* dst = arena + L.dst;
+      if (L.kind == L_STEM) {
+#pragma unroll 1
+        for (int vb = rank; vb < (int)L.gx; vb += P)
+          stem_body(src, a.wbase, a.model_stride, a.k0, L.w_off, L.b_off, B, a.C, L.h_in, L.h_out, dst, vb, kr, 0);
+      } else if (L.kind == L_DW) {
+#pragma unroll 1
+        for (int vb = rank; vb < (int)L.gx; vb += P)
+          dw_body(src, a.wbase, a.model_stride, a.k0, L.w_off, L.b_off, B, L.cout, L.h_in, L.h_out, L.stride, dst, vb, kr,
+                  0);
+      } else {
+        switch (L.variant) {
+          case 0: mega_pw<1, 1, 8, 1>(a, L, src, res, dst, kr, rank, P, part); break;
+          case 1: mega_pw<1, 2, 8, 1>(a, L, src, res, dst, kr, rank, P, part); break;
+          case 2: mega_pw<2, 2, 4, 1>(a, L, src, res, dst, kr, rank, P, part); break;
+          case 3: mega_pw<4, 2, 2, 1>(a, L, src, res, dst, kr, rank, P, part); break;
+          case 4: mega_pw<1, 1, 8, 4>(a, L, src, res, dst, kr, rank, P, part); break;
+          case 5: mega_pw<1, 2, 8, 4>(a, L, src, res, dst, kr, rank, P, part); break;
+          case 6: mega_pw<2, 2, 4, 4>(a, L, src, res, dst, kr, rank, P, part); break;
+          default: mega_pw<4, 2, 2, 4>(a, L, src, res, dst, kr, rank, P, part); break;
+        }
+      }
+      ++epoch;
+      if (a.ticks != nullptr && kr == 0 && rank == 0 && threadIdx.x == 0) a.ticks[64 + li] = wall_clock64();
+      if (!xcd_barrier(ctr, epoch * (unsigned)P, &s_flag)) {
+        if (threadIdx.x == 0) __hip_atomic_store(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      if (a.ticks != nullptr && kr == 0 && rank == 0 && threadIdx.x == 0) a.ticks[li] = wall_clock64();
+    }
+    // pool (if features.18 did not) + classifier, then the merger
+    float* feat = a.feat != nullptr ? a.feat + (size_t)kr * B * FEAT : arena + a.feat_off;
+    float* scratch = reinterpret_cast<float*>(part);
+#pragma unroll 1
+    for (int vb = rank; vb < B * (FEAT / CLS_GROUP); vb += P) {
+      const int b = vb / (FEAT / CLS_GROUP), og = vb - b * (FEAT / CLS_GROUP);
+      cls_body(arena + a.last_off, a.wbase, a.model_stride, a.k0, a.cls_w, a.cls_b, B, a.last_hw, feat, b, kr, 0, og,
+               scratch);
+      __syncthreads();
+    }
+    ++epoch;
+    if (!xcd_barrier(ctr, epoch * (unsigned)P, &s_flag)) {
+      if (threadIdx.x == 0) __hip_atomic_store(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+#pragma unroll 1
+    for (int b = rank; b < B; b += P) {
+      merger_body(feat, a.wbase, a.model_stride, a.k0, a.m0w, a.m0b, a.m1w, a.m1b, a.m2w, a.m2b, a.vec, B,
+                  a.z + (size_t)kr * B * HID, b, kr, 0, 0, scratch, scratch + 256);
+      __syncthreads();
+    }
+    if (a.ticks != nullptr && kr == 0 && rank == 0 && threadIdx.x == 0) a.ticks[a.n_layers] = wall_clock64();
+  }
+  // the last workgroup of this XCD to leave re-arms the counters for the next launch (every workgroup that leaves
+  // has passed the final barrier, so nobody still reads them)
   __syncthreads();
-  {
-    const float* wr = W + m2w + (size_t)tid * HID;
-    float s = W[m2b + tid];
-    for (int i = 0; i < HID; ++i) s = fmaf(wr[i], hbuf[1][i], s);
-    z[((size_t)k * B + b) * HID + tid] = fmaxf(s, 0.f);
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)P - 1u) {
+      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+
+__global__ void mega_probe_kernel(int* xcc) {
+  if (threadIdx.x == 0) xcc[blockIdx.x] = (int)xcc_id();
 }
 
 }  // namespace
@@ -878,6 +1135,163 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
   hipLaunchKernelGGL(merger_kernel, dim3(B, kc), dim3(64), 0, s, (const float*)feat_buf, enc_w, ms, k0,
                      plan.mrg_w_off[0], plan.mrg_b_off[0], plan.mrg_w_off[1], plan.mrg_b_off[1], plan.mrg_w_off[2],
                      plan.mrg_b_off[2], vec, B, z);
+  return hipGetLastError();
+}
+
+// ---- the one-launch encoder for small batches (encoder_mega_kernel) ----
+namespace {
+
+// pointwise tile shapes of the persistent kernel: the rule of dispatch_pw for ONE model and `want` waves
+int mega_pw_variant(int M, const Layer& l, int P, int& ct, int& pt, int& ks) {
+  // A layer of the persistent kernel costs (rounds of virtual blocks per workgroup) x (the latency chain of one
+  // block), so: as few rounds as the P workgroups allow, the K range split over the block's 4 waves when it is long,
+  // and among the shapes with equal rounds the smallest tile (the shortest chain, the most workgroups busy).
+  static const int V[8][3] = {{1, 1, 1}, {1, 2, 1}, {2, 2, 1}, {4, 2, 1}, {1, 1, 4}, {1, 2, 4}, {2, 2, 4}, {4, 2, 4}};
+  const long n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
+  int best = -1;
+  long best_rounds = 0, best_tile = 0;
+  for (int v = 0; v < 8; ++v) {
+    const int c = V[v][0], p = V[v][1], k = V[v][2];
+    if ((k == 4) != (l.cin >= 128)) continue;
+    if (c > n_ct && c > 1) continue;
+    const long groups = (n_pt + p - 1) / p;
+    const long blocks = (k == 1 ? (groups + 3) / 4 : groups) * ((n_ct + c - 1) / c);
+    const long rounds = (blocks + P - 1) / P, tile = (long)c * p;
+    if (best < 0 || rounds < best_rounds || (rounds == best_rounds && tile < best_tile)) {
+      best = v;
+      best_rounds = rounds;
+      best_tile = tile;
+    }
+  }
+  ct = V[best][0];
+  pt = V[best][1];
+  ks = V[best][2];
+  return best;
+}
+
+size_t mega_layout(const EncoderPlan& plan, int B, std::vector<uint32_t>* dst_off, uint32_t* feat_off) {
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    const size_t o = off;
+    off += (n + 63) / 64 * 64;  // 256-byte granules: two layers never share a cache line
+    return (uint32_t)o;
+  };
+  const size_t nl = plan.layers.size();
+  if (dst_off) dst_off->resize(nl);
+  for (size_t li = 0; li < nl; ++li) {
+    const Layer& l = plan.layers[li];
+    const bool pooled = li + 1 == nl && plan.final_hw == 4;
+    const uint32_t o = take(pooled ? (size_t)B * l.cout : (size_t)B * l.h_out * l.h_out * l.cout);
+    if (dst_off) (*dst_off)[li] = o;
+  }
+  const uint32_t f = take((size_t)B * FEAT);
+  if (feat_off) *feat_off = f;
+  return off;
+}
+
+}  // namespace
+
+size_t encoder_mega_arena_floats(const EncoderPlan& plan, int B) { return mega_layout(plan, B, nullptr, nullptr); }
+
+bool encoder_mega_supported(const EncoderPlan& plan, int B, int kc) {
+  return (int)plan.layers.size() <= MEGA_MAX_LAYERS && B >= 1 && B <= 16 && kc >= 1 && plan.in_channels <= 16 &&
+         (size_t)B * 2500 * 96 < 0xffffffffu;
+}
+
+// Is workgroup i of a launch placed on XCD i % 8 on this device (8 XCDs, round-robin)?  Checked once per device.
+bool encoder_mega_probe(int device) {
+  static int cache[64] = {0};  // 0 unknown, 1 yes, 2 no
+  if (device < 0 || device >= 64) return false;
+  if (cache[device] != 0) return cache[device] == 1;
+  constexpr int G = 256;
+  int* d = nullptr;
+  bool ok = hipMalloc((void**)&d, G * sizeof(int)) == hipSuccess;
+  if (ok) {
+    std::vector<int> hst(G, -1);
+    for (int rep = 0; rep < 3 && ok; ++rep) {
+      hipLaunchKernelGGL(mega_probe_kernel, dim3(G), dim3(64), 0, 0, d);
+      ok = hipMemcpy(hst.data(), d, G * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+      for (int i = 0; i < G && ok; ++i) ok = hst[i] == (i & 7);
+    }
+    (void)hipFree(d);
+  }
+  cache[device] = ok ? 1 : 2;
+  return ok;
+}
+
+hipError_t launch_encoder_mega(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
+                               const float* vec, int B, float* arena, size_t arena_model_stride, unsigned* sync,
+                               int* status, unsigned long long* ticks, float* z, float* feat, int wgs_per_xcd,
+                               hipStream_t s) {
+  MegaArgs a;
+  std::memset(&a, 0, sizeof(a));
+  std::vector<uint32_t> dst_off;
+  uint32_t feat_off = 0;
+  mega_layout(plan, B, &dst_off, &feat_off);
+  // where each of the four rotating workspace ids of the plan was last written
+  uint32_t where[4] = {MEGA_NONE, MEGA_NONE, MEGA_NONE, MEGA_NONE};
+  const int P = wgs_per_xcd;
+  const size_t nl = plan.layers.size();
+  for (size_t li = 0; li < nl; ++li) {
+    const Layer& l = plan.layers[li];
+    MegaLayer& L = a.layers[li];
+    L.w_off = (uint32_t)l.w_off;
+    L.b_off = (uint32_t)l.b_off;
+    L.src = l.src < 0 ? MEGA_NONE : where[l.src];
+    L.res = l.residual ? where[l.res] : MEGA_NONE;
+    L.dst = dst_off[li];
+    L.cin = (uint16_t)l.cin;
+    L.cout = (uint16_t)l.cout;
+    L.kind = (uint8_t)l.kind;
+    L.h_in = (uint8_t)l.h_in;
+    L.h_out = (uint8_t)l.h_out;
+    L.stride = (uint8_t)l.stride;
+    L.gy = 1;
+    if (l.kind == L_STEM) {
+      L.gx = (uint16_t)(((long)B * l.h_out * l.h_out * 8 + 255) / 256);
+    } else if (l.kind == L_DW) {
+      L.gx = (uint16_t)(((long)B * l.h_out * l.h_out * (l.cout / 4) + 255) / 256);
+    } else {
+      const int M = B * l.h_out * l.h_out;
+      const bool pool = li + 1 == nl && plan.final_hw == 4;
+      int ct = 1, pt = 1, ks = 1;
+      L.variant = (uint8_t)mega_pw_variant(M, l, P, ct, pt, ks);
+      const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16, groups = (n_pt + pt - 1) / pt;
+      L.gx = (uint16_t)(ks == 1 ? (groups + 3) / 4 : groups);
+      L.gy = (uint16_t)((n_ct + ct - 1) / ct);
+      L.M = (uint32_t)M;
+      L.flags = (uint8_t)(l.relu6 | (pool ? 2 : 0));
+    }
+    where[l.dst] = L.dst;
+  }
+  a.n_layers = (int)nl;
+  a.visual = visual;
+  a.vec = vec;
+  a.wbase = enc_w;
+  a.arena = arena;
+  a.z = z;
+  a.feat = feat;
+  a.sync = sync;
+  a.status = status;
+  a.ticks = ticks;
+  a.model_stride = plan.blob_floats;
+  a.arena_model_stride = arena_model_stride;
+  a.cls_w = plan.cls_w_off;
+  a.cls_b = plan.cls_b_off;
+  a.m0w = plan.mrg_w_off[0];
+  a.m0b = plan.mrg_b_off[0];
+  a.m1w = plan.mrg_w_off[1];
+  a.m1b = plan.mrg_b_off[1];
+  a.m2w = plan.mrg_w_off[2];
+  a.m2b = plan.mrg_b_off[2];
+  a.last_off = dst_off[nl - 1];
+  a.feat_off = feat_off;
+  a.last_hw = plan.final_hw == 4 ? 1 : plan.final_hw * plan.final_hw;
+  a.k0 = k0;
+  a.kc = kc;
+  a.B = B;
+  a.C = plan.in_channels;
+  hipLaunchKernelGGL(encoder_mega_kernel, dim3(8 * P), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -50,6 +50,16 @@ struct rip_handle {
   float* trace_loss = nullptr; // [RIP_MAX_STEPS][max_batch]   (ImitativeModel.forward)
   float* trace_x = nullptr;    // [RIP_MAX_STEPS][max_batch][8]
   unsigned long long* stats = nullptr;  // [1] executed inverse-pass adjoints of the phase-sequential kernels (rip_search_stats)
+  // one-launch fp32 encoder for small batches (encoder.hip: encoder_mega_kernel)
+  int encoder_mega = -1;        // -1 auto (= never: the launches measured faster), 0 never, 1 whenever the batch fits mega_max_b
+  int mega_max_b = 0;           // 0: not available on this device / handle
+  int mega_wgs = 32;            // workgroups per XCD
+  float* mega_arena = nullptr;  // [K][mega_stride]
+  size_t mega_stride = 0;
+  unsigned* mega_sync = nullptr;         // [8][64] barrier / exit counters, one pair per XCD
+  int* mega_status = nullptr;            // pinned host word: non-zero = the protocol failed, results of that call invalid
+  bool mega_reported = false;            // the failure has been handed to the caller (rip_encoder_status or an error)
+  unsigned long long* mega_ticks = nullptr;  // development (RIP_MEGA_TICKS=1): per-layer wall clock of model 0
 };
 
 // Makes the handle's device current for one entry point and restores the caller's on exit.
@@ -85,7 +95,8 @@ static hipError_t enter_stream(rip_handle* h, hipStream_t s) {
 #define ENTER(h_, stream_)                                                                  \
   DeviceScope scope_((h_)->device);                                                         \
   if (scope_.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", (h_)->device, hipGetErrorString(scope_.err)); \
-  HIP_TRY(enter_stream((h_), (hipStream_t)(stream_)))
+  HIP_TRY(enter_stream((h_), (hipStream_t)(stream_)));                                      \
+  if (int guard_ = mega_guard(h_)) return guard_
 
 
 static thread_local char g_err[512] = "";
@@ -130,6 +141,15 @@ static int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// A one-launch encoder call whose placement / barrier protocol failed left an invalid z behind: the first entry point
+// that runs after the failure became visible reports it (once), unless the caller has already asked rip_encoder_status.
+static int mega_guard(rip_handle* h) {
+  if (h->mega_status == nullptr || *h->mega_status == 0 || h->mega_reported) return RIP_OK;
+  h->mega_reported = true;
+  return fail(RIP_ESTATE, "an earlier one-launch encoder call failed (status %d): its outputs are invalid; the handle "
+              "uses the layer-wise launches from now on", *h->mega_status);
 }
 
 #define HIP_TRY(expr)                                                                       \
@@ -218,6 +238,34 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     h->stats = reinterpret_cast<unsigned long long*>(tmp);
     (void)hipMemset(h->stats, 0, sizeof(unsigned long long));
   }
+  // one-launch encoder: only where workgroup i of a launch lands on XCD i % 8 (checked once per device)
+  if (encoder_mega_probe(device)) {
+    int mb = max_batch < 4 ? max_batch : 4;
+    while (mb > 0 && !encoder_mega_supported(h->plan, mb, K)) --mb;
+    if (mb > 0) {
+      h->mega_stride = encoder_mega_arena_floats(h->plan, mb);
+      ALLOC(h->mega_arena, (size_t)K * h->mega_stride);
+      float* tmp = nullptr;
+      ALLOC(tmp, 8 * 64);
+      h->mega_sync = reinterpret_cast<unsigned*>(tmp);
+      (void)hipMemset(h->mega_sync, 0, 8 * 64 * sizeof(unsigned));
+      if (hipHostMalloc((void**)&h->mega_status, 64, hipHostMallocDefault) != hipSuccess) h->mega_status = nullptr;
+      if (h->mega_status != nullptr) {
+        *h->mega_status = 0;
+        h->mega_max_b = mb;
+      }
+      if (const char* e = getenv("RIP_MEGA_WGS")) {  // development: workgroups per XCD
+        const int v = atoi(e);
+        if (v >= 1 && v <= 128) h->mega_wgs = v;
+      }
+      if (const char* e = getenv("RIP_MEGA_TICKS"); e != nullptr && e[0] == '1') {
+        float* t2 = nullptr;
+        ALLOC(t2, 2 * 128);
+        h->mega_ticks = reinterpret_cast<unsigned long long*>(t2);
+        (void)hipMemset(h->mega_ticks, 0, 128 * sizeof(unsigned long long));
+      }
+    }
+  }
   // scratch of the MFMA search kernels (adjoint tape, prefix table): 0 when neither can ever run for this handle
   h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
   if (search_phase_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
@@ -239,6 +287,22 @@ int rip_destroy(rip_handle* h) {
   DeviceScope scope(h->device);
   if (h->order != nullptr) (void)hipEventDestroy(h->order);
   if (h->tape != nullptr) (void)hipFree(h->tape);
+  if (h->mega_ticks != nullptr) {  // development: where the one-launch encoder spends its time (model 0, last call)
+    unsigned long long t[128];
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(t, h->mega_ticks, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+      const int n = (int)h->plan.layers.size();
+      for (int i = 1; i <= n; ++i)
+        fprintf(stderr, "mega layer %2d: %6.2f us (workgroup 0 busy %5.2f us) %s %d -> %d @ %d\n", i,
+                (double)(t[i] - t[i - 1]) * 0.01, i < n ? (double)(t[64 + i] - t[i - 1]) * 0.01 : 0.0,
+                i < n ? (h->plan.layers[i].kind == L_DW ? "dw" : "pw") : "tail", i < n ? h->plan.layers[i].cin : 0,
+                i < n ? h->plan.layers[i].cout : 0, i < n ? h->plan.layers[i].h_out : 0);
+      fprintf(stderr, "mega layers 1..%d + tail: %.2f us\n", n, (double)(t[n] - t[0]) * 0.01);
+    }
+    (void)hipFree(h->mega_ticks);
+  }
+  if (h->mega_status != nullptr) (void)hipHostFree(h->mega_status);
+  if (h->mega_sync != nullptr) (void)hipFree(h->mega_sync);
+  if (h->mega_arena != nullptr) (void)hipFree(h->mega_arena);
   float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x, reinterpret_cast<float*>(h->stats)};
   for (float* p : ptrs)
@@ -261,6 +325,10 @@ int rip_set_option(rip_handle* h, int option, int value) {
     case RIP_OPT_SEARCH_REGROUP:
       REQUIRE(value == 0 || value == 1, "search regroup must be 0 or 1 (got %d)", value);
       h->search_regroup = value;
+      return RIP_OK;
+    case RIP_OPT_ENCODER_MEGA:
+      REQUIRE(value >= -1 && value <= 1, "encoder_mega must be -1 (auto), 0 or 1 (got %d)", value);
+      h->encoder_mega = value;
       return RIP_OK;
     default:
       return fail(RIP_EINVAL, "unknown option %d", option);
@@ -308,6 +376,20 @@ int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channe
   return RIP_OK;
 }
 
+// Does an fp32 encode of B observations take the one-launch kernel?  Never after its protocol failed once.
+static bool mega_applies(const rip_handle* h, int B) {
+  if (h->mega_max_b <= 0 || B > h->mega_max_b || h->encoder_mega == 0) return false;
+  if (*h->mega_status != 0) return false;
+  return h->encoder_mega == 1;  // auto = off: measured 251-273 us against 244 us of layer-wise launches
+}
+
+int rip_encoder_status(rip_handle* h) {
+  if (h == nullptr) return RIP_EINVAL;
+  if (h->mega_status == nullptr || *h->mega_status == 0) return 0;
+  h->mega_reported = true;
+  return *h->mega_status;
+}
+
 int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
                int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream) {
   int rc = check_models(h, k_begin, k_count);
@@ -320,6 +402,12 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   if (enc_dtype == RIP_ENC_BF16) {
     HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
                                 feat_dev, h->encoder_fused, (hipStream_t)stream));
+    return RIP_OK;
+  }
+  if (mega_applies(h, B)) {
+    HIP_TRY(launch_encoder_mega(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->mega_arena, h->mega_stride,
+                                h->mega_sync, h->mega_status, h->mega_ticks, z_dev, feat_dev, h->mega_wgs,
+                                (hipStream_t)stream));
     return RIP_OK;
   }
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,

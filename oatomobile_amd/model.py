@@ -188,10 +188,13 @@ class ImitativeModel(nn.Module):
     if self._dirty:
       self._hip[0].load_model(0, self.packed_weights())
       self._dirty = False
-    fused = getattr(self, "fused_encoder", None)
-    if fused is not None and self._options_applied != (id(self._hip[0]), int(fused)):
-      self._hip[0].set_option(_lib.OPT_ENCODER_FUSED, int(fused))
-      self._options_applied = (id(self._hip[0]), int(fused))
+    fused, mega = getattr(self, "fused_encoder", None), getattr(self, "mega_encoder", None)
+    if (fused is not None or mega is not None) and self._options_applied != (id(self._hip[0]), fused, mega):
+      if fused is not None:
+        self._hip[0].set_option(_lib.OPT_ENCODER_FUSED, int(fused))
+      if mega is not None:  # experimental one-launch fp32 encoder: 1 = up to 4 observations, 0 / -1 never
+        self._hip[0].set_option(_lib.OPT_ENCODER_MEGA, int(mega))
+      self._options_applied = (id(self._hip[0]), fused, mega)
     return self._hip[0]
 
   # -- reference API -------------------------------------------------------------------------

@@ -166,6 +166,92 @@ def test_layerwise_encoder_matches_fused(golden, dev):
       np.testing.assert_allclose(z[i], g["z_w5_o%d" % os_], atol=TOL, err_msg="fused_blocks=%d" % nfused)
 
 
+def _status(handle):
+  from oatomobile_amd import _lib
+  return _lib.load().rip_encoder_status(handle.raw)
+
+
+def test_mega_encoder_matches_layerwise(golden, dev):
+  """RIP_OPT_ENCODER_MEGA: the fp32 encoder of a small batch as ONE persistent launch (model k on XCD k % 8, layer
+  barriers in that XCD's L2) against the 55 layer-wise launches: the same layer arithmetic (tile shapes may differ:
+  last-bit differences), the golden z of g5 at 1e-4, and a status word that stays 0."""
+  g = golden("g5_params.npz")
+  m = hip_model(5, dev, max_batch=4)
+  obs = [synth_observation(np.random.default_rng(50 + i)) for i in range(4)]
+  for b in (1, 2, 4):
+    ctx = ctx_tensors(obs[:b], dev)
+    m.mega_encoder = 0
+    z0 = m._params(**ctx).cpu().numpy()
+    f0 = m.encoder_features(ctx["visual_features"]).cpu().numpy()
+    m.mega_encoder = 1
+    z1 = m._params(**ctx).cpu().numpy()
+    f1 = m.encoder_features(ctx["visual_features"]).cpu().numpy()
+    torch.cuda.synchronize()
+    assert _status(m._handle()) == 0
+    print("mega vs layer-wise, B = %d: max|dz| = %.3g, max|dfeat| = %.3g (max|feat| %.3g)" %
+          (b, np.abs(z1 - z0).max(), np.abs(f1 - f0).max(), np.abs(f0).max()))
+    np.testing.assert_allclose(z1, z0, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(f1, f0, atol=2e-5, rtol=2e-5)
+    for i, os_ in enumerate((50, 51)[:b]):
+      np.testing.assert_allclose(z1[i], g["z_w5_o%d" % os_], atol=TOL)
+      np.testing.assert_allclose(f1[i], g["feat_w5_o%d" % os_], atol=TOL)
+  # auto (the default) = the launches
+  m.mega_encoder = -1
+  ctx = ctx_tensors(obs[:1], dev)
+  za = m._params(**ctx).cpu().numpy()
+  m.mega_encoder = 0
+  np.testing.assert_array_equal(za, m._params(**ctx).cpu().numpy())
+
+
+def test_mega_encoder_repeats_and_ensemble(dev):
+  """The barrier counters re-arm themselves at the end of every launch: 200 back-to-back launches (no host sync in
+  between) give bit-identical z; a K = 4 ensemble (XCDs 0..3 busy, 4..7 idle) and a K = 8 one (every XCD) agree with
+  the layer-wise launches, and with the per-model handles."""
+  from oatomobile_amd import ImitativeModel, RIPAgent, _lib
+  lib = _lib.load()
+  obs = [synth_observation(np.random.default_rng(300 + i)) for i in range(2)]
+  for K in (4, 8):
+    models = [ImitativeModel.synthetic(700 + k, max_batch=2).to(dev) for k in range(K)]
+    agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=2, device=dev)
+    h = agent._handle
+    for b in (1, 2):
+      ctx = ctx_tensors(obs[:b], dev)
+      vis = ctx["visual_features"].contiguous()
+      vec = torch.cat([ctx["velocity"], ctx["is_at_traffic_light"], ctx["traffic_light_state"]], dim=-1).contiguous()
+      zs = {}
+      for mega in (0, 1):
+        h.set_option(_lib.OPT_ENCODER_MEGA, mega)
+        z = torch.empty(K, b, 64, device=dev)
+        reps = 200 if (mega == 1 and K == 4 and b == 1) else 3
+        outs = []
+        for _ in range(reps):
+          zi = torch.empty(K, b, 64, device=dev)
+          _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, K, 0, _lib.ptr(zi), None, h.stream()))
+          outs.append(zi)
+        torch.cuda.synchronize()
+        assert _status(h) == 0
+        for zi in outs[1:]:
+          assert torch.equal(zi, outs[0])
+        zs[mega] = outs[0].cpu().numpy()
+      np.testing.assert_allclose(zs[1], zs[0], atol=2e-5, rtol=2e-5)
+      for k in (0, K - 1):
+        models[k].mega_encoder = 0
+        zk = models[k]._params(**ctx).cpu().numpy()
+        np.testing.assert_allclose(zs[1][k], zk, atol=2e-5, rtol=2e-5)
+    # a sub-range of the ensemble (model-parallel ranks encode their own slice): members 1..2 on XCDs 0..1
+    h.set_option(_lib.OPT_ENCODER_MEGA, 1)
+    zsub = torch.empty(2, 1, 64, device=dev)
+    ctx = ctx_tensors(obs[:1], dev)
+    vis = ctx["visual_features"].contiguous()
+    vec = torch.cat([ctx["velocity"], ctx["is_at_traffic_light"], ctx["traffic_light_state"]], dim=-1).contiguous()
+    _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), 1, 1, 2, 0, _lib.ptr(zsub), None, h.stream()))
+    zall = torch.empty(K, 1, 64, device=dev)
+    _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), 1, 0, K, 0, _lib.ptr(zall), None, h.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(zsub, zall[1:3])
+    assert _status(h) == 0
+
+
 def test_bf16_encoder_close_to_fp32(dev):
   """BASELINE config 3: bf16 encoder (activations + pointwise weights bf16, fp32 accumulate).  The tolerance on z is
   the bf16 one (reported, not 1e-4): 52 layers of 2^-9 relative rounding."""

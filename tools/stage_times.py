@@ -16,6 +16,7 @@ def main():
   ap.add_argument("--algorithm", default="WCM")
   ap.add_argument("--enc", default="fp32")
   ap.add_argument("--fused", type=int, default=-1, help="RIP_OPT_ENCODER_FUSED (-1 = auto)")
+  ap.add_argument("--mega", type=int, default=-1, help="RIP_OPT_ENCODER_MEGA (-1 auto, 0 never, 1 up to 4 observations)")
   ap.add_argument("--search-kernel", type=int, default=0, help="RIP_OPT_SEARCH_KERNEL (0 auto, 1 chain, 2 mfma, 3 phase, 4 split)")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
@@ -26,6 +27,7 @@ def main():
   lib, h = _lib.load(), agent._handle.raw
   _lib.check(lib.rip_set_option(h, 1, args.fused))
   _lib.check(lib.rip_set_option(h, 0, args.search_kernel))
+  _lib.check(lib.rip_set_option(h, 3, args.mega))
   lidar, vec, goal = (torch.from_numpy(a).to(dev) for a in synth_batch(np.random.default_rng(0), B, 2))
   x0 = agent._x0(B)
   z = torch.empty(K, B, 64, device=dev); plan = torch.empty(B, 4, 2, device=dev); loss = torch.empty(B, N, device=dev)
@@ -45,6 +47,7 @@ def main():
   torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / args.iters
   enc = np.median([e[0].elapsed_time(e[1]) for e in ev]) * 1e3
   sea = np.median([e[1].elapsed_time(e[2]) for e in ev]) * 1e3
+  assert lib.rip_encoder_status(h) == 0
   print("B=%d K=%d N=%d: encode %.1f us, search %.1f us, wall/iter %.1f us -> %.0f calls/s" % (B, K, N, enc, sea, wall * 1e6, B / wall))
 
 
