@@ -238,34 +238,6 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     h->stats = reinterpret_cast<unsigned long long*>(tmp);
     (void)hipMemset(h->stats, 0, sizeof(unsigned long long));
   }
-  // one-launch encoder: only where workgroup i of a launch lands on XCD i % 8 (checked once per device)
-  if (encoder_mega_probe(device)) {
-    int mb = max_batch < 4 ? max_batch : 4;
-    while (mb > 0 && !encoder_mega_supported(h->plan, mb, K)) --mb;
-    if (mb > 0) {
-      h->mega_stride = encoder_mega_arena_floats(h->plan, mb);
-      ALLOC(h->mega_arena, (size_t)K * h->mega_stride);
-      float* tmp = nullptr;
-      ALLOC(tmp, 8 * 64);
-      h->mega_sync = reinterpret_cast<unsigned*>(tmp);
-      (void)hipMemset(h->mega_sync, 0, 8 * 64 * sizeof(unsigned));
-      if (hipHostMalloc((void**)&h->mega_status, 64, hipHostMallocDefault) != hipSuccess) h->mega_status = nullptr;
-      if (h->mega_status != nullptr) {
-        *h->mega_status = 0;
-        h->mega_max_b = mb;
-      }
-      if (const char* e = getenv("RIP_MEGA_WGS")) {  // development: workgroups per XCD
-        const int v = atoi(e);
-        if (v >= 1 && v <= 128) h->mega_wgs = v;
-      }
-      if (const char* e = getenv("RIP_MEGA_TICKS"); e != nullptr && e[0] == '1') {
-        float* t2 = nullptr;
-        ALLOC(t2, 2 * 128);
-        h->mega_ticks = reinterpret_cast<unsigned long long*>(t2);
-        (void)hipMemset(h->mega_ticks, 0, 128 * sizeof(unsigned long long));
-      }
-    }
-  }
   // scratch of the MFMA search kernels (adjoint tape, prefix table): 0 when neither can ever run for this handle
   h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
   if (search_phase_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
@@ -311,6 +283,43 @@ int rip_destroy(rip_handle* h) {
   return RIP_OK;
 }
 
+// Scratch of the one-launch encoder, allocated when the option is first switched on (rip_set_option is not a stream
+// call).  Only where workgroup i of a launch lands on XCD i % 8 (probed once per device); false = not available here.
+static bool mega_setup(rip_handle* h) {
+  if (h->mega_max_b > 0) return true;
+  if (!encoder_mega_probe(h->device)) return false;
+  int mb = h->max_batch < 4 ? h->max_batch : 4;
+  while (mb > 0 && !encoder_mega_supported(h->plan, mb, h->K)) --mb;
+  if (mb <= 0) return false;
+  h->mega_stride = encoder_mega_arena_floats(h->plan, mb);
+  bool ok = hipMalloc((void**)&h->mega_arena, (size_t)h->K * h->mega_stride * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->mega_sync, 8 * 64 * sizeof(unsigned)) == hipSuccess;
+  ok = ok && hipMemset(h->mega_sync, 0, 8 * 64 * sizeof(unsigned)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&h->mega_status, 64, hipHostMallocDefault) == hipSuccess;
+  if (const char* e = getenv("RIP_MEGA_TICKS"); ok && e != nullptr && e[0] == '1') {  // development
+    ok = hipMalloc((void**)&h->mega_ticks, 128 * sizeof(unsigned long long)) == hipSuccess &&
+         hipMemset(h->mega_ticks, 0, 128 * sizeof(unsigned long long)) == hipSuccess;
+  }
+  if (!ok) {
+    if (h->mega_arena != nullptr) (void)hipFree(h->mega_arena);
+    if (h->mega_sync != nullptr) (void)hipFree(h->mega_sync);
+    if (h->mega_status != nullptr) (void)hipHostFree(h->mega_status);
+    if (h->mega_ticks != nullptr) (void)hipFree(h->mega_ticks);
+    h->mega_arena = nullptr;
+    h->mega_sync = nullptr;
+    h->mega_status = nullptr;
+    h->mega_ticks = nullptr;
+    return false;
+  }
+  *h->mega_status = 0;
+  if (const char* e = getenv("RIP_MEGA_WGS")) {  // development: workgroups per XCD
+    const int v = atoi(e);
+    if (v >= 1 && v <= 128) h->mega_wgs = v;
+  }
+  h->mega_max_b = mb;
+  return true;
+}
+
 int rip_set_option(rip_handle* h, int option, int value) {
   REQUIRE(h != nullptr, "handle is NULL");
   switch (option) {
@@ -328,6 +337,11 @@ int rip_set_option(rip_handle* h, int option, int value) {
       return RIP_OK;
     case RIP_OPT_ENCODER_MEGA:
       REQUIRE(value >= -1 && value <= 1, "encoder_mega must be -1 (auto), 0 or 1 (got %d)", value);
+      if (value == 1) {
+        DeviceScope scope(h->device);
+        if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(scope.err));
+        (void)mega_setup(h);  // not available (placement probe / memory): the option is accepted and has no effect
+      }
       h->encoder_mega = value;
       return RIP_OK;
     default:
@@ -378,7 +392,7 @@ int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channe
 
 // Does an fp32 encode of B observations take the one-launch kernel?  Never after its protocol failed once.
 static bool mega_applies(const rip_handle* h, int B) {
-  if (h->mega_max_b <= 0 || B > h->mega_max_b || h->encoder_mega == 0) return false;
+  if (h->mega_max_b <= 0 || B > h->mega_max_b || h->encoder_mega != 1) return false;
   if (*h->mega_status != 0) return false;
   return h->encoder_mega == 1;  // auto = off: measured 251-273 us against 244 us of layer-wise launches
 }

@@ -20,5 +20,5 @@ python - <<'PY'
 import csv,glob
 f=glob.glob("gpurun_out/trainprof/stats/**/*kernel_stats.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
-for r in rows[:16]: print("%-70s calls %5s total_ms %8.2f avg_us %8.1f  %s%%"%(r["Name"].replace("void rip::(anonymous namespace)::","")[:70], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3, r["Percentage"]))
+for r in rows[:30]: print("%-70s calls %5s total_ms %8.2f avg_us %8.1f  %s%%"%(r["Name"].replace("void rip::(anonymous namespace)::","")[:70], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3, r["Percentage"]))
 PY
