@@ -306,14 +306,18 @@ int rip_train_num_layers(const rip_trainer* t);
  *     the layer-wise launches (tile shapes may differ: last-bit differences).  The kernel relies on
  *     the hardware placing workgroup i of a launch on XCD i % 8 (verified once per device at rip_create; the option is
  *     ignored where that does not hold); every workgroup re-checks its placement and every barrier wait is bounded
- *     (20 ms) — see rip_encoder_status. */
-enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2, RIP_OPT_ENCODER_MEGA = 3 };
+ *     (20 ms) — see rip_encoder_status.
+ *   RIP_OPT_DEBUG_ENCODER_FAULT (tests only): value 1 / 2 raises the one-launch encoder's failure word as its kernel
+ *     would after a placement miss / barrier timeout (RIP_ESTATE unless RIP_OPT_ENCODER_MEGA = 1 set the protocol up). */
+enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2, RIP_OPT_ENCODER_MEGA = 3,
+       RIP_OPT_DEBUG_ENCODER_FAULT = 4 };
 int rip_set_option(rip_handle* h, int option, int value);
 
 /* 0, or non-zero once a one-launch encoder call (RIP_OPT_ENCODER_MEGA) found a workgroup off its XCD (1) or gave up
  * waiting at a layer barrier (2): the z of THAT call is invalid.  Read it after synchronising the stream of the call
  * (a host word, no device access); from then on the handle uses the layer-wise launches, so repeating the call gives
- * the valid result (oatomobile_amd/agents.py does exactly that).  A caller that never asks gets RIP_ESTATE from the
+ * the valid result (oatomobile_amd/agents.py does exactly that).  ONE-SHOT: the failure is handed out once; every later
+ * call returns 0 (the handle stays on the layer-wise launches).  A caller that never asks gets RIP_ESTATE from the
  * first entry point it calls after the failure became visible — once, so that the failure cannot pass unnoticed. */
 int rip_encoder_status(rip_handle* h);
 

@@ -79,7 +79,7 @@ ABI_VERSION = 3
 
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
-OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED, OPT_SEARCH_REGROUP, OPT_ENCODER_MEGA = 0, 1, 2, 3
+OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED, OPT_SEARCH_REGROUP, OPT_ENCODER_MEGA, OPT_DEBUG_ENCODER_FAULT = 0, 1, 2, 3, 4
 SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2, "phase": 3, "split": 4}
 
 _lib = None

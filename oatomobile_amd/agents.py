@@ -376,7 +376,7 @@ class RIPAgent(SetPointAgent):
     self._online[key] = st
     return st
 
-  def __call__(self, observation: Mapping[str, np.ndarray]) -> np.ndarray:
+  def __call__(self, observation: Mapping[str, np.ndarray], _retry: bool = False) -> np.ndarray:
     """Returns the imitative-prior plan [30, 3] in ego coordinates (rip/agent.py:52-151)."""
     # rip/agent.py:59-69 straight into the pinned staging buffer (float32 casts happen in the assignments; shapes that
     # the kernels cannot take raise ValueError like `_prepare_observation`)
@@ -427,9 +427,13 @@ class RIPAgent(SetPointAgent):
       self._eager_pending = False
     if self._enc_status(self._handle.raw):
       # the one-launch encoder found its workgroups off their XCDs or a layer barrier timed out: this call's z is
-      # invalid.  The handle has switched to the layer-wise launches; drop the captured graphs and repeat the call.
+      # invalid.  The handle has switched to the layer-wise launches (for good); drop the captured graphs and repeat
+      # the call ONCE.  rip_encoder_status is one-shot, and the repeat is bounded here as well: a status raised a
+      # second time is an error, not another retry.
+      if _retry:
+        raise RuntimeError("the encoder reported a failure again after falling back to the layer-wise launches")
       self._online = {}
-      return self(observation)
+      return self.__call__(observation, _retry=True)
     return st["plan_h"].numpy()[0].copy()  # [30, 3] float64: R11 ran in the selection kernel
 
 

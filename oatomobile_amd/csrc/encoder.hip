@@ -11,6 +11,7 @@
 #include "flow_split_pack.h"
 #include "flow.h"
 
+#include <mutex>
 #include <cmath>
 #include <cstring>
 
@@ -1201,7 +1202,9 @@ bool encoder_mega_supported(const EncoderPlan& plan, int B, int kc) {
 // Is workgroup i of a launch placed on XCD i % 8 on this device (8 XCDs, round-robin)?  Checked once per device.
 bool encoder_mega_probe(int device) {
   static int cache[64] = {0};  // 0 unknown, 1 yes, 2 no
+  static std::mutex cache_mutex;  // rip_set_option on two handles from two threads
   if (device < 0 || device >= 64) return false;
+  std::lock_guard<std::mutex> lock(cache_mutex);
   if (cache[device] != 0) return cache[device] == 1;
   constexpr int G = 256;
   int* d = nullptr;
@@ -1209,7 +1212,9 @@ bool encoder_mega_probe(int device) {
   if (ok) {
     std::vector<int> hst(G, -1);
     for (int rep = 0; rep < 3 && ok; ++rep) {
-      hipLaunchKernelGGL(mega_probe_kernel, dim3(G), dim3(64), 0, 0, d);
+      hipLaunchKernelGGL(mega_probe_kernel, dim3(G), dim3(64), 0, hipStreamPerThread, d);
+      ok = hipStreamSynchronize(hipStreamPerThread) == hipSuccess;
+      if (!ok) break;
       ok = hipMemcpy(hst.data(), d, G * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
       for (int i = 0; i < G && ok; ++i) ok = hst[i] == (i & 7);
     }

@@ -344,6 +344,13 @@ int rip_set_option(rip_handle* h, int option, int value) {
       }
       h->encoder_mega = value;
       return RIP_OK;
+    case RIP_OPT_DEBUG_ENCODER_FAULT:
+      // test hook: raise the one-launch encoder's failure word as its kernel would (tests of the caller's recovery path)
+      REQUIRE(value == 1 || value == 2, "encoder fault code must be 1 (placement) or 2 (barrier timeout), got %d", value);
+      if (h->mega_status == nullptr) return fail(RIP_ESTATE, "the one-launch encoder is not set up on this handle (RIP_OPT_ENCODER_MEGA = 1 first)");
+      *h->mega_status = value;
+      h->mega_reported = false;
+      return RIP_OK;
     default:
       return fail(RIP_EINVAL, "unknown option %d", option);
   }
@@ -399,7 +406,9 @@ static bool mega_applies(const rip_handle* h, int B) {
 
 int rip_encoder_status(rip_handle* h) {
   if (h == nullptr) return RIP_EINVAL;
-  if (h->mega_status == nullptr || *h->mega_status == 0) return 0;
+  // one-shot: the word itself stays raised (mega_applies keeps the handle on the layer-wise launches), but it is handed
+  // out once — a caller that repeats the failed call and asks again must read 0, not the old failure
+  if (h->mega_status == nullptr || *h->mega_status == 0 || h->mega_reported) return 0;
   h->mega_reported = true;
   return *h->mega_status;
 }
@@ -666,6 +675,11 @@ int rip_interpolate_plans(const float* plan_dev, int B, double* out_dev, rip_str
   REQUIRE(B >= 0, "bad batch B=%d", B);
   REQUIRE(B == 0 || (plan_dev != nullptr && out_dev != nullptr), "NULL argument");
   if (B == 0) return RIP_OK;
+  // stateless: launch on the device that owns the plans, whatever the caller's current device is (like rip_train_adam)
+  hipPointerAttribute_t attr;
+  HIP_TRY(hipPointerGetAttributes(&attr, plan_dev));
+  DeviceScope scope(attr.device);
+  if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", attr.device, hipGetErrorString(scope.err));
   HIP_TRY(launch_interpolate_plans(plan_dev, B, out_dev, (hipStream_t)stream));
   return RIP_OK;
 }

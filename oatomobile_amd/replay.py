@@ -21,31 +21,7 @@ from typing import List, Mapping, Optional, Sequence
 import numpy as np
 import torch
 
-MODALITIES = ("lidar", "velocity", "is_at_traffic_light", "traffic_light_state", "player_future")
-
-
-def load_datum(fname: str, modalities: Sequence[str] = MODALITIES, mode: bool = False,
-               dataformat: str = "HWC") -> Mapping[str, np.ndarray]:
-  """datasets/carla.py:107-164: float32 casts, scalars -> 1-D, optional HWC->CHW, optional driving-mode label
-  ({0 FORWARD, 1 STOP, 2 LEFT, 3 RIGHT} from the last future waypoint), `name` = path."""
-  assert dataformat in ("HWC", "CHW")
-  sample = {}
-  with open(fname, "rb") as f:  # one read of the (small, compressed) file: the zip directory walk then costs no syscalls
-    blob = io.BytesIO(f.read())
-  with np.load(blob) as datum:
-    for attr in modalities:
-      v = np.atleast_1d(datum[attr]).astype(np.float32)
-      if v.ndim == 3 and dataformat == "CHW":
-        v = np.transpose(v, (2, 0, 1))
-      sample[attr] = v
-  if mode and "player_future" in sample:
-    x_T, y_T = sample["player_future"][-1, :2]
-    norm = np.linalg.norm([x_T, y_T])
-    theta = np.degrees(np.arccos(x_T / (norm + 1e-3)))
-    label = 1 if norm < 3 else (2 if theta > 15 else (3 if theta <= -15 else 0))
-    sample["mode"] = np.atleast_1d(label).astype(np.float32)
-  sample["name"] = fname
-  return sample
+from oatomobile_amd._datum import MODALITIES, _fill_rows, goal_from_future, load_datum  # noqa: F401  (torch-free)
 
 
 class Episode:
@@ -112,14 +88,6 @@ def as_torch(dataset_dir: str, modalities: Sequence[str] = MODALITIES, transform
   return _Datums()
 
 
-def goal_from_future(player_future: np.ndarray, num_goals: int = 10, stride: int = 8) -> np.ndarray:
-  """`player_future[stride-1::stride][:num_goals, :2]`, padded by repeating the last waypoint."""
-  g = np.asarray(player_future, dtype=np.float32)[stride - 1::stride][:num_goals, :2]
-  if g.shape[0] < num_goals:
-    g = np.concatenate([g, np.repeat(g[-1:], num_goals - g.shape[0], axis=0)], axis=0)
-  return g
-
-
 def effective_cpus() -> int:
   """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (containers report the
   host's core count in `os.cpu_count()`; worker processes beyond the quota are throttled and slow everything down:
@@ -141,18 +109,6 @@ def effective_cpus() -> int:
     except (OSError, ValueError):
       pass
   return n
-
-
-def _fill_rows(files, j0, lidar, vec, goal, num_goals, goal_stride):
-  """Decodes `files` into rows j0.. of the batch arrays (numpy views; shared memory in the worker processes)."""
-  for j, f in enumerate(files, start=j0):
-    d = load_datum(f)
-    lidar[j] = d["lidar"]
-    vec[j, :3] = d["velocity"].reshape(3)
-    vec[j, 3] = float(d["is_at_traffic_light"].reshape(-1)[0])
-    vec[j, 4] = float(d["traffic_light_state"].reshape(-1)[0])
-    goal[j] = goal_from_future(d["player_future"], num_goals, goal_stride)
-  return len(files)
 
 
 def _decode_worker(w, nworkers, files, batch_size, names, ctrl_name, shapes, ring, num_goals, goal_stride):
@@ -351,57 +307,99 @@ CACHE_FILES = ("codes.npy", "lut.npy", "vec.npy", "goal.npy")
 
 
 def pack_cache(files: Sequence[str], out_dir: str, num_goals: int = 10, goal_stride: int = 8, channels: Optional[int] = None,
-               chunk: int = 256) -> "PackedCache":
+               chunk: int = 256, workers: Optional[int] = None) -> "PackedCache":
   """One-time conversion of datum files (the reference's compressed `.npz`, datasets/carla.py:107-164 — they stay the
   source of truth) into a packed cache under `out_dir`:
 
     codes.npy [n,H,W,C] uint8   the BEV, every cell an index into
-    lut.npy   [256]    float32  the distinct float32 values `load_datum` yields for `lidar` over the whole file list
-                                (the CARLA histogram has six levels, k/5: utils/carla.py:225-233), padded with NaN
+    lut.npy   [256]    float32  the distinct float32 BIT PATTERNS `load_datum` yields for `lidar` over the whole file
+                                list, in ascending order of the pattern read as uint32 (= ascending value for the
+                                non-negative levels k/5 of the CARLA histogram, utils/carla.py:225-233; -0.0 is a value
+                                of its own, after the positive ones), padded with NaN
     vec.npy   [n,5]    float32  velocity[3], is_at_traffic_light, traffic_light_state
     goal.npy  [n,G,2]  float32  `goal_from_future(player_future)`
 
-  `lut[codes]` reproduces `load_datum(...)["lidar"]` bit for bit (checked per chunk while packing; more than 256
-  distinct values raise ValueError: such data is not a clipped histogram and keeps the `.npz` path).  80 KB instead of
-  320 KB per 200 x 200 x 2 observation, read back with `np.load(mmap_mode="r")`: no zip, no zlib, no dtype conversion —
-  what bounds `replay()` at ~1.7 k datums/s per process is gone."""
+  `lut[codes]` reproduces `load_datum(...)["lidar"]` bit for bit — compared as uint32 patterns per chunk while packing,
+  so the sign of a zero survives; more than 256 distinct values or a NaN raise ValueError: such data is not a clipped
+  histogram and keeps the `.npz` path.  80 KB instead of 320 KB per 200 x 200 x 2 observation, read back with
+  `np.load(mmap_mode="r")`: no zip, no zlib, no dtype conversion.
+
+  Packing is embarrassingly parallel: `workers` processes (None = `effective_cpus()`, 0 / 1 = this process) each decode
+  and code a contiguous span of the files straight into the `codes.npy` memmap against their own value table; this
+  process unifies the tables and re-codes the (rare) chunks packed before a value was first seen.  The workers run
+  `_datum.py` as a script: numpy only, no torch import, no inherited HIP context."""
+  from oatomobile_amd import _datum
   n = len(files)
   if n == 0:
     raise ValueError("pack_cache: no files")
+  files = [str(f) for f in files]
   os.makedirs(out_dir, exist_ok=True)
   first = load_datum(files[0])
   H, W, C = first["lidar"].shape
   if channels is not None and C != channels:
     raise ValueError("pack_cache: datums have %d BEV channels, expected %d" % (C, channels))
-  codes = np.lib.format.open_memmap(os.path.join(out_dir, "codes.npy"), mode="w+", dtype=np.uint8, shape=(n, H, W, C))
+  shape = (n, H, W, C)
+  codes = np.lib.format.open_memmap(os.path.join(out_dir, "codes.npy"), mode="w+", dtype=np.uint8, shape=shape)
+  del codes  # the spans open it themselves
+  if workers is None:
+    workers = effective_cpus()
+  workers = max(1, min(int(workers), (n + chunk - 1) // chunk))
   vec = np.empty((n, 5), np.float32)
   goal = np.empty((n, num_goals, 2), np.float32)
-  values = np.empty((0,), np.float32)  # sorted distinct BEV values seen so far
-  for i0 in range(0, n, chunk):
-    part = files[i0:i0 + chunk]
-    lid = np.empty((len(part), H, W, C), np.float32)
-    _fill_rows(part, 0, lid, vec[i0:i0 + len(part)], goal[i0:i0 + len(part)], num_goals, goal_stride)
-    new = np.unique(lid)
-    if np.isnan(new).any():
-      raise ValueError("pack_cache: NaN in a BEV")
-    merged = np.union1d(values, new)
-    if merged.size > 256:
-      raise ValueError("pack_cache: more than 256 distinct BEV values (%d): not a clipped histogram" % merged.size)
-    if merged.size != values.size and i0 > 0:
-      # the table grew: rows packed so far used the old one — repack them (rare: the value set is known after a few frames)
-      old = values
-      remap = np.searchsorted(merged, old).astype(np.uint8)
-      for j0 in range(0, i0, chunk):
-        codes[j0:j0 + chunk] = remap[codes[j0:j0 + chunk]]
-    values = merged
-    c = np.searchsorted(values, lid).astype(np.uint8)
-    if not np.array_equal(values[c], lid):
-      raise RuntimeError("pack_cache: table lookup does not reproduce the BEV")  # cannot happen: values holds every value
-    codes[i0:i0 + len(part)] = c
+  spans = []  # (row0, rows, table the rows were coded against)
+  if workers == 1:
+    spans, vec, goal = _datum.pack_span(files, 0, out_dir, shape, num_goals, goal_stride, chunk)
+  else:
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    per = ((n + workers - 1) // workers + chunk - 1) // chunk * chunk  # whole chunks per worker
+    with tempfile.TemporaryDirectory(prefix="rip_pack_") as tmp:
+      jobs = []
+      for w, i0 in enumerate(range(0, n, per)):
+        job = dict(files=files[i0:i0 + per], i0=i0, out_dir=os.path.abspath(out_dir), shape=list(shape),
+                   num_goals=num_goals, goal_stride=goal_stride, chunk=chunk, result=os.path.join(tmp, "r%d.npz" % w))
+        path = os.path.join(tmp, "j%d.json" % w)
+        with open(path, "w") as fh:
+          json.dump(job, fh)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        jobs.append((job, subprocess.Popen([sys.executable, os.path.abspath(_datum.__file__), path], env=env,
+                                           stderr=subprocess.PIPE)))
+      failure = None
+      for job, proc in jobs:
+        _, err = proc.communicate()
+        if proc.returncode == 3 and failure is None:
+          with open(job["result"] + ".err") as fh:
+            failure = ValueError(fh.read())
+        elif proc.returncode != 0 and failure is None:
+          failure = RuntimeError("pack_cache: a packing worker failed (exit code %d): %s" %
+                                 (proc.returncode, err.decode(errors="replace")[-2000:]))
+        if proc.returncode == 0:
+          with np.load(job["result"]) as r:
+            i0, m = job["i0"], len(job["files"])
+            vec[i0:i0 + m], goal[i0:i0 + m] = r["vec"], r["goal"]
+            off = 0
+            for (row0, rows), size in zip(r["rows"], r["sizes"]):
+              spans.append((int(row0), int(rows), r["tables"][off:off + int(size)].copy()))
+              off += int(size)
+      if failure is not None:
+        raise failure
+  values = np.empty((0,), np.uint32)
+  for _, _, t in spans:
+    values = np.union1d(values, t).astype(np.uint32)
+  if values.size > 256:
+    raise ValueError("pack_cache: more than 256 distinct BEV values (%d): not a clipped histogram" % values.size)
+  stale = [(r0, m, t) for r0, m, t in spans if not np.array_equal(t, values)]
+  if stale:  # coded before a value was first seen (or in a span that never saw it): re-code against the final table
+    codes = np.lib.format.open_memmap(os.path.join(out_dir, "codes.npy"), mode="r+")
+    for r0, m, t in stale:
+      remap = np.searchsorted(values, t).astype(np.uint8)
+      codes[r0:r0 + m] = remap[codes[r0:r0 + m]]
+    codes.flush()
+    del codes
   lut = np.full((256,), np.nan, np.float32)
-  lut[:values.size] = values
-  codes.flush()
-  del codes
+  lut[:values.size] = values.view(np.float32)
   np.save(os.path.join(out_dir, "lut.npy"), lut)
   np.save(os.path.join(out_dir, "vec.npy"), vec)
   np.save(os.path.join(out_dir, "goal.npy"), goal)

@@ -252,6 +252,46 @@ def test_mega_encoder_repeats_and_ensemble(dev):
     assert _status(h) == 0
 
 
+def test_mega_encoder_failure_is_reported_once_and_the_agent_recovers(dev):
+  """`rip_encoder_status` is one-shot.  The failure word of the one-launch encoder is raised through the
+  test hook (RIP_OPT_DEBUG_ENCODER_FAULT) exactly as its kernel raises it; `agent(observation)` must repeat the call
+  ONCE on the layer-wise launches and return the same plan as an agent that never used the one-launch encoder (it
+  used to recurse until RecursionError because the sticky word was read again by every retry)."""
+  from oatomobile_amd import ImitativeModel, RIPAgent, _lib
+  lib = _lib.load()
+  ob = synth_observation(np.random.default_rng(77))
+  models = [ImitativeModel.synthetic(710 + k, max_batch=1) for k in range(2)]
+  ref_agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=1, device=dev)
+  want = ref_agent(dict(ob))
+  models2 = [ImitativeModel.synthetic(710 + k, max_batch=1) for k in range(2)]
+  agent = RIPAgent(None, algorithm="WCM", models=models2, num_candidates=16, max_batch=1, device=dev)
+  h = agent._handle
+  h.set_option(_lib.OPT_ENCODER_MEGA, 1)
+  if lib.rip_set_option(h.raw, _lib.OPT_DEBUG_ENCODER_FAULT, 2) != 0:
+    pytest.skip("one-launch encoder not available on this device (placement probe): nothing to recover from")
+  assert lib.rip_encoder_status(h.raw) == 2 and lib.rip_encoder_status(h.raw) == 0  # handed out once
+  # a fresh agent: its first call captures the hipGraph WITH the one-launch kernel; the word is then raised as that
+  # kernel would raise it during a replay (after the call's entry points ran, visible after the stream sync)
+  models3 = [ImitativeModel.synthetic(710 + k, max_batch=1) for k in range(2)]
+  agent = RIPAgent(None, algorithm="WCM", models=models3, num_candidates=16, max_batch=1, device=dev)
+  h = agent._handle
+  h.set_option(_lib.OPT_ENCODER_MEGA, 1)
+  first = agent(dict(ob))
+  np.testing.assert_allclose(first, want, atol=TOL)
+  _lib.check(lib.rip_set_option(h.raw, _lib.OPT_DEBUG_ENCODER_FAULT, 2))
+  import sys
+  limit = sys.getrecursionlimit()
+  sys.setrecursionlimit(200)  # the old behaviour fails fast instead of re-capturing 1000 graphs
+  try:
+    got = agent(dict(ob))
+    again = agent(dict(ob))
+  finally:
+    sys.setrecursionlimit(limit)
+  np.testing.assert_allclose(got, want, atol=TOL)
+  np.testing.assert_array_equal(got, again)
+  assert lib.rip_encoder_status(h.raw) == 0
+
+
 def test_bf16_encoder_close_to_fp32(dev):
   """BASELINE config 3: bf16 encoder (activations + pointwise weights bf16, fp32 accumulate).  The tolerance on z is
   the bf16 one (reported, not 1e-4): 52 layers of 2^-9 relative rounding."""

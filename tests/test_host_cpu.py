@@ -399,6 +399,20 @@ def test_packed_replay_cache_round_trip(tmp_path):
   assert got == [(4, (4, 5), (4, 10, 2)), (3, (3, 5), (3, 10, 2))]
   reopened = replay.PackedCache(str(tmp_path / "cache"))
   np.testing.assert_array_equal(np.asarray(reopened.codes), np.asarray(cache.codes))
+  # the worker processes and the in-process packer write the same cache (codes, table, vectors, goals)
+  serial = replay.pack_cache(files, str(tmp_path / "cache_serial"), chunk=3, workers=1)
+  for name in ("codes", "lut", "vec", "goal"):
+    np.testing.assert_array_equal(np.asarray(getattr(serial, name)), np.asarray(getattr(cache, name)))
+  # -0.0 is a bit pattern of its own (float comparison would merge it with +0.0: ADVICE r3)
+  ep3 = replay.Episode(str(tmp_path), "negzero")
+  lid = synth_observation(np.random.default_rng(5))["lidar"].copy()
+  lid[0, :7, 0] = -0.0
+  ep3.append("z0", lidar=lid, velocity=np.zeros(3, np.float32), is_at_traffic_light=np.zeros(1, np.float32),
+             traffic_light_state=np.zeros(1, np.float32), player_future=np.ones((80, 3), np.float32))
+  cz = replay.pack_cache(ep3.files(), str(tmp_path / "cache3"))
+  back = cz.lidar(0)
+  np.testing.assert_array_equal(back.view(np.uint32), replay.load_datum(ep3.files()[0])["lidar"].view(np.uint32))
+  assert np.signbit(back[0, :7, 0]).all() and not np.signbit(back[0, 7:, 0]).any()
   ep2 = replay.Episode(str(tmp_path), "noisy")
   ep2.append("n0", lidar=rng.random((200, 200, 2)).astype(np.float32), velocity=np.zeros(3, np.float32),
              is_at_traffic_light=np.zeros(1, np.float32), traffic_light_state=np.zeros(1, np.float32),
