@@ -104,6 +104,17 @@ int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channe
 int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
                int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream);
 
+/* Diagnostics tap (tests: every conv layer of the encoder against the oracle, teacher-forced).  Runs model k's encoder
+ * on B observations with the handle's CURRENT kernel selection up to and including conv layer `layer` (network order of
+ * torchvision's `features`: 0 = features.0, then [expand,] depthwise, project of features.1..17, 51 = features.18 — the
+ * reference builds it at torch/networks/perception.py:36-51) and writes that layer's output as fp32:
+ * `dst_dev` [B][H][W][C] (NHWC; bf16 activations are widened exactly), or [B][1280] for layer 51, whose 4x4 average
+ * pool is part of its epilogue.  `dst_numel` must be exactly that size.  Overwrites the handle's activation workspace;
+ * z is not produced.  RIP_EINVAL when the layer's output never reaches memory under the current
+ * RIP_OPT_ENCODER_FUSED setting (an interior layer of a fused block). */
+int rip_encode_tap(rip_handle* h, const float* visual_dev, int B, int k, int enc_dtype, int layer, float* dst_dev,
+                   size_t dst_numel, rip_stream_t stream);
+
 /* Fused R2+R3+R4 for the agent's hot loop: raw sensor BEV [B,H,W,C]
  * (channels_last=1) or [B,C,H,W] -> z (any H, W >= 1 like F.interpolate; the
  * CARLA sensor gives 200 x 200).  Same results as rip_transform + rip_encode. */

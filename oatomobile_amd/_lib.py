@@ -21,6 +21,7 @@ SIGNATURES = [
     ("rip_load_model", c_int, [c_void_p, c_int, c_void_p, c_size_t]),
     ("rip_transform", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("rip_encode", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("rip_encode_tap", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     ("rip_encode_raw", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("rip_encode_raw_u8", c_int,

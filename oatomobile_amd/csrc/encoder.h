@@ -42,6 +42,17 @@ struct EncoderPlan {
 
 EncoderPlan build_encoder_plan(int in_channels);
 
+// Diagnostics tap (rip_encode_tap): stop the encoder after conv layer `layer` (network order) and hand its output out as
+// fp32 — `dst` [kc][B][H][W][C] (NHWC), or [kc][B][1280] for the last layer, whose 4x4 average pool is fused into its
+// epilogue.  `served` stays false when the layer's output never reaches memory under the kernel selection in force
+// (an interior layer of a fused block).
+struct EncoderTap {
+  int layer = -1;
+  float* dst = nullptr;
+  bool served = false;
+};
+hipError_t launch_tap_copy(const void* src, bool src_bf16, size_t n, float* dst, hipStream_t s);
+
 // Folds BN and re-lays the packed reference tensors (arch.py:packed_spec order) into the encoder blob
 // and the flow blob (flow.h layout).  Returns false (and a message) on size mismatch.
 bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc_blob,
@@ -60,7 +71,7 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
 //   the rest layer by layer.
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s);
+                          hipStream_t s, EncoderTap* tap = nullptr);
 
 // The whole fp32 encoder of a small batch as ONE persistent launch, model k on XCD k % 8 (encoder.hip:
 // encoder_mega_kernel).  arena: kc * arena_model_stride floats, arena_model_stride >= encoder_mega_arena_floats(B);
@@ -83,7 +94,7 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
 //   supports) run as one row-streaming kernel each (encoder_bf16_irb.hip); -1 = choose by batch.
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
-                               float* feat, int fused_blocks, hipStream_t s);
+                               float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap = nullptr);
 
 bool irb_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
 hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,

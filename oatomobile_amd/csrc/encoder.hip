@@ -1076,9 +1076,35 @@ hipError_t launch_transform_coded(const uint8_t* in, const float* lut, int B, in
   return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void tap_copy_kernel(const void* __restrict__ src, int src_bf16, size_t n,
+                                                        float* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dst[i] = src_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(src)[i] << 16)
+                      : reinterpret_cast<const float*>(src)[i];
+}
+}  // namespace
+
+hipError_t launch_tap_copy(const void* src, bool src_bf16, size_t n, float* dst, hipStream_t s) {
+  size_t grid = (n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(tap_copy_kernel, dim3((unsigned)grid), dim3(256), 0, s, src, src_bf16 ? 1 : 0, n, dst);
+  return hipGetLastError();
+}
+
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s) {
+                          hipStream_t s, EncoderTap* tap) {
+  // the tap: after the launch that completes layer `li`, copy its output out and stop
+  auto tapped = [&](size_t li) -> bool {
+    if (tap == nullptr || tap->layer != (int)li) return false;
+    const Layer& l = plan.layers[li];
+    const bool pooled = li + 1 == plan.layers.size() && plan.final_hw == 4;
+    const size_t n = (size_t)kc * B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
+    (void)launch_tap_copy(bufs[l.dst], false, n, tap->dst, s);
+    tap->served = true;
+    return true;
+  };
   const size_t ms = plan.blob_floats;
   std::vector<char> in_block(plan.layers.size(), 0);
   {
@@ -1098,6 +1124,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       hipError_t e = launch_fused_block(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw],
                                         plan.layers[fb.project], enc_w, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
       if (e != hipSuccess) return e;
+      if (tapped(li)) return hipGetLastError();
       continue;
     }
     float* dst = bufs[l.dst];
@@ -1116,7 +1143,9 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       const bool pool = li + 1 == plan.layers.size() && plan.final_hw == 4;  // features.18: fuse the 4x4 average pool
       dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, pool, s);
     }
+    if (tapped(li)) return hipGetLastError();
   }
+  if (tap != nullptr) return hipGetLastError();  // an interior layer of a fused block: not served
   return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], plan.final_hw == 4 ? 1 : plan.final_hw * plan.final_hw, vec,
                      B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
 }

@@ -1075,8 +1075,19 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
 
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
-                               float* feat, int fused_blocks, hipStream_t s) {
+                               float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap) {
   const size_t ms = plan.blob_floats;
+  // the tap: after the launch that completes layer `li`, copy its output out (as fp32) and stop
+  auto tapped = [&](size_t li) -> bool {
+    if (tap == nullptr || tap->layer != (int)li) return false;
+    const Layer& l = plan.layers[li];
+    const bool last = li + 1 == plan.layers.size();  // features.18: fp32, pooled when the map is 4x4
+    const bool pooled = last && plan.final_hw == 4;
+    const size_t n = (size_t)kc * B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
+    (void)launch_tap_copy(bufs[l.dst], !last, n, tap->dst, s);
+    tap->served = true;
+    return true;
+  };
   // inverted-residual blocks as one fused kernel each.  auto (measured, K = 4): the front kernel and the row-streaming
   // blocks (features.0-7) win at every batch size (B = 1: 304 vs 311 us, B = 4: 359 vs 401); the tile blocks
   // (features.8-16, one workgroup per 1-8 observations walking 6-15 hidden chunks in sequence) from 64 (model,
@@ -1110,6 +1121,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     hipError_t e = launch_front_bf16(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc,
                                      B, visual, reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
     if (e != hipSuccess) return e;
+    if (tapped((size_t)fb.project)) return hipGetLastError();
   }
   (void)front;
   for (size_t li = 0; li < plan.layers.size(); ++li) {
@@ -1122,6 +1134,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
           le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc, B,
           reinterpret_cast<const unsigned short*>(bufs[fb.src]), reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
       if (e != hipSuccess) return e;
+      if (tapped(li)) return hipGetLastError();
       continue;
     }
     bf16_t* dst = reinterpret_cast<bf16_t*>(bufs[l.dst]);
@@ -1172,7 +1185,9 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
       dispatch_pwb(reinterpret_cast<const bf16_t*>(bufs[l.src]), enc_wh, enc_w, ms, k0, kc, l, res,
                    reinterpret_cast<void*>(bufs[l.dst]), M, last, pool, s);
     }
+    if (tapped(li)) return hipGetLastError();
   }
+  if (tap != nullptr) return hipGetLastError();  // an interior layer of a fused block: not served
   return launch_tail(plan, enc_w, k0, kc, bufs[plan.final_buf], plan.final_hw == 4 ? 1 : plan.final_hw * plan.final_hw, vec,
                      B, bufs[(plan.final_buf + 1) & 3], z, feat, s);
 }

@@ -438,6 +438,35 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   return RIP_OK;
 }
 
+int rip_encode_tap(rip_handle* h, const float* visual_dev, int B, int k, int enc_dtype, int layer, float* dst_dev,
+                   size_t dst_numel, rip_stream_t stream) {
+  int rc = check_models(h, k, 1);
+  if (rc != RIP_OK) return rc;
+  REQUIRE(visual_dev != nullptr && dst_dev != nullptr, "NULL argument");
+  REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
+  REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
+  const int L = (int)h->plan.layers.size();
+  REQUIRE(layer >= 0 && layer < L, "layer %d outside [0,%d)", layer, L);
+  const Layer& l = h->plan.layers[layer];
+  const bool pooled = layer + 1 == L && h->plan.final_hw == 4;
+  const size_t need = (size_t)B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
+  REQUIRE(dst_numel == need, "dst_numel=%zu, layer %d of B=%d observations has %zu elements", dst_numel, layer, B, need);
+  ENTER(h, stream);
+  EncoderTap tap;
+  tap.layer = layer;
+  tap.dst = dst_dev;
+  if (enc_dtype == RIP_ENC_BF16)
+    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k, 1, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
+                                h->encoder_fused, (hipStream_t)stream, &tap));
+  else
+    HIP_TRY(launch_encoder(h->plan, h->enc_w, k, 1, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
+                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap));
+  if (!tap.served)
+    return fail(RIP_EINVAL, "layer %d is inside a fused block under the current RIP_OPT_ENCODER_FUSED setting: its output "
+                "never reaches memory (tap the block's last layer, or set the option to 0)", layer);
+  return RIP_OK;
+}
+
 int rip_encode_raw(rip_handle* h, const float* lidar_dev, int channels_last, int H, int W, const float* vec_dev, int B,
                    int k_begin, int k_count, int enc_dtype, float* z_dev, rip_stream_t stream) {
   int rc = check_models(h, k_begin, k_count);

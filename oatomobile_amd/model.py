@@ -282,6 +282,21 @@ class ImitativeModel(nn.Module):
                                       h.stream()))
     return feat
 
+  def encoder_layer_output(self, visual_features: torch.Tensor, layer: int) -> torch.Tensor:
+    """Diagnostics (rip_encode_tap): the output of conv layer `layer` (index into `arch.conv_layers()`) under the
+    model's current `encoder_dtype` / `fused_encoder` selection, as fp32 NCHW [B,C,H,W] ([B,1280] for the last layer,
+    whose average pool is fused into it).  `_lib.RipError` (RIP_EINVAL) when that layer is interior to a fused block."""
+    vis = _f32c(visual_features)
+    _require_device(vis, "visual_features")
+    b = vis.shape[0]
+    spec = arch.conv_layers(self._in_channels)[layer]
+    last = layer + 1 == len(arch.conv_layers(self._in_channels))
+    out = torch.empty((b, spec.cout) if last else (b, spec.h_out, spec.h_out, spec.cout), device=vis.device)
+    h = self._handle()
+    _lib.check(_lib.load().rip_encode_tap(h.raw, _lib.ptr(vis), b, 0, _lib.ENC_DTYPES[getattr(self, "encoder_dtype", "fp32")],
+                                          int(layer), _lib.ptr(out), out.numel(), h.stream()))
+    return out if last else out.permute(0, 3, 1, 2).contiguous()
+
   def transform(self, sample: Mapping[str, torch.Tensor]) -> Mapping[str, torch.Tensor]:
     """dim/model.py:221-253: mutates and returns `sample` (lidar -> visual_features, 200->100 + H/W swap;
     player_future subsampled to T steps)."""

@@ -48,6 +48,14 @@ class DIMTrainer:
     self._lr, self._wd, self._noise = float(lr), float(weight_decay), float(noise_level)
     self._betas, self._eps = (float(betas[0]), float(betas[1])), float(eps)
     self._group = group
+    if group is None and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1:
+      # torch's convention is group=None == the default WORLD group; here None means "do not reduce" (ranks that train
+      # independent ensemble members).  Say so once instead of silently training unsynchronised replicas.
+      import warnings
+      warnings.warn("DIMTrainer(group=None) in a %d-rank job: gradients are NOT all-reduced (independent replicas).  "
+                    "Pass group=torch.distributed.group.WORLD for data-parallel training." %
+                    torch.distributed.get_world_size(), stacklevel=2)
     self._max_batch = int(max_batch)
     self._lib = _lib.load()
     n = int(self._lib.rip_train_numel(self._C))

@@ -1,0 +1,145 @@
+"""TEST INFRASTRUCTURE — CPU restatement of the encoder in the arithmetic BASELINE configs[2] names ("bf16 encoder").
+
+The reference computes the MobileNetV2 encoder in fp32 (oatomobile/torch/networks/perception.py:25-55 ->
+torchvision v0.6.0 `mobilenet_v2`; `oracle/mobilenet_v2.py` is the published module tree).  The headline
+configuration stores activations and pointwise weights in bfloat16.  This module is the fp32 restatement with the
+roundings of that storage format applied at exactly the points the HIP bf16 path applies them
+(`oatomobile_amd/csrc/encoder_bf16*.hip`), so that the bf16 kernels have an oracle of their own instead of a 10 % gate
+against the fp32 one:
+
+  * BatchNorm (eval mode, running statistics) is folded into the preceding conv in float64 and the result is rounded to
+    fp32 (`scale = gamma / sqrt(var + 1e-5)`, `w' = fp32(w * scale)`, `b' = fp32(beta - mean * scale)`) — the
+    definition `fold_and_pack` (csrc/encoder.hip) implements;
+  * pointwise (1x1) weights are rounded to bf16 (round to nearest even); stem and depthwise taps and every bias stay fp32
+    (`dw_weights_bf16=True` rounds the depthwise taps as well: the definition a `v_dot2_f32_bf16` depthwise uses);
+  * the network input (`visual_features`, fp32) is NOT rounded: the stem reads fp32;
+  * every layer computes in fp32 (conv -> + bias -> [ReLU6] -> [+ residual, read back as the bf16 it was stored as])
+    and its OUTPUT is rounded to bf16 once — except `features.18`, whose output stays fp32 for the fp32 tail
+    (global average pool, `classifier.1`, merger: oatomobile/baselines/torch/dim/model.py:203-217).
+
+What it cannot reproduce bit for bit: the summation ORDER inside a contraction (MFMA accumulation, K chunking).  An fp32
+sum that differs in the last place occasionally lands on the other side of a bf16 rounding boundary, so a teacher-forced
+layer (HIP input -> one layer -> compare) agrees to 1 bf16 ulp (2^-8 relative), which is what the GPU tests gate.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this package.
+"""
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+  """fp32 -> bfloat16 (round to nearest even) -> fp32."""
+  return t.to(torch.bfloat16).to(torch.float32)
+
+
+class FoldedLayer:
+  """One conv + folded BN of the stack, network order (= `oatomobile_amd.arch.conv_layers()` order)."""
+
+  def __init__(self, kind: str, w: torch.Tensor, b: torch.Tensor, stride: int, relu6: bool) -> None:
+    self.kind, self.w, self.b, self.stride, self.relu6 = kind, w, b, stride, relu6
+    self.residual_from: Optional[int] = None  # index of the layer whose OUTPUT is added (block input), or None
+
+
+def _fold(conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
+  scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + BN_EPS)
+  w = (conv.weight.double() * scale.view(-1, 1, 1, 1)).float()
+  b = (bn.bias.double() - bn.running_mean.double() * scale).float()
+  return w, b
+
+
+def folded_layers(model, dw_weights_bf16: bool = False) -> List[FoldedLayer]:
+  """The 52 conv layers of `model._encoder._model.features` (an `oracle.reference_cpu.OracleImitativeModel`) with BN
+  folded and the storage roundings of the bf16 path applied to the weights."""
+  feats = model._encoder._model.features
+  out: List[FoldedLayer] = []
+  w, b = _fold(feats[0][0], feats[0][1])
+  out.append(FoldedLayer("stem", w, b, 2, True))
+  for blk in list(feats)[1:-1]:
+    seq = list(blk.conv)
+    block_input = len(out) - 1
+    j = 0
+    if len(seq) == 4:  # expand
+      w, b = _fold(seq[0][0], seq[0][1])
+      out.append(FoldedLayer("pw", bf16_round(w), b, 1, True))
+      j = 1
+    w, b = _fold(seq[j][0], seq[j][1])
+    out.append(FoldedLayer("dw", bf16_round(w) if dw_weights_bf16 else w, b, seq[j][0].stride[0], True))
+    w, b = _fold(seq[j + 1], seq[j + 2])
+    proj = FoldedLayer("pw", bf16_round(w), b, 1, False)
+    if blk.use_res_connect:
+      proj.residual_from = block_input
+    out.append(proj)
+  w, b = _fold(feats[-1][0], feats[-1][1])
+  out.append(FoldedLayer("pw", bf16_round(w), b, 1, True))
+  return out
+
+
+def layer_forward(layer: FoldedLayer, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                  round_output: bool = True) -> torch.Tensor:
+  """One layer on NCHW fp32 `x` (holding bf16 values, or the fp32 network input for the stem): fp32 arithmetic, one
+  bf16 rounding of the output.  `residual` = the block input as stored (bf16 values)."""
+  if layer.kind == "pw":
+    y = F.conv2d(x, layer.w, layer.b)
+  elif layer.kind == "dw":
+    y = F.conv2d(x, layer.w, layer.b, stride=layer.stride, padding=1, groups=layer.w.shape[0])
+  else:
+    y = F.conv2d(x, layer.w, layer.b, stride=layer.stride, padding=1)
+  if layer.relu6:
+    y = torch.clamp(y, 0.0, 6.0)
+  if residual is not None:
+    y = y + residual
+  return bf16_round(y) if round_output else y
+
+
+def encoder_taps(model, visual: torch.Tensor, dw_weights_bf16: bool = False) -> List[torch.Tensor]:
+  """Outputs of all 52 layers, NCHW fp32 (bf16 values except the last: `features.18` stays fp32)."""
+  layers = folded_layers(model, dw_weights_bf16)
+  taps: List[torch.Tensor] = []
+  x = visual.float()
+  for i, l in enumerate(layers):
+    res = taps[l.residual_from] if l.residual_from is not None else None
+    x = layer_forward(l, x, res, round_output=i + 1 < len(layers))
+    taps.append(x)
+  return taps
+
+
+def features(model, visual: torch.Tensor, dw_weights_bf16: bool = False) -> torch.Tensor:
+  """`self._encoder(visual_features)` (dim/model.py:203) in the bf16 storage arithmetic: [B,128] fp32."""
+  x = encoder_taps(model, visual, dw_weights_bf16)[-1]
+  pooled = x.mean(dim=(2, 3))  # adaptive_avg_pool2d(1); Dropout is the identity in eval mode
+  cls = model._encoder._model.classifier[1]
+  return F.linear(pooled, cls.weight, cls.bias)
+
+
+def params(model, visual_features: torch.Tensor, velocity: torch.Tensor, is_at_traffic_light: torch.Tensor,
+           traffic_light_state: torch.Tensor, dw_weights_bf16: bool = False) -> torch.Tensor:
+  """`ImitativeModel._params` (dim/model.py:173-219) with the bf16-storage encoder; the merger is fp32."""
+  feat = features(model, visual_features, dw_weights_bf16)
+  merged = torch.cat([feat, velocity, is_at_traffic_light, traffic_light_state], dim=-1)
+  return model._merger(merged)
+
+
+def teacher_forced(model, taps_hip: Dict[int, torch.Tensor], visual: torch.Tensor, layer_ranges,
+                   dw_weights_bf16: bool = False) -> Dict[int, torch.Tensor]:
+  """For each `(first, last)` in `layer_ranges`: runs layers first..last from the HIP path's OWN input of layer
+  `first` (`taps_hip[first - 1]`, or `visual` for first == 0) and returns {last: output}.  A residual source inside the
+  range is the oracle's tensor, one before it is the HIP tap (it must be in `taps_hip`)."""
+  layers = folded_layers(model, dw_weights_bf16)
+  out: Dict[int, torch.Tensor] = {}
+  for first, last in layer_ranges:
+    local: Dict[int, torch.Tensor] = {}
+    x = visual.float() if first == 0 else taps_hip[first - 1]
+    for i in range(first, last + 1):
+      l = layers[i]
+      res = None
+      if l.residual_from is not None:
+        res = local[l.residual_from] if l.residual_from in local else taps_hip[l.residual_from]
+      x = layer_forward(l, x, res, round_output=i + 1 < len(layers))
+      local[i] = x
+    out[last] = x
+  return out

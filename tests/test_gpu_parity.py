@@ -292,26 +292,128 @@ def test_mega_encoder_failure_is_reported_once_and_the_agent_recovers(dev):
   assert lib.rip_encoder_status(h.raw) == 0
 
 
-def test_bf16_encoder_close_to_fp32(dev):
-  """BASELINE config 3: bf16 encoder (activations + pointwise weights bf16, fp32 accumulate).  The tolerance on z is
-  the bf16 one (reported, not 1e-4): 52 layers of 2^-9 relative rounding."""
+BF16_ULP = 2.0 ** -8   # relative spacing of bfloat16 (8 significand bits)
+
+
+def _bf16_layer_gate(tag, got, want, worst):
+  """One teacher-forced layer (or block) of the bf16 encoder against `oracle/bf16_encoder.py`: both ran the same
+  arithmetic on the same input, so they differ only where an fp32 sum that differs in its last places (summation order:
+  MFMA K-chunks vs torch's conv) falls on the other side of a bf16 rounding boundary — one bf16 ulp of the value.
+  Gate: |d| <= 2^-7 |ref| + 3e-5 max|ref| everywhere (2 ulp + the fp32 summation noise of cancelling sums); reported:
+  the fraction of elements that differ at all, and the worst error in ulps."""
+  got, want = got.double().cpu(), want.double()
+  d = (got - want).abs()
+  scale = float(want.abs().max())
+  tol = 2.0 ** -7 * want.abs() + 3e-5 * scale
+  frac = float((d > 0).double().mean())
+  ulps = float((d / (BF16_ULP * want.abs().clamp_min(1e-3 * scale))).max())
+  worst.append((ulps, frac, tag))
+  assert bool((d <= tol).all()), "%s: max |d| %.3g at scale %.3g (%.2f bf16 ulp), %.2f %% of the elements differ" % (
+      tag, float(d.max()), scale, ulps, 100 * frac)
+
+
+def test_bf16_encoder_every_layer_teacher_forced_vs_bf16_oracle(dev):
+  """a bf16-emulating oracle for the arithmetic the headline runs.  Layer-wise bf16 kernels
+  (RIP_OPT_ENCODER_FUSED = 0), all 52 conv layers tapped through `rip_encode_tap`; layer i of the oracle is fed the HIP
+  path's own output of layer i-1 (teacher forcing removes error propagation: a wrong tap, a dropped residual or a
+  missing ReLU6 in ONE layer cannot hide under the noise of the other 51)."""
+  from oracle import bf16_encoder as BE
+  from oatomobile_amd import arch
+  m, mo = hip_model(21, dev, max_batch=4), oracle_model(21)
+  m.encoder_dtype = "bf16"
+  m.fused_encoder = 0
+  obs = [synth_observation(np.random.default_rng(1000 + i)) for i in range(3)]
+  vis = ctx_tensors(obs, dev)["visual_features"]
+  L = len(arch.conv_layers())
+  taps = {i: m.encoder_layer_output(vis, i).cpu() for i in range(L)}
+  pooled_last = taps.pop(L - 1)
+  want = BE.teacher_forced(mo, taps, vis.cpu(), [(i, i) for i in range(L)])
+  worst = []
+  for i in range(L - 1):
+    assert torch.equal(BE.bf16_round(taps[i]), taps[i])  # what is stored IS bf16
+    _bf16_layer_gate("layer %d (%s)" % (i, arch.conv_layers()[i].name.split("features.")[1]), taps[i], want[i], worst)
+  # features.18: fp32 out, 4x4 average pool in its epilogue
+  got, ref = pooled_last.double(), want[L - 1].double().mean(dim=(2, 3))
+  assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+  worst.sort(reverse=True)
+  print("bf16 layer-wise vs bf16 oracle, teacher-forced: worst layers (ulp, fraction of elements that differ): " +
+        "; ".join("%s %.2f ulp %.3f %%" % (t, u, 100 * f) for u, f, t in worst[:4]))
+  assert max(f for _, f, _ in worst) < 0.05  # flips are rare: a systematic difference would touch most elements
+
+
+@pytest.mark.parametrize("B", [3, 64])
+def test_bf16_fused_blocks_teacher_forced_vs_bf16_oracle(dev, B):
+  """The SHIPPED bf16 kernels (front kernel, row-streaming and tile blocks: RIP_OPT_ENCODER_FUSED = 17; B = 64 is where
+  `auto` engages the tile blocks too): every block output that reaches memory, teacher-forced per block against the
+  bf16 oracle from the HIP path's own block input — the gate that makes restructuring those kernels safe.  Reported:
+  whether each block is still bit-identical to the layer-wise kernels."""
+  from oracle import bf16_encoder as BE
+  from oatomobile_amd import _lib, arch
+  m, mo = hip_model(22, dev, max_batch=B), oracle_model(22)
+  m.encoder_dtype = "bf16"
+  rng = np.random.default_rng(5)
+  obs = [synth_observation(np.random.default_rng(2000 + i)) for i in range(min(B, 4))]
+  vis = ctx_tensors(obs, dev)["visual_features"]
+  vis = vis.repeat((B + vis.shape[0] - 1) // vis.shape[0], 1, 1, 1)[:B].contiguous()
+  vis = (vis * torch.from_numpy(rng.uniform(0.5, 1.0, size=(B, 1, 1, 1)).astype(np.float32)).to(dev)).contiguous()
+  L = len(arch.conv_layers())
+  m.fused_encoder = 17
+  fused, ranges, first = {}, [], 0
+  for i in range(L):
+    try:
+      fused[i] = m.encoder_layer_output(vis, i).cpu()
+    except _lib.RipError:
+      continue  # interior to a fused block
+    ranges.append((first, i))
+    first = i + 1
+  assert len(ranges) >= 18 and any(b - a == 2 for a, b in ranges), ranges  # blocks really ran fused
+  m.fused_encoder = 0
+  check = sorted({0, B // 2, B - 1})  # the oracle runs these rows (CPU seconds), the bit-identity report all of them
+  identical = []
+  worst = []
+  pooled = fused.pop(L - 1)
+  want = BE.teacher_forced(mo, {i: t[check] for i, t in fused.items()}, vis[check].cpu(), ranges)
+  for a, b in ranges:
+    layerwise = m.encoder_layer_output(vis, b).cpu()
+    if b == L - 1:
+      identical.append(bool(torch.equal(layerwise, pooled)))
+      ref = want[b].double().mean(dim=(2, 3))
+      assert float((pooled[check].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+      continue
+    identical.append(bool(torch.equal(layerwise, fused[b])))
+    _bf16_layer_gate("layers %d..%d" % (a, b), fused[b][check], want[b], worst)
+  worst.sort(reverse=True)
+  print("bf16 fused blocks, B = %d: %d / %d launches bit-identical to the layer-wise kernels; worst vs oracle: %s" %
+        (B, sum(identical), len(identical), "; ".join("%s %.2f ulp %.3f %%" % (t, u, 100 * f) for u, f, t in worst[:3])))
+  assert max(f for _, f, _ in worst) < 0.05
+
+
+def test_bf16_encoder_end_to_end_vs_bf16_oracle(dev):
+  """BASELINE config 3 end to end: z of the shipped bf16 path (auto kernel selection) against the bf16 oracle at <= 1 %
+  of max|z| (replaces round 3's 10 % / 2 % gate against the FP32 oracle: that distance is the storage format's own
+  effect — reported below — not an error of the kernels).  16 observations reach the streaming / block-GEMM kernels
+  (M >= 32768); the same observations two at a time take the small-batch kernels."""
+  from oracle import bf16_encoder as BE
   from oracle import reference_cpu as O
   m, mo = hip_model(21, dev), oracle_model(21)
-  obs = [synth_observation(np.random.default_rng(1000 + i)) for i in range(16)]  # 16: reaches the streaming /
-  ctx = ctx_tensors(obs, dev)                                                     # block-GEMM kernels (M >= 32768)
+  obs = [synth_observation(np.random.default_rng(1000 + i)) for i in range(16)]
+  ctx = ctx_tensors(obs, dev)
   z32 = m._params(**ctx).cpu().numpy()
   m.encoder_dtype = "bf16"
   z16 = m._params(**ctx).cpu().numpy()
-  # the same observations two at a time take the small-batch kernels: same arithmetic up to summation order
   z16_small = np.concatenate([m._params(**{k: v[i:i + 2].contiguous() for k, v in ctx.items()}).cpu().numpy()
                               for i in range(0, 16, 2)])
-  assert np.abs(z16_small - z16).max() <= 0.03 * np.abs(z16).max()
-  zo = O.params(mo, **{k: v.cpu() for k, v in ctx.items()}).numpy()
-  np.testing.assert_allclose(z32, zo, atol=TOL)
-  err = np.abs(z16 - zo)
-  scale = np.abs(zo).max()
-  print("bf16 encoder: max|dz| = %.3g, mean|dz| = %.3g, max|z| = %.3g" % (err.max(), err.mean(), scale))
-  assert err.max() <= 0.10 * scale and err.mean() <= 0.02 * scale  # measured: 6.5 % / 0.8 % of max|z|
+  cpu = {k: v.cpu() for k, v in ctx.items()}
+  zo32 = O.params(mo, **cpu).numpy()
+  zo16 = BE.params(mo, **cpu).numpy()
+  np.testing.assert_allclose(z32, zo32, atol=TOL)
+  scale = np.abs(zo16).max()
+  for tag, z in (("auto kernels, B = 16", z16), ("small-batch kernels, B = 2", z16_small)):
+    err = np.abs(z - zo16)
+    print("bf16 encoder vs bf16 oracle (%s): max|dz| = %.3g, mean|dz| = %.3g, max|z| = %.3g" % (tag, err.max(), err.mean(), scale))
+    assert err.max() <= 0.01 * scale, tag
+  fmt = np.abs(zo16 - zo32)
+  print("bf16 storage format itself (bf16 oracle vs fp32 oracle): max|dz| = %.3g, mean|dz| = %.3g" % (fmt.max(), fmt.mean()))
   assert not np.array_equal(z16, z32)  # really a different arithmetic
 
 
