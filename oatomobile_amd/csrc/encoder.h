@@ -101,6 +101,12 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
                            const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
                            const unsigned short* x, unsigned short* y, hipStream_t s);
 
+// round 4: the same blocks with the depthwise on the matrix cores as well (encoder_bf16_irb2.hip)
+bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
+hipError_t launch_irb2_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
+                            const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
+                            const unsigned short* x, unsigned short* y, hipStream_t s);
+
 // stem + features.1 in one kernel (encoder_bf16_front.hip)
 bool front_bf16_supported(const Layer& ls, const Layer& ld, const Layer& lp);
 hipError_t launch_front_bf16(const Layer& ls, const Layer& ld, const Layer& lp, const float* enc_w,

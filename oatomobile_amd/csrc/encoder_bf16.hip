@@ -7,6 +7,8 @@
 // B = 16 pixels, lane (n, q) ends with 4 consecutive channels of pixel n.  Both operands use the same
 // "lane q <-> K values 8q..8q+7 of the chunk" assignment, so the contraction is independent of the instruction's
 // internal k ordering.  features.18 is written in fp32 for the (fp32) pooling/classifier/merger tail.
+#include <stdlib.h>
+
 #include "encoder.h"
 
 namespace rip {
@@ -1098,13 +1100,15 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
   std::vector<char> tiled(plan.blocks.size(), 0);
+  static const bool irb_old = getenv("RIP_IRB_OLD") != nullptr && getenv("RIP_IRB_OLD")[0] == '1';  // A/B hook (round 3's kernel)
   for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-    const bool rows = irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    const bool rows = rows2 || irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
     const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
     if (!rows && !tile) continue;
-    tiled[bi] = tile;
+    tiled[bi] = tile ? 1 : (rows2 ? 2 : 0);
     if (fb.expand >= 0) in_block[fb.expand] = 1;
     in_block[fb.dw] = 1;
     in_block[fb.project] = 2;  // the block is launched where its last layer sits
@@ -1130,7 +1134,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     if (in_block[li] == 2) {
       const FusedBlock& fb = plan.blocks[block_of[li]];
       const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-      hipError_t e = (tiled[block_of[li]] ? launch_irb_tile_bf16 : launch_irb_bf16)(
+      hipError_t e = (tiled[block_of[li]] == 1 ? launch_irb_tile_bf16 : (tiled[block_of[li]] == 2 ? launch_irb2_bf16 : launch_irb_bf16))(
           le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc, B,
           reinterpret_cast<const unsigned short*>(bufs[fb.src]), reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
       if (e != hipSuccess) return e;

@@ -10,5 +10,5 @@ for r in rows[idx[-2]:idx[-1]]:
   dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
   tot += dur
   n = r["Kernel_Name"].replace("void rip::(anonymous namespace)::", "").replace("rip::(anonymous namespace)::", "")
-  print(f"{n[:34]:34s} grid={r['Grid_Size_X']:>8s},{r['Grid_Size_Y']:>3s} {dur:8.1f}")
+  print(f"{n[:64]:64s} grid={r['Grid_Size_X']:>8s},{r['Grid_Size_Y']:>3s} {dur:8.1f}")
 print("sum of kernel durations: %.1f us  (%s)" % (tot, fs[-1]))
