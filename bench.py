@@ -17,8 +17,14 @@ selection with the [30,3] float64 interpolation (R11 on the device) and the copy
 to pinned host memory.  Every observation is one `RIPAgent.act()` call: value = obs_batch * steps * n_gpus / time.
 `hbm_resident` is the same step on observations already in HBM without R11 (R2..R10: last round's headline).
 
-Multi-GPU (`--mode`; one process per GPU, RCCL):
-  replay      (default) observation-parallel replicas, no data-path collective                  -> "weak"
+Multi-GPU (one process per GPU, RCCL).  `--gpus N` with NO `--mode` (what the driver runs) times the
+observation-parallel replicas for `value` AND, in the same invocation, the two compositions that need a collective, and
+prints ONE line: `candidate_parallel` (north_star's "candidate throughput": N candidates per rank, one RCCL all-gather
+of (best loss, plan) per step), `model_parallel` (when K % N == 0: K / N models per rank, one all-gather of the per-model
+(posterior, d posterior / dy) block per Adam step, the K-aggregation of rip/agent.py:109-127 after the gather), each with
+its plan difference against ONE rank holding everything, and `rccl` = {backend, ranks_seen, librccl_mapped}; the run
+aborts unless every rank was seen by a collective.  An explicit `--mode` runs one composition alone:
+  replay      observation-parallel replicas, no data-path collective                            -> "weak"
   candidates  every rank searches `--candidates` latent starts of the SAME observations (N_total = N * world), one
               all-gather of (best loss, plan) per step                                          -> "weak"
   models      `--models` K split over the ranks, gradient-mode model parallelism: per Adam step ONE all-gather of
@@ -26,8 +32,10 @@ Multi-GPU (`--mode`; one process per GPU, RCCL):
 
 The JSON line also carries
   roofline      — the dominant kernel (plan search): executed MFMA flops (exact instruction count of this launch
-                  configuration, from the kernel's own per-step selection trace) / fp32 MFMA peak; the §8(d)
-                  contract-formula figure is reported separately (it prices work the kernel legitimately skips)
+                  configuration, from the kernel's own per-step selection trace) / the dense-f16 MFMA peak (`frac`; the
+                  kernel is instruction-issue bound: `bound` = "issue"), `matrix_pipe_busy` = the fraction of the launch
+                  the matrix pipe is busy with this instruction mix; the §8(d) contract-formula figure is reported
+                  separately (it prices work the kernel legitimately skips)
   cpu_baseline  — the CPU oracle (oracle/reference_cpu.py, "port") timed on this box's host cores
   online        — `agent(observation)` one call at a time, host numpy in -> host numpy out (H2D + D2H inside)
   hbm_resident  — the step without R1 / R11: observations resident in HBM, [B,4,2] plans copied back
@@ -247,7 +255,8 @@ def main():
   ap.add_argument("--channels", type=int, default=2, help="BEV channels (reference sensor: 2; BASELINE.json text: 4)")
   ap.add_argument("--algorithm", default="WCM")
   ap.add_argument("--search-steps", type=int, default=10)
-  ap.add_argument("--mode", default="replay", choices=["replay", "candidates", "models"])
+  ap.add_argument("--mode", default=None, choices=["replay", "candidates", "models"],
+                  help="default: replay; with --gpus N > 1 and no --mode the candidate- / model-parallel compositions run too")
   ap.add_argument("--cpu-seconds", type=float, default=5.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (online, pcie, scoring, fp32, C=4)")
@@ -255,6 +264,9 @@ def main():
   if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
     return _cpu_baseline_worker(sys.argv[2:])
   args = ap.parse_args()
+  explicit_mode = args.mode is not None
+  if args.mode is None:
+    args.mode = "replay"
 
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     return _self_spawn(args)
@@ -327,7 +339,12 @@ def main():
   seeds = [100 + k for k in range(K)]
 
   if args.mode != "replay":
-    return _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all)
+    line = _bench_parallel_mode(args, args.mode, rank, world, dev, dist, timed, args.steps, args.warmup)
+    if rank == 0:
+      print(json.dumps(line))
+    dist.barrier()
+    dist.destroy_process_group()
+    return
 
   models = [ImitativeModel.synthetic(s, in_channels=C, max_batch=1) for s in seeds]
   agent = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, num_steps=S, max_batch=B, seed=0,
@@ -509,6 +526,32 @@ def main():
       c4_line = extra(_bench_c4, args, dev, timed, seeds)
     train_line = extra(_bench_train, args, dev, timed)
     replay_line = extra(_bench_replay, args, agent, dev, B, C)
+  # ---------------- N > 1 without --mode: the compositions that need a collective, same invocation ----------------
+  par_lines, rccl = {}, None
+  if world > 1 and not explicit_mode:
+    rccl = _rccl_seen(dist, dev, world)
+    if rccl["ranks_seen"] != world or rccl["all_reduce_of_ones"] != float(world):
+      raise SystemExit("bench.py: the collectives saw %d ranks (all-reduce of ones = %g), expected %d" %
+                       (rccl["ranks_seen"], rccl["all_reduce_of_ones"], world))
+    del agent
+    torch.cuda.empty_cache()
+    sub_steps, sub_warm = max(4, args.steps // 2), 2
+    for mode in ["candidates"] + (["models"] if K % world == 0 else []):
+      try:
+        line = _bench_parallel_mode(args, mode, rank, world, dev, dist, timed, sub_steps, sub_warm)
+      except Exception as exc:  # noqa: BLE001 -- every rank raises or none does (same code path); the headline stands
+        torch.cuda.synchronize()
+        line = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+      if rank == 0:
+        if "error" in line:
+          par_lines[mode] = line
+        else:
+          par_lines[mode] = {"calls_per_s": line["value"], "candidate_plans_per_s": line["candidate_plans_per_s"],
+                             "ms_per_step": line["ms_per_step"], "collectives_per_step": line["collectives_per_step"],
+                             "max_abs_plan_diff_vs_single_gpu": line["check"]["max_abs_plan_diff_vs_single_gpu"],
+                             "scaling": line["scaling"], "candidates_total": line["config"]["candidates"],
+                             "parallelism": line["config"]["parallelism"], "steps": sub_steps, "warmup": sub_warm}
+      torch.cuda.empty_cache()
   if rank == 0:
     measured = _measured(args)
     flow_flops = 2.0 * 3.0 * (1 + K) * 4 * FLOW_MAC_PER_STEP * N * S * B  # SURVEY §8(d) flops_flow(grad)
@@ -522,12 +565,13 @@ def main():
     roof = {
         "kernel": "%s: per 16-candidate wave F_0 + %d inverses + adjoints + Adam, operands in LDS, %d steps in one launch" %
                   (KERNEL_NAMES[plan_info["kernel"]], K - 1, S),
-        "bound": "mfma",
+        "bound": "issue",
         "achieved": exec_tf,
-        "peak": mix_peak,
+        "peak": PEAK_BF16_TFLOPS,
         "unit": "TFLOP/s",
-        "frac": exec_tf / mix_peak if exec_tf else None,
+        "frac": exec_tf / PEAK_BF16_TFLOPS if exec_tf else None,
         "frac_of_dense_f16_peak": exec_tf / PEAK_BF16_TFLOPS if exec_tf else None,
+        "matrix_pipe_busy": exec_tf / mix_peak if exec_tf else None,
         "fp32_equivalent_tflops": extras.pop("fp32_kernel_flops_same_launch") / (search_ms * 1e-3) / 1e12
                                   if "fp32_kernel_flops_same_launch" in extras else None,
         # L2 <-> fabric bytes per launch: the adjoint tape, written once and read back once per 16-candidate block,
@@ -545,10 +589,11 @@ def main():
                 "= 2048; instruction counts per pass from rip_search_plan, passes from the kernel's per-step selection "
                 "trace: an inverse's adjoint only runs for blocks where some candidate selects that model) over the mean "
                 "launch time from HIP events on the launch stream; checked against rocprofv3 SQ_INSTS_MFMA (profiles/).  "
-                "`peak`: what the matrix pipe delivers running this launch's instruction mix back to back (f16 MFMAs at the "
-                "2.5 PFLOP/s dense rate = one per 16 cycles and SIMD, fp32 MFMAs at 157.3 TFLOP/s = one per 32), so "
-                "`frac` = the fraction of the launch the matrix pipe is busy; `frac_of_dense_f16_peak` prices every flop at "
-                "the f16 rate.  `fp32_equivalent_tflops`: the flops the fp32-MFMA kernel of round 2 executes for the same "
+                "`peak` = the dense f16 MFMA peak (2.5 PFLOP/s), `frac` = achieved / peak (every flop priced at the f16 "
+                "rate).  `bound` = \"issue\": the kernel runs one wave per SIMD at 256 + 209 registers and is limited by the "
+                "instructions it issues between matrix instructions (gate math, operand splits), not by the matrix pipe: "
+                "`matrix_pipe_busy` = the time the pipe needs for this launch's instruction mix back to back (f16 MFMAs one "
+                "per 16 cycles and SIMD, fp32 MFMAs one per 32) / the launch time.  `fp32_equivalent_tflops`: the flops the fp32-MFMA kernel of round 2 executes for the same "
                 "launch / this launch's time — above 157.3 means past that kernel's floor.  `contract_*`: "
                 "SURVEY.md §8(d) flops_flow(grad) = 2*3*(1+K)*T*14848*N*steps per act x obs_batch / launch time -- NOT "
                 "a utilisation: the formula prices the candidate-independent step-0 prefix, model 0's inverse "
@@ -569,7 +614,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 encoder (bf16 MFMA, fp32 accumulate) + f32 flow/search" if args.encoder_dtype == "bf16" else "f32",
+        "dtype": ("bf16 encoder (bf16 storage, fp32 accumulate) + " if args.encoder_dtype == "bf16" else "fp32 encoder + ") +
+                 "flow/search: fp32 accumulate, GRU/head contractions as two-term binary16 (22-bit) operands on f16 MFMA",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV, "
                                "%s encoder + fp32 flow" % (K, args.algorithm, N, S, C, args.encoder_dtype),
@@ -583,6 +629,9 @@ def main():
         "hbm_resident": hbm_line,
         "backend": args.backend_seen,
         "world_size_seen": args.world_seen,
+        "candidate_parallel": par_lines.get("candidates"),
+        "model_parallel": par_lines.get("models") if world > 1 else None,
+        "rccl": rccl,
         "online": online,
         "scoring_only": scoring,
         "fp32_parity": fp32_line,
@@ -778,14 +827,30 @@ def _bench_train(args, dev, timed):
                   "every step (the loss falls)"}
 
 
-def _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all):
-  """--mode candidates | models: the compositions of oatomobile_amd/distributed.py over RCCL."""
+def _rccl_seen(dist, dev, world):
+  """What the collectives themselves saw: every rank contributes its index to an all-gather and a one to an all-reduce
+  on DEVICE tensors (RCCL when the backend is nccl); `librccl_mapped` from /proc/self/maps."""
+  mine = torch.tensor([dist.get_rank()], device=dev, dtype=torch.int64)
+  got = [torch.empty_like(mine) for _ in range(world)]
+  dist.all_gather(got, mine)
+  ones = torch.ones(1, device=dev)
+  dist.all_reduce(ones)
+  torch.cuda.synchronize()
+  with open("/proc/self/maps") as f:
+    mapped = any("librccl" in line for line in f)
+  return {"backend": dist.get_backend(), "ranks_seen": len({int(t.item()) for t in got}), "all_reduce_of_ones": float(ones.item()),
+          "librccl_mapped": mapped}
+
+
+def _bench_parallel_mode(args, mode, rank, world, dev, dist, timed, steps, warmup):
+  """`candidates` | `models`: the compositions of oatomobile_amd/distributed.py over RCCL.  Every rank
+  calls this; rank 0 gets the result line (a dict), the others None."""
   from oatomobile_amd import ImitativeModel
   from oatomobile_amd import distributed as D
   K, N, B, C, S = args.models, args.candidates, args.obs_batch, args.channels, args.search_steps
   rng = np.random.default_rng(1000)  # the SAME observations on every rank in both modes
   lidar, vec, goal = (torch.from_numpy(a).to(dev) for a in synth_batch(rng, B, C))
-  if args.mode == "candidates":
+  if mode == "candidates":
     models = [ImitativeModel.synthetic(100 + k, in_channels=C, max_batch=1) for k in range(K)]
     cp = D.CandidateParallelRIP(models, N * world, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B, device=dev,
                                 encoder_dtype=args.encoder_dtype)
@@ -796,7 +861,7 @@ def _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all):
       out_host.copy_(plan, non_blocking=True)
 
     par = "candidate-parallel: %d candidates per rank x %d ranks (N_total = %d), one all-gather of (best loss, plan) per step" % (N, world, N * world)
-    scaling, n_total = "weak", N * world
+    scaling, n_total, collectives = "weak", N * world, 1
   else:
     kb, ke = D.shard_range(K, rank, world)
     models = [ImitativeModel.synthetic(100 + k, in_channels=C, max_batch=1) for k in range(kb, ke)]
@@ -809,42 +874,41 @@ def _bench_parallel_modes(args, rank, world, dev, dist, timed, sync_all):
       plan, best, lb = mp(lidar, vec, goal)
       out_host.copy_(plan, non_blocking=True)
 
-    par = "model-parallel (gradient mode): K = %d models over %d ranks, one all-gather of the [K_local,B,N,9] block per Adam step" % (K, world)
-    scaling, n_total = "strong", N
-  elapsed = timed(step, args.steps, args.warmup)
+    par = ("model-parallel (gradient mode): K = %d models over %d ranks, one all-gather of z_0 per call and one of the "
+           "[K_local,B,N,9] (posterior, d posterior / dy) block per Adam step; the K-aggregation (rip/agent.py:109-127) "
+           "runs on every rank after the gather" % (K, world))
+    scaling, n_total, collectives = "strong", N, S + 1
+  elapsed = timed(step, steps, warmup)
   # the distributed result against the world-1 composition of the same search on rank 0 (same candidate stream)
-  if args.mode == "candidates":
+  if mode == "candidates":
     plan_d = cp(lidar, vec, goal)[0]
   else:
     plan_d = mp(lidar, vec, goal)[0]
-  check = None
-  if rank == 0:
-    if args.mode == "candidates":
-      one = D.CandidateParallelRIP(models, N * world, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B, device=dev,
-                                   encoder_dtype=args.encoder_dtype, rank=0, world=1)
-      plan_1 = one(lidar, vec, goal)[0]
-    else:
-      full = [ImitativeModel.synthetic(100 + k, in_channels=C, max_batch=1) for k in range(K)]
-      one = D.ModelParallelRIP(full, K, num_candidates=N, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B,
-                               device=dev, rank=0, world=1)
-      plan_1 = one(lidar, vec, goal)[0]
-    check = {"max_abs_plan_diff_vs_single_gpu": float((plan_d - plan_1).abs().max().item()),
-             "note": "plans of the %d-rank run vs ONE rank holding everything, same observations and latent starts" % world}
-  if rank == 0:
-    calls = B * args.steps
-    print(json.dumps({
-        "check": check,
-        "metric": "RIPAgent.act() calls/sec (K=%d, %d plans, 200x200 BEV)" % (K, n_total),
-        "value": calls / elapsed, "unit": "calls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32 flow/search, %s encoder" % args.encoder_dtype, "data": "synthetic",
-        "candidate_plans_per_s": calls / elapsed * n_total,
-        "backend": args.backend_seen, "world_size_seen": args.world_seen,
-        "config": {"workload": "RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV" % (K, args.algorithm, n_total, S, C),
-                   "obs_per_step": B, "models": K, "candidates": n_total, "bev_channels": C, "mode": args.mode, "parallelism": par}}))
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  if rank != 0:
+    return None
+  if mode == "candidates":
+    one = D.CandidateParallelRIP(models, N * world, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B, device=dev,
+                                 encoder_dtype=args.encoder_dtype, rank=0, world=1)
+    plan_1 = one(lidar, vec, goal)[0]
+  else:
+    full = [ImitativeModel.synthetic(100 + k, in_channels=C, max_batch=1) for k in range(K)]
+    one = D.ModelParallelRIP(full, K, num_candidates=N, algorithm=args.algorithm, num_steps=S, seed=0, max_batch=B,
+                             device=dev, rank=0, world=1)
+    plan_1 = one(lidar, vec, goal)[0]
+  check = {"max_abs_plan_diff_vs_single_gpu": float((plan_d - plan_1).abs().max().item()),
+           "note": "plans of the %d-rank run vs ONE rank holding everything, same observations and latent starts" % world}
+  calls = B * steps
+  return {
+      "check": check,
+      "metric": "RIPAgent.act() calls/sec (K=%d, %d plans, 200x200 BEV)" % (K, n_total),
+      "value": calls / elapsed, "unit": "calls/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+      "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+      "dtype": "%s encoder + flow/search: fp32 accumulate, GRU/head contractions as two-term binary16 operands on f16 MFMA" % args.encoder_dtype,
+      "data": "synthetic",
+      "candidate_plans_per_s": calls / elapsed * n_total, "collectives_per_step": collectives,
+      "backend": args.backend_seen, "world_size_seen": args.world_seen,
+      "config": {"workload": "RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV" % (K, args.algorithm, n_total, S, C),
+                 "obs_per_step": B, "models": K, "candidates": n_total, "bev_channels": C, "mode": mode, "parallelism": par}}
 
 
 if __name__ == "__main__":

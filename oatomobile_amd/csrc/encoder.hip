@@ -1241,9 +1241,10 @@ bool encoder_mega_probe(int device) {
   if (ok) {
     std::vector<int> hst(G, -1);
     for (int rep = 0; rep < 3 && ok; ++rep) {
-      hipLaunchKernelGGL(mega_probe_kernel, dim3(G), dim3(64), 0, hipStreamPerThread, d);
-      ok = hipStreamSynchronize(hipStreamPerThread) == hipSuccess;
-      if (!ok) break;
+      // on the NULL stream on purpose: probing from hipStreamPerThread (tried in round 4) left later launches of the
+      // one-launch kernel with workgroups off their XCDs (status 1 on every call) — the placement is a property of the
+      // queue state, which is why the kernel re-checks it in every launch
+      hipLaunchKernelGGL(mega_probe_kernel, dim3(G), dim3(64), 0, 0, d);
       ok = hipMemcpy(hst.data(), d, G * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
       for (int i = 0; i < G && ok; ++i) ok = hst[i] == (i & 7);
     }

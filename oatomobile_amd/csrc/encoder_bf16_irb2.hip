@@ -23,7 +23,8 @@
 // Decomposition: a workgroup owns (model, observation, band of output rows), wave w owns NG 16-channel groups of the
 // hidden dimension with a private 3-row ring in LDS (no barrier between expansion and depthwise); the depthwise output
 // row goes to a shared, double-buffered projection operand row; after ONE barrier per output row the waves share the
-// projection tiles.  Rows off the image are zero-filled ring rows (wave-uniform branch at the image border only).
+// projection tiles.  Rows off the image expand from empty descriptors to zero ring rows: the row loop is branch-free.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "encoder.h"
@@ -67,6 +68,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_srd(const bf16_t* row, int
   void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+#ifdef RIP_IRB2_TICKS  // development: per-phase shader cycles of the row loop, summed over the waves of a launch
+__device__ unsigned long long g_irb2_ticks[8];
+#define IRB2_TICK(slot_)                                            \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    tk[slot_] += now_ - tlast;                                      \
+    tlast = now_;                                                   \
+  } while (0)
+#else
+#define IRB2_TICK(slot_) do { } while (0)
+#endif
 constexpr int OOB = 0x40000000;  // byte offset beyond any row descriptor: loads return 0, stores are dropped
 constexpr unsigned ONES = 0x3F803F80u;  // two bf16 1.0
 
@@ -101,11 +113,11 @@ struct Irb2Shape {
   static constexpr size_t DS_EL = (size_t)2 * 16 * NPTO * DLD;
   static constexpr size_t LDS_BYTES = (RING_EL + DS_EL) * 2;
   static_assert(HID % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "channel counts");
-  static_assert(NW * NG >= NGT, "not every hidden group has a wave");
+  static_assert(NW * NG == NGT, "every wave owns exactly NG hidden groups (a branch-free row loop)");
   static_assert(H_OUT == (H_IN + 2 - 3) / S + 1, "3x3, padding 1");
 };
 
-template <int S, int CIN, int HID, int COUT, int H_IN, int H_OUT, int NW, int NG, bool RES, int OCC>
+template <int S, int CIN, int HID, int COUT, int H_IN, int H_OUT, int NW, int NG, bool RES, int OCC, int BTD>
 __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
   using SH = Irb2Shape<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG>;
   constexpr int NGT = SH::NGT, NPTI = SH::NPTI, NPTO = SH::NPTO, KBE = SH::KBE, KE = SH::KE, KS = SH::KS, ELD = SH::ELD,
@@ -124,8 +136,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
   const bf16_t* xin = a.x + ((size_t)k * a.B + b) * H_IN * H_IN * CIN;
   bf16_t* yout = a.y + ((size_t)k * a.B + b) * H_OUT * H_OUT * COUT;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const int g0 = w * NG;                                     // first hidden group of this wave
-  const int ng = NGT - g0 < NG ? (NGT - g0 < 0 ? 0 : NGT - g0) : NG;  // its group count (wave-uniform)
+  const int g0 = w * NG;  // first hidden group of this wave
 
   // ---- zero the LDS once: ring borders, the K padding of the projection operand rows ----
   for (int e = threadIdx.x; e < (int)(SH::LDS_BYTES / 16); e += NW * 64) reinterpret_cast<u32x4*>(lds)[e] = zero4;
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
   f32x4 bdw[NG];      // depthwise bias of channels 4q .. 4q+3 of the group (fp32, the first MFMA's C operand)
 #pragma unroll
   for (int gl = 0; gl < NG; ++gl) {
-    const bool gv = gl < ng;
+    constexpr bool gv = true;
     const int h = 16 * (g0 + gl) + n;  // the A row of this lane
     {
       u32x4 v = zero4;
@@ -225,24 +236,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
     for (int i = 0; i < NPTI; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, xoff[i], 0, 0);
   };
   const int lane_ring = (n * ELD + 4 * q) * 2;  // byte offset of this lane's 4 channels of pixel n inside a ring row
-  auto expand_row = [&](int iy, const u32x4(&xr)[NPTI]) {
-    if (ng == 0) return;
+  // The row loop holds NO branch between a vector-memory load and its use: the s_waitcnt insertion falls back to
+  // vmcnt(0) behind every control-flow merge, which waits for the operand prefetches of the NEXT rows as well (measured:
+  // the "expand" phase of the stride-2 blocks and the residual add each cost a full memory latency per row that way).
+  // A row off the image is therefore expanded like any other: its descriptor is empty (operands load as zeros) and the
+  // bias columns' ones are masked off, so the ring row comes out as ReLU6(0) = 0.
+  auto expand_row = [&](int iy, const u32x4(&xr)[NPTI]) __attribute__((always_inline)) {
     unsigned char* ring = reinterpret_cast<unsigned char*>(es + (size_t)((iy + 3) % 3) * EW * ELD);
-    if (iy < 0 || iy >= H_IN) {  // a row off the image: zeros (wave-uniform, top / bottom of the image only)
-      for (int e = lane * 16; e < EW * ELD * 2; e += 64 * 16) *reinterpret_cast<u32x4*>(ring + e) = zero4;
-      return;
-    }
+    const unsigned rowmask = (iy >= 0 && iy < H_IN) ? 0xffffffffu : 0u;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NPTI; ++i) {
       u32x4 bx = xr[i];
       u32x4 b2 = zero4;
       if (KE == 1)
-        bx.x |= onesx[i];  // lanes of the bias block loaded zeros
+        bx.x |= onesx[i] & rowmask;  // lanes of the bias block loaded zeros
       else
-        b2.x = onesx[i];
+        b2.x = onesx[i] & rowmask;
 #pragma unroll
       for (int gl = 0; gl < NG; ++gl) {
-        if (gl >= ng) continue;
         f32x4 c = mfma_bf16(ae[gl][0], bx, f32x4{0.f, 0.f, 0.f, 0.f});
         if (KE == 2) c = mfma_bf16(ae[gl][KE - 1], b2, c);
         u32x2 o;
@@ -257,32 +268,45 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
   __syncthreads();  // LDS zeroed
 
   // prologue: rows oy0*S-1 .. oy0*S+1-S are expanded here, the remaining S rows of the first window in the loop
-  u32x4 xr[S][NPTI];
 #pragma unroll
   for (int i = 0; i < 3 - S; ++i) {
     u32x4 x0[NPTI];
     load_x(oy0 * S - 1 + i, x0);
     expand_row(oy0 * S - 1 + i, x0);
   }
+  // block-input operands are requested TWO output rows ahead (two register sets, the row loop is unrolled by two): with
+  // the depthwise off the vector unit a row takes less time than a load that misses the L2
+  u32x4 xa[S][NPTI], xb[S][NPTI];
 #pragma unroll
-  for (int i = 0; i < S; ++i) load_x(oy0 * S + 2 - S + i, xr[i]);
+  for (int i = 0; i < S; ++i) load_x(oy0 * S + 2 - S + i, xa[i]);
+#pragma unroll
+  for (int i = 0; i < S; ++i) load_x((oy0 + 1) * S + 2 - S + i, xb[i]);  // (rows past the band / image: zero-byte descriptors)
 
   // depthwise B operand of lane (n, q): pixel slot S*n (+ kx), channel half q & 1; the tap of the pair by q >> 1
   const int lane_dw = (int)(reinterpret_cast<unsigned char*>(es) - smem_raw) + (S * n * ELD + 8 * (q & 1)) * 2;
   const bool second = q >= 2;
-  int buf = 0;
-#pragma unroll 1
-  for (int oy = oy0; oy < oy1; ++oy) {
-    // 1. expand the S new rows (operands fetched during the previous row), then request the next ones
+#ifdef RIP_IRB2_TICKS
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+  auto row = [&](int oy, u32x4(&xr)[S][NPTI], int buf) __attribute__((always_inline)) {
+    IRB2_TICK(5);
+    // 0. the residual (= block input row oy, this wave's projection tiles) is requested now and added after the projection
+    const __amdgpu_buffer_rsrc_t rsrd = row_srd(xin + (size_t)oy * H_IN * CIN, RES ? X_ROW_BYTES : 0);
+    u32x2 rres[TPW];
+    if (RES) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) rres[t] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, roff[t], 0, 0);
+    }
+    // 1. expand the S new rows (operands fetched two rows ago), then request the rows of output row oy + 2
 #pragma unroll
     for (int i = 0; i < S; ++i) expand_row(oy * S + 2 - S + i, xr[i]);
-    if (oy + 1 < oy1) {
 #pragma unroll
-      for (int i = 0; i < S; ++i) load_x((oy + 1) * S + 2 - S + i, xr[i]);
-    }
+    for (int i = 0; i < S; ++i) load_x((oy + 2) * S + 2 - S + i, xr[i]);  // (beyond the image: empty descriptor)
+    IRB2_TICK(0);
     // 2. depthwise of this wave's groups on the matrix cores
     unsigned char* drow = reinterpret_cast<unsigned char*>(ds + (size_t)buf * 16 * NPTO * DLD);
-    if (ng > 0) {
+    {
       // byte offset of tap t's ring row / column (wave-uniform); lanes q >= 2 read the second tap of a pair
       auto tap_off = [&](int t) { return (((oy * S - 1 + t / 3 + 3) % 3) * EW * ELD + (t % 3) * ELD) * 2; };
       int addr[5];
@@ -292,55 +316,46 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
         addr[j] = lane_dw + ta + (second ? d : 0);
       }
       addr[4] = lane_dw + tap_off(8);
-      // (pixel tile, group) items two at a time: two independent accumulator chains in flight per wave
+      // (pixel tile, group) items one after the other.  An item's nine MFMAs accumulate into ONE register tuple and
+      // issue back to back; the operand reads of item i + 1 are issued BEFORE item i's chain, and the chain starts with
+      // the K block whose operand was read last (LDS returns in order: one s_waitcnt in front of the chain covers all
+      // five, nothing sits between two dependent MFMAs).
       constexpr int NIT = NPTO * NG;
+      u32x4 bt[BTD][5];  // BTD = 2: item i + 1's operands in flight during item i's chain (register-tight shapes: 1)
+      auto issue_reads = [&](int item, u32x4(&dst)[5]) __attribute__((always_inline)) {
+        const int imm = (16 * (item / NG) * S * ELD + 16 * (item % NG)) * 2;
 #pragma unroll
-      for (int it = 0; it < NIT; it += 2) {
-        constexpr int PAIR = 2;
-        u32x4 bt[PAIR][5];
-        f32x4 c[PAIR];
-        int pts[PAIR], gls[PAIR];
-        bool on[PAIR];
+        for (int j = 0; j < 5; ++j) dst[j] = *reinterpret_cast<const u32x4*>(smem_raw + addr[j] + imm);
+      };
+      if (BTD == 2) issue_reads(0, bt[0]);
 #pragma unroll
-        for (int e = 0; e < PAIR; ++e) {
-          const int item = it + e < NIT ? it + e : it;
-          pts[e] = item / NG;
-          gls[e] = item % NG;
-          on[e] = it + e < NIT && gls[e] < ng;
+      for (int it = 0; it < NIT; ++it) {
+        const int pt = it / NG, gl = it % NG;
+        if (BTD == 2) {
+          if (it + 1 < NIT) issue_reads(it + 1, bt[(it + 1) % BTD]);
+        } else {
+          issue_reads(it, bt[0]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 c = mfma_bf16(ad[gl][4], bt[it % BTD][4], bdw[gl]);  // (t8h t8l): the operand read last
 #pragma unroll
-        for (int e = 0; e < PAIR; ++e) {
-          if (!on[e]) continue;
-          const int imm = (16 * pts[e] * S * ELD + 16 * gls[e]) * 2;
-#pragma unroll
-          for (int j = 0; j < 5; ++j) bt[e][j] = *reinterpret_cast<const u32x4*>(smem_raw + addr[j] + imm);
+        for (int j = 0; j < 4; ++j) {
+          c = mfma_bf16(ad[gl][j], bt[it % BTD][j], c);
+          c = mfma_bf16(ad[gl][5 + j], bt[it % BTD][j], c);
         }
-        // K block order hi0 lo0 hi1 lo1 .. hi3 lo3 (t8h t8l): a B operand dies after its second use
-#pragma unroll
-        for (int jj = 0; jj < 9; ++jj) {
-          const int j = jj == 8 ? 4 : (jj & 1 ? 5 + jj / 2 : jj / 2);
-#pragma unroll
-          for (int e = 0; e < PAIR; ++e) {
-            if (!on[e]) continue;
-            c[e] = mfma_bf16(ad[gls[e]][j], bt[e][j < 5 ? j : j - 5], jj == 0 ? bdw[gls[e]] : c[e]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < PAIR; ++e) {
-          if (!on[e]) continue;
-          u32x2 o;
-          o.x = pack_bf16(relu6(c[e][0]), relu6(c[e][1]));
-          o.y = pack_bf16(relu6(c[e][2]), relu6(c[e][3]));
-          *reinterpret_cast<u32x2*>(drow + ((16 * pts[e] + n) * DLD + 16 * (g0 + gls[e]) + 4 * q) * 2) = o;
-        }
-        if (it + 2 < NIT) __builtin_amdgcn_sched_barrier(0);  // keep the next pair's operand reads out of this pair's registers
+        __builtin_amdgcn_sched_barrier(0);
+        u32x2 o;
+        o.x = pack_bf16(relu6(c[0]), relu6(c[1]));
+        o.y = pack_bf16(relu6(c[2]), relu6(c[3]));
+        *reinterpret_cast<u32x2*>(drow + ((16 * pt + n) * DLD + 16 * (g0 + gl) + 4 * q) * 2) = o;
       }
     }
     if (!APREG) load_ap();
+    IRB2_TICK(1);
     __syncthreads();  // every group of ds[buf] is in place
+    IRB2_TICK(2);
     // 3. projection tiles of this wave over the full hidden K
     const __amdgpu_buffer_rsrc_t ysrd = row_srd(yout + (size_t)oy * H_OUT * COUT, H_OUT * COUT * 2);
-    const __amdgpu_buffer_rsrc_t rsrd = row_srd(xin + (size_t)oy * H_IN * CIN, RES ? X_ROW_BYTES : 0);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tile = w + NW * t;
@@ -348,24 +363,40 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
       const int pt = tile / NCT;
       f32x4 c = {bpj[t].x, bpj[t].y, bpj[t].z, bpj[t].w};
       const unsigned char* brow = drow + ((16 * pt + n) * DLD + 8 * q) * 2;
+      u32x4 bp[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) c = mfma_bf16(ap[t][ks], *reinterpret_cast<const u32x4*>(brow + 64 * ks), c);
+      for (int ks = 0; ks < KS; ++ks) bp[ks] = *reinterpret_cast<const u32x4*>(brow + 64 * ks);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = KS - 1; ks >= 0; --ks) c = mfma_bf16(ap[t][ks], bp[ks], c);  // back to back, last-read operand first
+      __builtin_amdgcn_sched_barrier(0);
       f32x2 v0 = {c[0], c[1]}, v1 = {c[2], c[3]};
       if (RES) {
-        const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rsrd, roff[t], 0, 0);
-        v0 += bfpair(rr.x);
-        v1 += bfpair(rr.y);
+        v0 += bfpair(rres[t].x);
+        v1 += bfpair(rres[t].y);
       }
       u32x2 o;
       o.x = pack_bf16(v0.x, v0.y);
       o.y = pack_bf16(v1.x, v1.y);
       __builtin_amdgcn_raw_buffer_store_b64(o, ysrd, yoff[t], 0, 0);
     }
-    buf ^= 1;
+    IRB2_TICK(3);
+  };
+#pragma unroll 1
+  for (int oy = oy0; oy < oy1; oy += 2) {
+    row(oy, xa, 0);
+    if (oy + 1 < oy1) row(oy + 1, xb, 1);
   }
+#ifdef RIP_IRB2_TICKS
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_irb2_ticks[i], tk[i]);
+    atomicAdd(&g_irb2_ticks[6], (unsigned long long)(oy1 - oy0));
+  }
+#endif
 }
 
-template <int S, int CIN, int HID, int COUT, int H_IN, int H_OUT, int NW, int NG, bool RES, int OCC>
+template <int S, int CIN, int HID, int COUT, int H_IN, int H_OUT, int NW, int NG, bool RES, int OCC, int BTD = 2>
 hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
   using SH = Irb2Shape<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG>;
   // bands: enough workgroups for ~3 per CU, but bands re-expand their halo rows, so keep them >= 6 rows
@@ -374,7 +405,7 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
   if (bands < 1) bands = 1;
   a.band_rows = (H_OUT + bands - 1) / bands;
   bands = (H_OUT + a.band_rows - 1) / a.band_rows;
-  auto kern = irb2_bf16_kernel<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG, RES, OCC>;
+  auto kern = irb2_bf16_kernel<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG, RES, OCC, BTD>;
   static bool attr_done = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr_done && SH::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -383,24 +414,41 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(bands, B, kc), dim3(NW * 64), SH::LDS_BYTES, s, a);
+#ifdef RIP_IRB2_TICKS
+  {
+    unsigned long long t[8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_irb2_ticks), sizeof(t));
+    const double rows = t[6] > 0 ? (double)t[6] : 1.0;  // wave-rows
+    fprintf(stderr, "irb2<S=%d HID=%d NW=%d NG=%d> cycles per wave-row: expand %.0f  depthwise %.0f  barrier %.0f  project %.0f  loop %.0f\n",
+            S, HID, NW, NG, t[0] / rows, t[1] / rows, t[2] / rows, t[3] / rows, t[5] / rows);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_irb2_ticks), z, sizeof(z));
+  }
+#endif
   return hipGetLastError();
 }
 
 }  // namespace
 
-// the shapes of torchvision's features.2 .. features.7 behind a 100 x 100 network input
+// The shapes of torchvision's features.2 .. features.7 behind a 100 x 100 network input.  `shipped_only`: the blocks for
+// which this kernel is the faster one at 512 observations x 4 models (profiles/r4: features.2 287 -> 172 us, features.3
+// 230 -> 196, features.4 111 -> 92); the 13x13 / 7x7-output blocks (one pixel tile per row: 39 MFMAs of dependent chains
+// per wave and row at two waves per SIMD, 80 -> 87 us and 55 -> 70 us) stay on round 3's kernel (encoder_bf16_irb.hip)
+// unless RIP_IRB2_ALL=1 asks for this one everywhere (tests run both).
 bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp) {
   if (le == nullptr) return false;
   const int cin = le->cin, hid = ld.cout, cout = lp.cout, s = ld.stride, hi = ld.h_in, ho = ld.h_out;
   auto is = [&](int a, int b, int c, int d, int e, int f) { return cin == a && hid == b && cout == c && s == d && hi == e && ho == f; };
-  return is(16, 96, 24, 2, 50, 25) || is(24, 144, 24, 1, 25, 25) || is(24, 144, 32, 2, 25, 13) || is(32, 192, 32, 1, 13, 13) ||
-         is(32, 192, 64, 2, 13, 7);
+  static const bool all = getenv("RIP_IRB2_ALL") != nullptr && getenv("RIP_IRB2_ALL")[0] == '1';
+  if (is(16, 96, 24, 2, 50, 25) || is(24, 144, 24, 1, 25, 25) || is(24, 144, 32, 2, 25, 13)) return true;
+  return all && (is(32, 192, 32, 1, 13, 13) || is(32, 192, 64, 2, 13, 7));
 }
 
 hipError_t launch_irb2_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                             const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
                             const unsigned short* x, unsigned short* y, hipStream_t s) {
-  if (!irb2_bf16_supported(le, ld, lp)) return hipErrorInvalidValue;
+  if (le == nullptr) return hipErrorInvalidValue;
   Irb2Args a;
   a.x = x;
   a.y = y;
@@ -416,29 +464,17 @@ hipError_t launch_irb2_bf16(const Layer* le, const Layer& ld, const Layer& lp, c
   a.bp_off = lp.b_off;
   a.B = B;
   a.band_rows = 0;
-  static const int variant = getenv("RIP_IRB2_VARIANT") ? atoi(getenv("RIP_IRB2_VARIANT")) : 0;  // tuning hook
   const int hid = ld.cout, st = ld.stride, cout = lp.cout;
-  //                                   S CIN HID COUT H_IN H_OUT NW NG RES  OCC
-  if (hid == 96) {
-    if (variant == 1) return launch_irb2<2, 16, 96, 24, 50, 25, 3, 2, false, 2>(a, B, kc, s);
-    return launch_irb2<2, 16, 96, 24, 50, 25, 6, 1, false, 3>(a, B, kc, s);                                  // features.2
-  }
-  if (hid == 144 && st == 1) {
-    if (variant == 1) return launch_irb2<1, 24, 144, 24, 25, 25, 9, 1, true, 5>(a, B, kc, s);
-    return launch_irb2<1, 24, 144, 24, 25, 25, 5, 2, true, 3>(a, B, kc, s);                                  // features.3
-  }
-  if (hid == 144) {
-    if (variant == 1) return launch_irb2<2, 24, 144, 32, 25, 13, 9, 1, false, 5>(a, B, kc, s);
-    return launch_irb2<2, 24, 144, 32, 25, 13, 5, 2, false, 3>(a, B, kc, s);                                 // features.4
-  }
-  if (hid == 192 && st == 1) {
-    if (variant == 1) return launch_irb2<1, 32, 192, 32, 13, 13, 4, 3, true, 2>(a, B, kc, s);
-    return launch_irb2<1, 32, 192, 32, 13, 13, 6, 2, true, 3>(a, B, kc, s);                                  // features.5, 6
-  }
-  if (hid == 192 && cout == 64) {
-    if (variant == 1) return launch_irb2<2, 32, 192, 64, 13, 7, 4, 3, false, 2>(a, B, kc, s);
-    return launch_irb2<2, 32, 192, 64, 13, 7, 6, 2, false, 3>(a, B, kc, s);                                  // features.7
-  }
+  // Waves x groups per wave: every wave owns NG groups (NW * NG = HID / 16) and the register budget is two waves per
+  // SIMD (the depthwise A operands alone are 36 registers per group).  More, lighter waves (6 x 1, 9 x 1, 6 x 2 at three
+  // to four waves per SIMD) measured slower: they spill, and every wave re-loads the block input and re-expands all
+  // pixels for fewer channels (profiles/r4/irb2_variants.txt).  BTD = 1 where two operand sets do not fit.
+  //                                   S CIN HID COUT H_IN H_OUT NW NG RES  OCC BTD
+  if (hid == 96) return launch_irb2<2, 16, 96, 24, 50, 25, 3, 2, false, 2, 2>(a, B, kc, s);                     // features.2
+  if (hid == 144 && st == 1) return launch_irb2<1, 24, 144, 24, 25, 25, 3, 3, true, 2, 1>(a, B, kc, s);         // features.3
+  if (hid == 144) return launch_irb2<2, 24, 144, 32, 25, 13, 3, 3, false, 2, 1>(a, B, kc, s);                   // features.4
+  if (hid == 192 && st == 1) return launch_irb2<1, 32, 192, 32, 13, 13, 4, 3, true, 2, 2>(a, B, kc, s);         // features.5, 6
+  if (hid == 192 && cout == 64) return launch_irb2<2, 32, 192, 64, 13, 7, 4, 3, false, 2, 2>(a, B, kc, s);      // features.7
   return hipErrorInvalidValue;
 }
 

@@ -295,12 +295,17 @@ def test_mega_encoder_failure_is_reported_once_and_the_agent_recovers(dev):
 BF16_ULP = 2.0 ** -8   # relative spacing of bfloat16 (8 significand bits)
 
 
-def _bf16_layer_gate(tag, got, want, worst):
-  """One teacher-forced layer (or block) of the bf16 encoder against `oracle/bf16_encoder.py`: both ran the same
+def _bf16_layer_gate(tag, got, want, worst, layers=1):
+  """One teacher-forced layer (or fused block) of the bf16 encoder against `oracle/bf16_encoder.py`: both ran the same
   arithmetic on the same input, so they differ only where an fp32 sum that differs in its last places (summation order:
-  MFMA K-chunks vs torch's conv) falls on the other side of a bf16 rounding boundary — one bf16 ulp of the value.
-  Gate: |d| <= 2^-7 |ref| + 3e-5 max|ref| everywhere (2 ulp + the fp32 summation noise of cancelling sums); reported:
-  the fraction of elements that differ at all, and the worst error in ulps."""
+  MFMA K-chunks vs torch's conv; the 16-bit hi + lo depthwise taps of the fused blocks) falls on the other side of a
+  bf16 rounding boundary — one bf16 ulp of the value.
+  One layer: |d| <= 2^-7 |ref| + 3e-5 max|ref| EVERYWHERE (2 ulp + the fp32 summation noise of cancelling sums).
+  A fused block (3 layers, the two inner tensors never leave the chip): a flip of an INNER element moves the outputs it
+  feeds by |w| ulp(inner) — an absolute error, so near-zero outputs leave the relative bound; the gate is then >= 99 % of
+  the elements inside the one-layer bound and every element within 4 bf16 ulp OF THE TENSOR'S SCALE (2^-6 max|ref|): a
+  wrong tap, a dropped residual or a missing ReLU6 moves most elements by O(scale).
+  Reported: the fraction of elements that differ at all, and the worst error in ulps of the element."""
   got, want = got.double().cpu(), want.double()
   d = (got - want).abs()
   scale = float(want.abs().max())
@@ -308,8 +313,13 @@ def _bf16_layer_gate(tag, got, want, worst):
   frac = float((d > 0).double().mean())
   ulps = float((d / (BF16_ULP * want.abs().clamp_min(1e-3 * scale))).max())
   worst.append((ulps, frac, tag))
-  assert bool((d <= tol).all()), "%s: max |d| %.3g at scale %.3g (%.2f bf16 ulp), %.2f %% of the elements differ" % (
-      tag, float(d.max()), scale, ulps, 100 * frac)
+  inside = float((d <= tol).double().mean())
+  msg = "%s: max |d| %.3g at scale %.3g, %.3f %% of the elements differ, %.4f %% beyond the one-layer bound" % (
+      tag, float(d.max()), scale, 100 * frac, 100 * (1 - inside))
+  if layers == 1:
+    assert inside == 1.0, msg
+  else:
+    assert inside >= 0.99 and float(d.max()) <= 2.0 ** -6 * scale, msg
 
 
 def test_bf16_encoder_every_layer_teacher_forced_vs_bf16_oracle(dev):
@@ -338,25 +348,24 @@ def test_bf16_encoder_every_layer_teacher_forced_vs_bf16_oracle(dev):
   worst.sort(reverse=True)
   print("bf16 layer-wise vs bf16 oracle, teacher-forced: worst layers (ulp, fraction of elements that differ): " +
         "; ".join("%s %.2f ulp %.3f %%" % (t, u, 100 * f) for u, f, t in worst[:4]))
-  assert max(f for _, f, _ in worst) < 0.05  # flips are rare: a systematic difference would touch most elements
+  assert max(f for _, f, _ in worst) < 0.01  # flips are rare: a systematic difference would touch most elements
 
 
-@pytest.mark.parametrize("B", [3, 64])
-def test_bf16_fused_blocks_teacher_forced_vs_bf16_oracle(dev, B):
-  """The SHIPPED bf16 kernels (front kernel, row-streaming and tile blocks: RIP_OPT_ENCODER_FUSED = 17; B = 64 is where
-  `auto` engages the tile blocks too): every block output that reaches memory, teacher-forced per block against the
-  bf16 oracle from the HIP path's own block input — the gate that makes restructuring those kernels safe.  Reported:
-  whether each block is still bit-identical to the layer-wise kernels."""
+def _fused_blocks_vs_oracle(dev, B, C, seed):
+  """The SHIPPED bf16 kernels (RIP_OPT_ENCODER_FUSED = 17: front kernel, row-streaming blocks with the depthwise on the
+  matrix cores, tile blocks): every block output that reaches memory, teacher-forced per block against the bf16 oracle
+  from the HIP path's own block input, for three rows of the batch (first, middle, last: the last workgroup's partly
+  empty observation group / pixel tiles)."""
   from oracle import bf16_encoder as BE
+  from oracle import reference_cpu as O
   from oatomobile_amd import _lib, arch
-  m, mo = hip_model(22, dev, max_batch=B), oracle_model(22)
+  m = hip_model(seed, dev, max_batch=B, in_channels=C)
+  mo = O.OracleImitativeModel.from_numpy_state_dict(W.synthetic_state_dict(seed, C), in_channels=C)
   m.encoder_dtype = "bf16"
-  rng = np.random.default_rng(5)
-  obs = [synth_observation(np.random.default_rng(2000 + i)) for i in range(min(B, 4))]
-  vis = ctx_tensors(obs, dev)["visual_features"]
-  vis = vis.repeat((B + vis.shape[0] - 1) // vis.shape[0], 1, 1, 1)[:B].contiguous()
-  vis = (vis * torch.from_numpy(rng.uniform(0.5, 1.0, size=(B, 1, 1, 1)).astype(np.float32)).to(dev)).contiguous()
-  L = len(arch.conv_layers())
+  rng = np.random.default_rng(5 + B)
+  vis = torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32))
+  vis = (vis * (torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32)) < 0.3)).to(dev)  # sparse, like a BEV
+  L = len(arch.conv_layers(C))
   m.fused_encoder = 17
   fused, ranges, first = {}, [], 0
   for i in range(L):
@@ -366,33 +375,65 @@ def test_bf16_fused_blocks_teacher_forced_vs_bf16_oracle(dev, B):
       continue  # interior to a fused block
     ranges.append((first, i))
     first = i + 1
-  assert len(ranges) >= 18 and any(b - a == 2 for a, b in ranges), ranges  # blocks really ran fused
-  m.fused_encoder = 0
-  check = sorted({0, B // 2, B - 1})  # the oracle runs these rows (CPU seconds), the bit-identity report all of them
-  identical = []
-  worst = []
+  assert len(ranges) >= 18 and sum(b - a == 2 for a, b in ranges) >= 16, ranges  # the blocks really ran fused
+  check = sorted({0, B // 2, B - 1})
   pooled = fused.pop(L - 1)
   want = BE.teacher_forced(mo, {i: t[check] for i, t in fused.items()}, vis[check].cpu(), ranges)
+  worst = []
   for a, b in ranges:
-    layerwise = m.encoder_layer_output(vis, b).cpu()
     if b == L - 1:
-      identical.append(bool(torch.equal(layerwise, pooled)))
       ref = want[b].double().mean(dim=(2, 3))
       assert float((pooled[check].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
       continue
-    identical.append(bool(torch.equal(layerwise, fused[b])))
-    _bf16_layer_gate("layers %d..%d" % (a, b), fused[b][check], want[b], worst)
-  worst.sort(reverse=True)
-  print("bf16 fused blocks, B = %d: %d / %d launches bit-identical to the layer-wise kernels; worst vs oracle: %s" %
-        (B, sum(identical), len(identical), "; ".join("%s %.2f ulp %.3f %%" % (t, u, 100 * f) for u, f, t in worst[:3])))
-  assert max(f for _, f, _ in worst) < 0.05
+    _bf16_layer_gate("layers %d..%d" % (a, b), fused[b][check], want[b], worst, layers=b - a + 1)
+  worst.sort(key=lambda t: -t[1])
+  print("bf16 fused blocks vs bf16 oracle, B = %d, C = %d: most differing blocks (fraction of elements): %s" %
+        (B, C, "; ".join("%s %.3f %%" % (t, 100 * f) for _, f, t in worst[:4])))
+  assert max(f for _, f, _ in worst) < 0.02  # 16-bit depthwise taps / bias: ~2^-8 of the elements flip per block
+
+
+@pytest.mark.parametrize("B", [1, 3, 9, 64, 130])
+def test_bf16_fused_blocks_teacher_forced_vs_bf16_oracle(dev, B):
+  """Batches that leave the last workgroup's observation group / pixel tiles partly empty (1, 3, 9, 130) and the size
+  from which `auto` engages the tile blocks (64).  Replaces round 3's z-level comparisons of fused against layer-wise
+  kernels: those held at 2-3 % only while the two were bit-identical — the encoder amplifies a single bf16 flip in
+  0.5 % of one early tensor to 4 % of max|z| (measured on the oracle, see test_bf16_encoder_end_to_end), so z cannot
+  gate a kernel; a teacher-forced block can."""
+  _fused_blocks_vs_oracle(dev, B, 2, 22)
+
+
+def test_bf16_fused_blocks_four_channel_bev_vs_bf16_oracle(dev):
+  """BASELINE configs[1] input (200x200x4 BEV): the fused front (stem + features.1 with C = 4: its LDS input band is
+  twice as large, one workgroup per CU) and every other block, 160 observations."""
+  _fused_blocks_vs_oracle(dev, 160, 4, 33)
+
+
+def test_bf16_block_kernels_everywhere_subprocess(dev):
+  """The matrix-core depthwise kernel ships for features.2-4 only (it is slower on the 13x13 / 7x7-output blocks);
+  RIP_IRB2_ALL=1 runs it on features.5-7 as well, RIP_IRB_OLD=1 runs round 3's kernel everywhere: both selections are
+  read once per process, so the teacher-forced block test runs again in a child process under each."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  for var in ("RIP_IRB2_ALL", "RIP_IRB_OLD"):
+    if os.environ.get(var) == "1":
+      pytest.skip("already running under %s" % var)
+  for var in ("RIP_IRB2_ALL", "RIP_IRB_OLD"):
+    env = dict(os.environ, **{var: "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_bf16_fused_blocks_teacher_forced_vs_bf16_oracle and (3 or 64)"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "%s=1:\n%s" % (var, r.stdout[-3000:] + r.stderr[-2000:])
 
 
 def test_bf16_encoder_end_to_end_vs_bf16_oracle(dev):
-  """BASELINE config 3 end to end: z of the shipped bf16 path (auto kernel selection) against the bf16 oracle at <= 1 %
-  of max|z| (replaces round 3's 10 % / 2 % gate against the FP32 oracle: that distance is the storage format's own
-  effect — reported below — not an error of the kernels).  16 observations reach the streaming / block-GEMM kernels
-  (M >= 32768); the same observations two at a time take the small-batch kernels."""
+  """BASELINE config 3 end to end.  z of the shipped bf16 path against the bf16 oracle, gated by what the oracle ITSELF
+  does under the only freedom a correct bf16 implementation has — which way an element on a rounding boundary falls:
+  `flip_noise` re-runs the oracle with 0.5 % of the elements of every block output moved by one bf16 ulp (the rate the
+  teacher-forced block tests measure for the kernels) and the HIP deviation must stay within twice the largest of three
+  such runs.  (A flat 1 % of max|z| is not attainable by any kernel that sums in a different order: the random-weight
+  MobileNetV2 amplifies those flips to several per cent of max|z|; the tight gates are the per-layer / per-block ones.)
+  Reported next to it: the storage format's own effect (bf16 oracle vs fp32 oracle)."""
   from oracle import bf16_encoder as BE
   from oracle import reference_cpu as O
   m, mo = hip_model(21, dev), oracle_model(21)
@@ -408,10 +449,12 @@ def test_bf16_encoder_end_to_end_vs_bf16_oracle(dev):
   zo16 = BE.params(mo, **cpu).numpy()
   np.testing.assert_allclose(z32, zo32, atol=TOL)
   scale = np.abs(zo16).max()
+  floor = max(np.abs(BE.params(mo, **cpu, flip_fraction=0.005, flip_seed=s).numpy() - zo16).max() for s in (1, 2, 3))
+  print("oracle under one-ulp flips of 0.5 %% of every block output: max|dz| = %.3g (%.2f %% of max|z| = %.3g)" % (floor, 100 * floor / scale, scale))
   for tag, z in (("auto kernels, B = 16", z16), ("small-batch kernels, B = 2", z16_small)):
     err = np.abs(z - zo16)
-    print("bf16 encoder vs bf16 oracle (%s): max|dz| = %.3g, mean|dz| = %.3g, max|z| = %.3g" % (tag, err.max(), err.mean(), scale))
-    assert err.max() <= 0.01 * scale, tag
+    print("bf16 encoder vs bf16 oracle (%s): max|dz| = %.3g, mean|dz| = %.3g" % (tag, err.max(), err.mean()))
+    assert err.max() <= 2.0 * floor, tag
   fmt = np.abs(zo16 - zo32)
   print("bf16 storage format itself (bf16 oracle vs fp32 oracle): max|dz| = %.3g, mean|dz| = %.3g" % (fmt.max(), fmt.mean()))
   assert not np.array_equal(z16, z32)  # really a different arithmetic
@@ -441,79 +484,6 @@ def test_bf16_encoder_large_batch_kernels_match_small_batch(dev):
   # rows are independent: the tail of the batch equals the same observations computed alone
   z_tail = m._params(**{k: v[B - 4:].contiguous() for k, v in ctx.items()}).cpu().numpy()
   assert np.abs(z_big[B - 4:] - z_tail).max() <= 0.03 * np.abs(z_small).max()
-
-
-def test_bf16_fused_blocks_match_layerwise_same_batch(dev):
-  """RIP_OPT_ENCODER_FUSED on the bf16 path: the fused row-streaming blocks (features.2-7) against the layer-wise
-  kernels on the SAME 256 observations (same large-batch depthwise / GEMM kernels elsewhere); the only differences
-  fused kernel keeps every fp32 accumulation in the layer-wise order and rounds to bf16 (RNE) at the same points, so
-  the two paths currently agree bit for bit (a rocprofv3 trace shows 6 `irb_rows_bf16_kernel` launches with the
-  option at 7 and none at 0); the tolerance leaves room for a reordered accumulation."""
-  B = 256
-  m = hip_model(29, dev, max_batch=B)
-  m.encoder_dtype = "bf16"
-  rng = np.random.default_rng(78)
-  vis = torch.from_numpy(rng.random((B, 2, 100, 100), dtype=np.float32)).to(dev)
-  vis[:, :, :, 60:] = 0
-  ctx = dict(visual_features=vis,
-             velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
-             is_at_traffic_light=torch.zeros(B, 1, device=dev),
-             traffic_light_state=torch.ones(B, 1, device=dev))
-  m.fused_encoder = 0
-  z_layer = m._params(**ctx).cpu().numpy()
-  for nfused in (7, 17):  # 7: row-streaming blocks (features.2-7); 17: + the 7x7 / 4x4 tile blocks (features.8-17)
-    m.fused_encoder = nfused
-    z_fused = m._params(**ctx).cpu().numpy()
-    d = np.abs(z_fused - z_layer)
-    print("bf16 fused=%d vs layer-wise: max|dz| = %.3g of max|z| = %.3g" % (nfused, d.max(), np.abs(z_layer).max()))
-    assert np.isfinite(z_fused).all()
-    assert d.max() <= 0.03 * np.abs(z_layer).max()
-
-
-@pytest.mark.gpu
-def test_bf16_fused_kernels_four_channel_bev(dev):
-  """BASELINE configs[1] input (200x200x4 BEV) on the bf16 encoder: the fused front (stem + features.1 with C = 4:
-  its LDS input band is twice as large, one workgroup per CU), the row-streaming and the tile blocks against the
-  layer-wise kernels on the same 160 observations."""
-  B = 160
-  m = hip_model(33, dev, in_channels=4, max_batch=B)
-  m.encoder_dtype = "bf16"
-  rng = np.random.default_rng(81)
-  ctx = dict(visual_features=torch.from_numpy(rng.random((B, 4, 100, 100), dtype=np.float32)).to(dev),
-             velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
-             is_at_traffic_light=torch.zeros(B, 1, device=dev),
-             traffic_light_state=torch.ones(B, 1, device=dev))
-  m.fused_encoder = 0
-  z_layer = m._params(**ctx).cpu().numpy()
-  for nfused in (1, 17):  # 1: only the front kernel; 17: everything that has a fused kernel
-    m.fused_encoder = nfused
-    z_fused = m._params(**ctx).cpu().numpy()
-    d = np.abs(z_fused - z_layer)
-    print("C=4 bf16 fused=%d vs layer-wise: max|dz| = %.3g of max|z| = %.3g" % (nfused, d.max(), np.abs(z_layer).max()))
-    assert np.isfinite(z_fused).all()
-    assert d.max() <= 0.02 * np.abs(z_layer).max()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3, 9, 130])
-def test_bf16_tile_blocks_ragged_batches(dev, B):
-  """encoder_bf16_tile.hip (features.8-17 fused per block): batches that leave the last workgroup's observation
-  group partly empty and pixel tiles partly filled, against the layer-wise bf16 kernels on the same inputs."""
-  m = hip_model(31, dev, max_batch=B)
-  m.encoder_dtype = "bf16"
-  rng = np.random.default_rng(100 + B)
-  ctx = dict(visual_features=torch.from_numpy(rng.random((B, 2, 100, 100), dtype=np.float32)).to(dev),
-             velocity=torch.from_numpy(rng.normal(0, 3, size=(B, 3)).astype(np.float32)).to(dev),
-             is_at_traffic_light=torch.zeros(B, 1, device=dev),
-             traffic_light_state=torch.ones(B, 1, device=dev))
-  m.fused_encoder = 0
-  z_layer = m._params(**ctx).cpu().numpy()
-  m.fused_encoder = 17
-  z_tile = m._params(**ctx).cpu().numpy()
-  d = np.abs(z_tile - z_layer)
-  print("B=%d: max|dz| = %.3g of max|z| = %.3g" % (B, d.max(), np.abs(z_layer).max()))
-  assert np.isfinite(z_tile).all()
-  assert d.max() <= 0.02 * np.abs(z_layer).max()  # the layer-wise GEMMs split K differently at small batches: bf16 rounding noise
 
 
 def test_params_missing_key_raises(dev):
