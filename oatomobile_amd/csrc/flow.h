@@ -54,7 +54,14 @@ struct SearchArgs {
   float* trace_grad;     // [steps][B][N][8] dLoss/dx of every Adam step, or nullptr
   int regroup = 0;       // split kernel: regroup a workgroup's candidates by selected model between Adam steps (RIP_OPT_SEARCH_REGROUP)
   unsigned long long* stats = nullptr;  // device counter: += executed inverse-pass adjoints (phase-sequential kernels), or nullptr
+  // Operand-range guard of the split-f16 kernel (hidden states are split into binary16 terms unscaled: |h| <= max(1, |z|)
+  // must stay below the binary16 range).  `range_flag` is a device word the split launch zeroes and its prefix kernel
+  // raises when some |z| >= SPLIT_Z_LIMIT; the split kernel then does nothing and the fp32-MFMA kernel, launched behind
+  // it with `run_if_flag` = the same word, does the whole search instead (it exits at once when the word is 0).
+  unsigned* range_flag = nullptr;
+  const unsigned* run_if_flag = nullptr;
 };
+constexpr float SPLIT_Z_LIMIT = 16384.0f;  // binary16 overflows at 65504; hidden states reach max(1, |z|)
 
 // Gradient-mode model-parallel search: one Adam step split at the exchange point.
 struct MpArgs {

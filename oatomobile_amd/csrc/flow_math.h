@@ -23,18 +23,29 @@ __device__ __forceinline__ float softplus_gradf_(float x) { return x > 20.0f ? 1
 
 
 // goal log-likelihood of the last waypoint and (optionally) its gradient  (dim/model.py:163-171)
+// -|y - g|^2 / (2 eps^2) of one goal, with every operation rounded on its own (no fma contraction): goal_ll evaluates
+// it twice per goal (running maximum, then the exponentials) and the two values of the arg-max goal must be THE SAME
+// float — at |y| ~ 5e4 one ulp of the quadratic is 128, and a contraction chosen differently in the two loops made the
+// largest exponent -128 instead of 0: every term underflowed, log(0) = -inf (found by test_split_kernel_operand_ranges).
+__device__ __forceinline__ float goal_arg(const float* __restrict__ goal, int j, float inv2, float y0, float y1, float* d0o,
+                                          float* d1o) {
+  const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
+  *d0o = d0;
+  *d1o = d1;
+  return __fmul_rn(-__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), inv2);
+}
 __device__ __forceinline__ float goal_ll(const float* __restrict__ goal, int G, float eps, float y0, float y1,
                                          float* g0, float* g1) {
   const float inv2 = 1.0f / (2.0f * eps * eps);
   float m = -INFINITY;
   for (int j = 0; j < G; ++j) {
-    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
-    m = fmaxf(m, -(d0 * d0 + d1 * d1) * inv2);
+    float d0, d1;
+    m = fmaxf(m, goal_arg(goal, j, inv2, y0, y1, &d0, &d1));
   }
   float se = 0.f, a0 = 0.f, a1 = 0.f;
   for (int j = 0; j < G; ++j) {
-    const float d0 = y0 - goal[2 * j], d1 = y1 - goal[2 * j + 1];
-    const float e = __expf(-(d0 * d0 + d1 * d1) * inv2 - m);  // argument <= 0; v_exp_f32 (~1 ulp) is plenty for 1e-4
+    float d0, d1;
+    const float e = __expf(goal_arg(goal, j, inv2, y0, y1, &d0, &d1) - m);  // argument <= 0, == 0 for the arg-max goal
     se += e;
     a0 = fmaf(e, -d0, a0);
     a1 = fmaf(e, -d1, a1);

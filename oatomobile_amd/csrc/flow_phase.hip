@@ -684,6 +684,7 @@ __device__ __forceinline__ void load_tbuf(PShared<WPB>& sh, const float* __restr
 // the operands read straight from global memory (L2) — a 2 x 251-MFMA kernel in front of the search.
 __global__ __launch_bounds__(64) void phase_prefix_kernel(SearchArgs a, const float* __restrict__ mw_all,
                                                           float* __restrict__ pre_out) {
+  if (a.run_if_flag != nullptr && __builtin_nontemporal_load(a.run_if_flag) == 0u) return;  // fallback launch, not needed
   const int lane = threadIdx.x, q = lane >> 4;
   const int b = blockIdx.x, k = blockIdx.y;
   const float4* wl = reinterpret_cast<const float4*>(mw_all + (size_t)(a.k0 + k) * MW_SIZE) + lane;
@@ -729,6 +730,8 @@ __global__ __launch_bounds__(WPB * 64) void search_phase_kernel(SearchArgs a, co
                                                                 float4* __restrict__ tape_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   PShared<WPB>& sh = *reinterpret_cast<PShared<WPB>*>(smem_raw);
+  // launched behind the split-f16 kernel as its operand-range fallback: nothing to do unless that launch raised the word
+  if (a.run_if_flag != nullptr && __builtin_nontemporal_load(a.run_if_flag) == 0u) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -88,6 +88,12 @@ __global__ __launch_bounds__(64) void split_prefix_kernel(SearchArgs a, const ui
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int r = 0; r < 4; ++r) H[u * 4 + r] = a.z[((size_t)k * a.B + b) * 64 + 16 * u + 4 * q + r];
+  if (a.range_flag != nullptr) {  // operand-range guard: NaN counts as out of range
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, H[i] == H[i] ? fabsf(H[i]) : SPLIT_Z_LIMIT);
+    if (__any(m >= SPLIT_Z_LIMIT) && lane == 0) atomicOr(a.range_flag, 1u);
+  }
   float o[4];
   BSplit hs;
   split16(H, hs);
@@ -127,6 +133,9 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
                                                                 float4* __restrict__ tape_all, float4* __restrict__ park_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   PShared<WPB>& sh = *reinterpret_cast<PShared<WPB>*>(smem_raw);
+  // operand-range guard: some |z| of this launch is beyond what the unscaled binary16 split carries -> the fp32-MFMA
+  // kernel behind this launch does the search (the whole launch: one word, read by every workgroup, uniform)
+  if (a.range_flag != nullptr && __builtin_nontemporal_load(a.range_flag) != 0u) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -474,6 +483,10 @@ hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void
   float* pre = reinterpret_cast<float*>(scratch);
   const size_t pre_bytes = ((size_t)a.K * a.B * PRE_FLOATS * sizeof(float) + 255) / 256 * 256;
   float4* tape = reinterpret_cast<float4*>(reinterpret_cast<char*>(scratch) + pre_bytes);
+  if (a.range_flag != nullptr) {
+    hipError_t e = hipMemsetAsync(a.range_flag, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(split_prefix_kernel, dim3(a.B, a.K), dim3(64), 0, s, a, mh_all, pre);
   const int items = a.B * (a.N / CB);
   const size_t items_pad = ((size_t)items + WPB_MAX - 1) / WPB_MAX * WPB_MAX;

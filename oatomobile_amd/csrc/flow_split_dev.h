@@ -82,9 +82,13 @@ __device__ __forceinline__ float qmax(float m) {
   auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
   return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
 }
-// power of two that moves `amax` (>= 0) to [2^13, 2^14), and its inverse; amax == 0 -> 1
+// power of two that moves `amax` (>= 0) to [2^13, 2^14), and its inverse; amax == 0 -> 1.  The exponent is clamped at
+// -100: a candidate whose gate gradients have all but vanished (saturated gates: r (1 - r) ~ 1e-35 at |z| ~ 1e3) would
+// otherwise ask for 2^130 = inf, and inf * 0 = NaN in every zero entry (found by test_split_kernel_operand_ranges;
+// below 2^-100 the scaled values are simply smaller than 2^13, which loses nothing that matters).
 __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
-  const int e = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) : 14;  // amax = f * 2^e, f in [0.5, 1)
+  int e = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) : 14;  // amax = f * 2^e, f in [0.5, 1)
+  e = e < -100 ? -100 : e;
   s = __builtin_ldexpf(1.0f, 14 - e);
   inv = __builtin_ldexpf(1.0f, e - 14);
 }

@@ -50,6 +50,7 @@ struct rip_handle {
   float* trace_loss = nullptr; // [RIP_MAX_STEPS][max_batch]   (ImitativeModel.forward)
   float* trace_x = nullptr;    // [RIP_MAX_STEPS][max_batch][8]
   unsigned long long* stats = nullptr;  // [1] executed inverse-pass adjoints of the phase-sequential kernels (rip_search_stats)
+  unsigned* range_flag = nullptr;        // operand-range word of the split-f16 search (flow.h SearchArgs)
   // one-launch fp32 encoder for small batches (encoder.hip: encoder_mega_kernel)
   int encoder_mega = -1;        // -1 auto (= never: the launches measured faster), 0 never, 1 whenever the batch fits mega_max_b
   int mega_max_b = 0;           // 0: not available on this device / handle
@@ -234,9 +235,10 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
   ALLOC(h->trace_x, (size_t)RIP_MAX_STEPS * max_batch * 8);
   {
     float* tmp = nullptr;
-    ALLOC(tmp, 2);
+    ALLOC(tmp, 4);  // the adjoint counter (8 bytes) + the split kernel's operand-range word
     h->stats = reinterpret_cast<unsigned long long*>(tmp);
-    (void)hipMemset(h->stats, 0, sizeof(unsigned long long));
+    h->range_flag = reinterpret_cast<unsigned*>(tmp + 2);
+    (void)hipMemset(h->stats, 0, 4 * sizeof(float));
   }
   // scratch of the MFMA search kernels (adjoint tape, prefix table): 0 when neither can ever run for this handle
   h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
@@ -644,9 +646,18 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
     if (need > h->tape_bytes)
       return fail(RIP_ESTATE, "MFMA search scratch for B=%d N=%d needs %zu B, rip_create sized %zu B (max_batch=%d x "
                   "max_candidates=%d)", B, N, need, h->tape_bytes, h->max_batch, h->max_candidates);
-    if (kernel == 4)
+    if (kernel == 4) {
+      // hidden states are split into binary16 terms unscaled (|h| <= max(1, |z|)): a launch with some |z| >= 2^14 raises
+      // a device word in its prefix kernel, the split kernel then returns at once and the fp32-MFMA kernel queued behind
+      // it (which returns at once otherwise: ~10 us of empty workgroups per launch) runs the search — no silent inf
+      a.range_flag = h->range_flag;
       HIP_TRY(launch_search_split(a, h->split_w, h->tape, (hipStream_t)stream));
-    else if (kernel == 3)
+      if (search_phase_supported(a) && search_phase_scratch_bytes(B, N, h->K) <= h->tape_bytes) {
+        a.run_if_flag = h->range_flag;
+        a.range_flag = nullptr;
+        HIP_TRY(launch_search_phase(a, h->mfma_w, h->tape, (hipStream_t)stream));
+      }
+    } else if (kernel == 3)
       HIP_TRY(launch_search_phase(a, h->mfma_w, h->tape, (hipStream_t)stream));
     else
       HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));

@@ -615,6 +615,80 @@ def test_teacher_forced_steps_vs_oracle(dev, kernel, algo, K):
   np.testing.assert_allclose(grad_h[ok], grad_o[ok], rtol=1e-4, atol=TOL)
 
 
+def _scaled_flow_models(seeds, wscale, dev):
+  """HIP and oracle models from the synthetic weights with the flow (GRU + head) weights multiplied by `wscale`."""
+  from oatomobile_amd import ImitativeModel
+  from oracle import reference_cpu as O
+  hips, refs = [], []
+  for s in seeds:
+    sd = W.synthetic_state_dict(s)
+    for key in sd:
+      if key.startswith("_decoder.") and key.endswith(("weight_ih", "weight_hh", "0.weight", "2.weight")):
+        sd[key] = (sd[key] * np.float32(wscale)).astype(np.float32)
+    hips.append(ImitativeModel().load_numpy_state_dict(sd).to(dev))
+    refs.append(O.OracleImitativeModel.from_numpy_state_dict(sd))
+  return hips, refs
+
+
+@pytest.mark.parametrize("zscale,wscale", [(1e-3, 1.0), (1.0, 1.0), (1e2, 1.0), (1e3, 1.0), (1.0, 0.1), (1.0, 10.0), (5e3, 1.0)])
+def test_split_kernel_operand_ranges(dev, zscale, wscale):
+  """the split-f16 kernel carries hidden states as two binary16 terms UNSCALED (|h| <= max(1, |z|)) —
+  every other test drives it with O(1) z and weights.  One teacher-forced Adam step (algorithm MA: every model's adjoint
+  reaches the gradient, no arg-best ties) against the oracle with z scaled by 1e-3 .. 1e3 (lo' terms near the subnormal
+  range / hi terms in the thousands), flow weights x0.1 / x10 (saturated gates) and goals 100 m away.  Bar: 1e-4 relative
+  to max(1, |posterior|) (gradients: to the candidate's largest entry) — or, where the conditioning of the inputs puts
+  that out of reach of fp32 arithmetic itself, no worse than twice what the fp32-MFMA kernel (`phase`) reaches on the
+  same launch.  z x 5e3 (max |z| ~ 2e4) is past the limit the split kernel accepts (2^14; binary16 ends at 65504): its
+  prefix kernel raises the operand-range word, the split kernel returns and the fp32-MFMA kernel queued behind it runs
+  the step — bit for bit the fp32 kernel's result, no silent inf.
+  Found with this test and fixed: `pow2_scale` overflowed to inf for candidates whose gate gradients had all but
+  vanished (NaN gradients at z x 1e3), and `goal_ll` returned -inf at |y| ~ 5e4 (all kernels; flow_math.h)."""
+  from oatomobile_amd import _lib, RIPAgent
+  from oracle import reference_cpu as O
+  K, N, S, algo = 3, 128, 24, "MA"  # S x N = 3072 >= 2304: what `auto` would give the split kernel as well
+  hips, refs = _scaled_flow_models([300 + k for k in range(K)], wscale, dev)
+  rng = np.random.default_rng(11)
+  z_np = (np.abs(rng.normal(size=(K, S, 64))) * zscale).astype(np.float32)  # a ReLU output: non-negative
+  z_np[:, :, ::7] = 0.0
+  goal_np = (np.cumsum(np.abs(rng.normal(size=(S, 10, 2))) * 2.0, axis=1) + 100.0).astype(np.float32)
+  x_np = rng.normal(size=(S, N, 4, 2)).astype(np.float32)
+  z, goal, x = (torch.from_numpy(a).to(dev) for a in (z_np, goal_np, x_np))
+  lib = _lib.load()
+
+  def one_step(kernel):
+    agent = RIPAgent(None, algorithm=algo, models=hips, num_candidates=N, seed=9, search_kernel=kernel, max_batch=S)
+    handle = agent._handle
+    lb = torch.empty(S, N, device=dev)
+    tp = torch.empty(1, K, S, N, device=dev)
+    tg = torch.empty(1, S, N, 4, 2, device=dev)
+    _lib.check(lib.rip_search(handle.raw, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(x), S, N, 10, _lib.ALGORITHMS[algo], 1, 0.1,
+                              1.0, None, None, _lib.ptr(lb), None, _lib.ptr(tp), None, _lib.ptr(tg), handle.stream()))
+    return tp.cpu().numpy()[0].transpose(1, 0, 2), lb.cpu().numpy(), tg.cpu().numpy()[0]   # [S,K,N], [S,N], [S,N,4,2]
+
+  post_h, loss_h, grad_h = one_step("split")
+  post_p, loss_p, grad_p = one_step("phase")
+  bad = ~np.isfinite(post_h)
+  assert not bad.any() and np.isfinite(loss_h).all() and np.isfinite(grad_h).all(), (
+      "non-finite results: %d posteriors (first at [s,k,n] = %s), %d losses, %d gradient entries" %
+      (int(bad.sum()), np.argwhere(bad)[:4].tolist(), int((~np.isfinite(loss_h)).sum()), int((~np.isfinite(grad_h)).sum())))
+  if float(z_np.max()) >= 16384.0:  # past the split kernel's range: the fp32-MFMA kernel ran, bit for bit
+    assert np.array_equal(post_h, post_p) and np.array_equal(loss_h, loss_p) and np.array_equal(grad_h, grad_p)
+  # the oracle, one observation (= one z row per model) at a time
+  e_post, e_grad = {"split": 0.0, "phase": 0.0}, {"split": 0.0, "phase": 0.0}
+  for b in (0, S // 2, S - 1):
+    zs = [torch.from_numpy(z_np[k, b:b + 1]) for k in range(K)]
+    res = O.rip_search(refs, zs, torch.from_numpy(goal_np[b:b + 1]), torch.from_numpy(x_np[b]), algorithm=algo, num_steps=1)
+    post_o, grad_o = res["trace_post"].numpy()[0], res["trace_grad"].numpy()[0]   # [K,N], [N,4,2]
+    gmax = np.maximum(1.0, np.abs(grad_o).max(axis=(1, 2), keepdims=True))
+    for name, post, grad in (("split", post_h, grad_h), ("phase", post_p, grad_p)):
+      e_post[name] = max(e_post[name], float((np.abs(post[b] - post_o) / np.maximum(1.0, np.abs(post_o))).max()))
+      e_grad[name] = max(e_grad[name], float((np.abs(grad[b] - grad_o) / gmax).max()))
+  print("z x %g, flow weights x %g: relative error of the posteriors split %.3g / fp32 kernel %.3g, of the gradients %.3g / %.3g" %
+        (zscale, wscale, e_post["split"], e_post["phase"], e_grad["split"], e_grad["phase"]))
+  assert e_post["split"] <= max(1e-4, 2.0 * e_post["phase"])
+  assert e_grad["split"] <= max(1e-4, 2.0 * e_grad["phase"])
+
+
 def test_g7_dim_forward(golden, dev):
   g = golden("g7_dim_forward.npz")
   m = hip_model(7, dev)
@@ -788,7 +862,7 @@ def test_full_size_properties(dev):
   _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"], ob["goal"],
                       x0=agent._x0_rows.cpu()[:64], algorithm="WCM")  # the first 64 candidates suffice for the oracle
   lo, lh = res["loss_best"].numpy(), loss.cpu().numpy()[0, :64]
-  assert (np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.97
+  assert (np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.99
   perm = torch.randperm(N, generator=torch.Generator().manual_seed(0))
   agent._x0_rows = agent._x0_rows[perm.to(dev)].contiguous()
   agent._x0_cache = {}
