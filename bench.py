@@ -830,10 +830,11 @@ def _bench_train(args, dev, timed):
 def _rccl_seen(dist, dev, world):
   """What the collectives themselves saw: every rank contributes its index to an all-gather and a one to an all-reduce
   on DEVICE tensors (RCCL when the backend is nccl); `librccl_mapped` from /proc/self/maps."""
-  mine = torch.tensor([dist.get_rank()], device=dev, dtype=torch.int64)
+  where = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (the one-GPU test hook runs gloo: host tensors)
+  mine = torch.tensor([dist.get_rank()], device=where, dtype=torch.int64)
   got = [torch.empty_like(mine) for _ in range(world)]
   dist.all_gather(got, mine)
-  ones = torch.ones(1, device=dev)
+  ones = torch.ones(1, device=where)
   dist.all_reduce(ones)
   torch.cuda.synchronize()
   with open("/proc/self/maps") as f:

@@ -113,6 +113,12 @@ hipError_t launch_front_bf16(const Layer& ls, const Layer& ld, const Layer& lp, 
                              const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B, const float* visual,
                              unsigned short* y, hipStream_t s);
 
+// round 4: the front with the stem and the depthwise on the matrix cores as well (encoder_bf16_front2.hip; C = 2 only)
+bool front2_bf16_supported(const Layer& ls, const Layer& ld, const Layer& lp);
+hipError_t launch_front2_bf16(const Layer& ls, const Layer& ld, const Layer& lp, const float* enc_w,
+                              const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B, const float* visual,
+                              unsigned short* y, hipStream_t s);
+
 // small-image stages (7x7 / 4x4 maps, features.8 .. features.17): encoder_bf16_tile.hip
 bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
 hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,

@@ -1122,8 +1122,11 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     const FusedBlock& fb = plan.blocks[0];
     front = true;
     in_block[0] = in_block[fb.dw] = in_block[fb.project] = 1;
-    hipError_t e = launch_front_bf16(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc,
-                                     B, visual, reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
+    static const bool front_old = getenv("RIP_FRONT_OLD") != nullptr && getenv("RIP_FRONT_OLD")[0] == '1';  // A/B hook
+    const bool f2 = !front_old && front2_bf16_supported(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project]);
+    hipError_t e = (f2 ? launch_front2_bf16 : launch_front_bf16)(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w,
+                                                                 enc_wh, ms, k0, kc, B, visual,
+                                                                 reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
     if (e != hipSuccess) return e;
     if (tapped((size_t)fb.project)) return hipGetLastError();
   }

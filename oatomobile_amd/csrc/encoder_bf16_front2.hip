@@ -1,0 +1,364 @@
+// Fused front of the bf16 encoder on gfx950, round 4: features.0 (3x3 stride-2 stem conv, 2 -> 32, ReLU6) and features.1
+// (t = 1 inverted residual: depthwise 3x3 on 32 channels, ReLU6, linear 1x1 32 -> 16) in one kernel with ALL THREE
+// convolutions on the matrix cores.
+//
+// torchvision v0.6.0 MobileNetV2 `features[0:2]` (reference call site oatomobile/torch/networks/perception.py:36-51), BN
+// folded.  Round 2's kernel (encoder_bf16_front.hip, kept for C != 2) ran the stem and the depthwise on the vector unit:
+// 2585 VALU instructions per wave and 10-row band, the vector pipe 72 % busy at two waves per SIMD, 282 us per 512
+// observations x 4 models.  The stem is a K = 18 contraction (2 channels x 9 taps) per output: ONE 32-deep K block.
+//   * stem: the fp32 input band is staged in LDS as (hi, lo) bf16 pairs — x = hi + lo to 16 significant bits, the same
+//     4 bytes per value — and the folded fp32 weights are split the same way; a 16-pixel x 16-channel tile is three
+//     MFMAs (Whi xhi + Wlo xhi + Whi xlo; the dropped Wlo xlo is 2^-18 relative), the bias rides in K columns 18 / 19
+//     (hi / lo against B = 1.0).  The B operand of lane (n, q) = taps 8q .. 8q+7 of pixel n: eight 4-byte LDS reads and
+//     eight v_perm_b32 that separate the hi and lo halves.
+//   * depthwise: the block-diagonal contraction of encoder_bf16_irb2.hip (taps as hi + lo bf16 terms, nine MFMAs per 16
+//     pixels x 16 channels, bias as the C operand), reading the stem's bf16 output from LDS.
+//   * projection: the depthwise result of a lane — channels 4q .. 4q+3 of both 16-channel groups — IS its B operand
+//     (K order [g0: 4q..4q+3, g1: 4q..4q+3], the A operand gathers the weights accordingly): no LDS round trip.
+// A workgroup owns (model, observation, band of RB output rows): stage -> barrier -> stem tiles -> barrier -> depthwise +
+// projection tiles, four waves, pixel tiles of 16 across row boundaries.
+#include <stdlib.h>
+
+#include "encoder.h"
+#include "flow.h"
+
+namespace rip {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ float relu6(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// (hi, lo) bf16 terms of an fp32 value, hi in the low half: value ~= hi + lo to 16 significant bits
+__device__ __forceinline__ unsigned split_bf16(float f) {
+  const unsigned h = bf16_rne(f);
+  const unsigned l = bf16_rne(f - __uint_as_float(h << 16));
+  return h | (l << 16);
+}
+// the same for two values at once: v_cvt_pk_bf16_f32 x 2 + unpack / subtract; returns the two packed (hi | lo << 16) words
+__device__ __forceinline__ void split_bf16_2(float a, float b, unsigned& wa, unsigned& wb) {
+  const unsigned h = pack_bf16(a, b);                                     // (hi_a, hi_b)
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  const unsigned l = pack_bf16(ra, rb);                                   // (lo_a, lo_b)
+  wa = __builtin_amdgcn_perm(l, h, 0x05040100u);                          // (h.lo16, l.lo16)
+  wb = __builtin_amdgcn_perm(l, h, 0x07060302u);                          // (h.hi16, l.hi16)
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, int bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+constexpr int OOB = 0x40000000;
+constexpr unsigned ONES = 0x3F803F80u;  // two bf16 1.0
+
+constexpr int RB = 10;            // output rows per workgroup
+constexpr int HI = 100, HS = 50;  // input / stem (= output) map
+constexpr int SR = RB + 2;        // stem rows of a band (halo of the depthwise)
+constexpr int IR = 2 * SR + 1;    // input rows of a band
+constexpr int PADL = 4;           // input column ix sits at word ix + PADL (16-byte aligned staging stores)
+constexpr int IW = HI + 8;        // words per staged input row
+constexpr int SW = HS + 2;        // stem row: zero slot, HS pixels, zero slot
+constexpr int SLD = 40;           // bf16 elements per stem pixel slot (32 channels + 8: odd multiple of 16 bytes)
+constexpr int XS_WORDS = 2 * IR * IW;
+constexpr int SS_EL = SR * SW * SLD;
+constexpr int DUMP_EL = 64;       // where lanes beyond the band's pixels store
+constexpr size_t LDS_BYTES = (size_t)XS_WORDS * 4 + (size_t)(SS_EL + DUMP_EL) * 2;
+
+struct Front2Args {
+  const float* in;       // [B][2][HI][HI] fp32
+  bf16_t* out;           // [K][B][HS][HS][16]
+  const float* wbase;    // fp32 folded blobs
+  const bf16_t* whbase;  // bf16 copy (projection weights)
+  size_t model_stride;
+  int k0;
+  size_t ws_off, bs_off, wd_off, bd_off, wp_off, bp_off;
+  int B;
+  int bands;  // row bands per observation; a workgroup loops over the (observation, band) items of ONE model
+};
+
+__global__ __launch_bounds__(256, 2) void front2_bf16_kernel(Front2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned* xs = reinterpret_cast<unsigned*>(smem_raw);                     // [2][IR][IW] (hi | lo << 16), zero borders
+  bf16_t* ss = reinterpret_cast<bf16_t*>(smem_raw + (size_t)XS_WORDS * 4);  // [SR][SW][SLD] stem output, zero borders
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.z;
+  const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
+  const bf16_t* Wh = a.whbase + (size_t)(a.k0 + k) * a.model_stride;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int nitems = a.B * a.bands;
+
+  // ---- once per workgroup: the padding words of the staged rows, the border slots of the stem rows, the dump slot ----
+  for (int e = tid; e < 2 * IR * 2; e += 256) {
+    const int cr = e >> 1, side = e & 1;
+    *reinterpret_cast<u32x4*>(xs + (size_t)cr * IW + (side ? HI + PADL : 0)) = zero4;
+  }
+  for (int e = tid; e < SR * 2 * (SLD / 8); e += 256) {
+    const int c8 = e % (SLD / 8), side = (e / (SLD / 8)) & 1, r = e / (2 * (SLD / 8));
+    *reinterpret_cast<u32x4*>(ss + ((size_t)r * SW + (side ? SW - 1 : 0)) * SLD + 8 * c8) = zero4;
+  }
+  if (tid < DUMP_EL / 8) reinterpret_cast<u32x4*>(ss + SS_EL)[tid] = zero4;
+
+  // the input band of an item: every thread's float4 groups, ALL requested before anything waits for them
+  constexpr int Q4 = HI / 4, TOTAL = 2 * IR * Q4;  // float4 groups of a band
+  constexpr int NL = (TOTAL + 255) / 256;
+  auto load_input = [&](int item, float4(&v)[NL]) __attribute__((always_inline)) {
+    const int ib = item / a.bands, iband = item - ib * a.bands;
+    const int iiy0 = 2 * (iband * RB - 1) - 1;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int e = tid + 256 * j;
+      const int cr = e / Q4, x4 = e - cr * Q4;
+      const int c = cr / IR, r = cr - c * IR;
+      const int iy = iiy0 + r;
+      v[j] = (e < TOTAL && iy >= 0 && iy < HI) ? *reinterpret_cast<const float4*>(a.in + ((size_t)ib * 2 + c) * HI * HI + (size_t)iy * HI + 4 * x4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float4 vnext[NL];
+  if ((int)blockIdx.x < nitems) load_input(blockIdx.x, vnext);
+
+  // ---- per-lane constants ----
+  // stem A operands: K slot k = 8q + j holds tap (c, ky, kx) = (k / 9, (k % 9) / 3, k % 3) for k < 18, bias hi / lo at 18 / 19
+  u32x4 ash[2], asl[2];
+  int xoff[8];  // word offset of tap j of this lane relative to the pixel's window origin
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kk = 8 * q + j;
+    const int c = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
+    xoff[j] = kk < 18 ? (c * IR + ky) * IW + kx : 0;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int oc = 16 * ct + n;
+    unsigned hw[8], lw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = 8 * q + j;
+      const int c = kk / 9, t = kk % 9;
+      float wv_ = 0.f;
+      if (kk < 18) wv_ = W[a.ws_off + (size_t)(t * 2 + c) * 32 + oc];
+      unsigned s = split_bf16(wv_);
+      if (kk == 18) s = split_bf16(W[a.bs_off + oc]) & 0xffffu;           // bias hi (the lo operand holds nothing here)
+      if (kk == 19) s = split_bf16(W[a.bs_off + oc]) >> 16;              // bias lo, as a "hi" entry against B = 1.0
+      hw[j] = s & 0xffffu;
+      lw[j] = kk < 18 ? s >> 16 : 0u;
+    }
+    ash[ct] = u32x4{hw[0] | hw[1] << 16, hw[2] | hw[3] << 16, hw[4] | hw[5] << 16, hw[6] | hw[7] << 16};
+    asl[ct] = u32x4{lw[0] | lw[1] << 16, lw[2] | lw[3] << 16, lw[4] | lw[5] << 16, lw[6] | lw[7] << 16};
+  }
+  // the B operand's constant part: ones in K slots 18, 19 (lane block q == 2, dword 1 of the hi operand); the lo
+  // operand's dword 1 of that block is masked to zero (those lanes read arbitrary finite words for slots >= 18)
+  const unsigned ones_q2 = q == 2 ? ONES : 0u;
+  const unsigned keep_y = q == 2 ? 0u : 0xffffffffu;
+  // depthwise A operands (encoder_bf16_irb2.hip): K block kb = taps (2kb, 2kb+1) hi | (8 hi, 8 lo) | taps (2(kb-5), ..) lo
+  u32x4 ad[2][9];
+  f32x4 bdw[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const bool diag = (q & 1) == (n >> 3);
+    const int pos = n & 7;
+#pragma unroll
+    for (int kb = 0; kb < 9; ++kb) {
+      const int half = q >> 1;
+      const int tap = kb < 4 ? 2 * kb + half : (kb == 4 ? 8 : 2 * (kb - 5) + half);
+      const bool lo = kb > 4 || (kb == 4 && half == 1);
+      unsigned v16 = 0;
+      if (diag) {
+        const unsigned s = split_bf16(W[a.wd_off + (size_t)tap * 32 + 16 * g + n]);
+        v16 = lo ? (s >> 16) : (s & 0xffffu);
+      }
+      const unsigned dw = v16 << ((pos & 1) * 16);
+      ad[g][kb] = u32x4{(pos >> 1) == 0 ? dw : 0u, (pos >> 1) == 1 ? dw : 0u, (pos >> 1) == 2 ? dw : 0u, (pos >> 1) == 3 ? dw : 0u};
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(W + a.bd_off + 16 * g + 4 * q);
+    bdw[g] = f32x4{bb.x, bb.y, bb.z, bb.w};
+  }
+  // projection A operand in the K order the depthwise epilogue produces: slots 0..3 = hidden 4q .. 4q+3 of group 0, 4..7 of group 1
+  u32x4 apj;
+  {
+    const bf16_t* wr = Wh + a.wp_off + (size_t)n * 32;  // row n = output channel
+    const u32x2 g0 = *reinterpret_cast<const u32x2*>(wr + 4 * q), g1 = *reinterpret_cast<const u32x2*>(wr + 16 + 4 * q);
+    apj = u32x4{g0.x, g0.y, g1.x, g1.y};
+  }
+  const float4 bp4 = *reinterpret_cast<const float4*>(W + a.bp_off + 4 * q);
+  const f32x4 bpj = {bp4.x, bp4.y, bp4.z, bp4.w};
+  // depthwise B operand offsets (bytes) relative to the pixel's window origin: tap of the pair by q >> 1, channel half q & 1
+  int doff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int t = j < 4 ? 2 * j + (q >> 1) : 8;
+    doff[j] = ((t / 3) * SW + (t % 3)) * SLD * 2 + 16 * (q & 1);
+  }
+  // ---- persistent loop over this model's (observation, band) items: the NEXT item's input is requested before the
+  // depthwise phase of the current one, so its HBM latency is covered ----
+#pragma unroll 1
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int b = item / a.bands, band = item - b * a.bands;
+  const int oy0 = band * RB;
+  const int rows = min(RB, HS - oy0);
+  // ---- 1. stage the input band as (hi, lo) pairs (rows off the image were loaded as zeros) ----
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int e = tid + 256 * j;
+    const int cr = e / Q4, x4 = e - cr * Q4;
+    u32x4 wds;
+    unsigned w0, w1, w2, w3;
+    split_bf16_2(vnext[j].x, vnext[j].y, w0, w1);
+    split_bf16_2(vnext[j].z, vnext[j].w, w2, w3);
+    wds.x = w0, wds.y = w1, wds.z = w2, wds.w = w3;
+    if (e < TOTAL) *reinterpret_cast<u32x4*>(xs + (size_t)cr * IW + PADL + 4 * x4) = wds;
+  }
+  // stem rows off the map (above row 0 in the first band, below row HS - 1 in the last) are the depthwise's zero
+  // padding: zeroed here, and the stem tiles below send whatever they compute for them to the dump slot
+  for (int r = 0; r < SR; ++r) {
+    const int sr = oy0 - 1 + r;
+    if (sr >= 0 && sr < HS) continue;  // workgroup-uniform
+    for (int e = tid; e < SW * SLD / 8; e += 256) reinterpret_cast<u32x4*>(ss + (size_t)r * SW * SLD)[e] = zero4;
+  }
+  __syncthreads();  // the staged band is in place
+
+  // ---- 2. stem rows oy0-1 .. oy0+RB as 16-pixel tiles across rows (rows off the map: results go to the dump slot) ----
+  {
+    constexpr int P = SR * HS, NT = (P + 15) / 16;
+    for (int tile = wv; tile < NT; tile += 4) {
+      const int p = 16 * tile + n;
+      const bool pv = p < P;
+      const int pc = pv ? p : P - 1;
+      const int r = (pc * 1311) >> 16, ox = pc - r * HS;  // pc / 50 for pc < 2^15
+      const int sr = oy0 - 1 + r;
+      const bool rok = sr >= 0 && sr < HS;
+      const unsigned* xp = xs + (2 * r) * IW + 2 * ox + (PADL - 1);  // window origin: input row 2 sr - 1, column 2 ox - 1
+      unsigned wd[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wd[j] = xp[xoff[j]];
+      u32x4 bh, bl;
+      bh.x = __builtin_amdgcn_perm(wd[1], wd[0], 0x05040100u);
+      bh.y = __builtin_amdgcn_perm(wd[3], wd[2], 0x05040100u);
+      bh.z = __builtin_amdgcn_perm(wd[5], wd[4], 0x05040100u);
+      bh.w = __builtin_amdgcn_perm(wd[7], wd[6], 0x05040100u);
+      bl.x = __builtin_amdgcn_perm(wd[1], wd[0], 0x07060302u);
+      bl.y = __builtin_amdgcn_perm(wd[3], wd[2], 0x07060302u);
+      bl.z = __builtin_amdgcn_perm(wd[5], wd[4], 0x07060302u);
+      bl.w = __builtin_amdgcn_perm(wd[7], wd[6], 0x07060302u);
+      bh.y = (bh.y & keep_y) | ones_q2;
+      bl.y &= keep_y;
+      bf16_t* dst = (pv && rok) ? ss + ((size_t)r * SW + ox + 1) * SLD + 4 * q : ss + SS_EL + 4 * q;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 c = mfma_bf16(ash[ct], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+        c = mfma_bf16(asl[ct], bh, c);
+        c = mfma_bf16(ash[ct], bl, c);
+        u32x2 o;
+        o.x = pack_bf16(relu6(c[0]), relu6(c[1]));
+        o.y = pack_bf16(relu6(c[2]), relu6(c[3]));
+        *reinterpret_cast<u32x2*>(dst + 16 * ct) = o;
+      }
+    }
+  }
+  __syncthreads();
+  if (item + (int)gridDim.x < nitems) load_input(item + gridDim.x, vnext);  // lands under step 3
+
+  // ---- 3. depthwise + projection, 16-pixel tiles of the band's rows x HS pixels ----
+  {
+    const int P = rows * HS, NT = (P + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t osrd = make_srd(a.out + (((size_t)k * a.B + b) * HS + oy0) * HS * 16, P * 16 * 2);
+    const int ss_base = XS_WORDS * 4;
+    for (int tile = wv; tile < NT; tile += 4) {
+      const int p = 16 * tile + n;
+      const bool pv = p < P;
+      const int pc = pv ? p : P - 1;
+      const int r = (pc * 1311) >> 16, ox = pc - r * HS;
+      const int base = ss_base + (r * SW + ox) * SLD * 2;  // window origin: stem row (output row - 1), slot ox = column - 1
+      u32x4 bt[2][5];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bt[g][j] = *reinterpret_cast<const u32x4*>(smem_raw + base + doff[j] + 32 * g);
+      unsigned d[2][2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        f32x4 c = mfma_bf16(ad[g][4], bt[g][4], bdw[g]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c = mfma_bf16(ad[g][j], bt[g][j], c);
+          c = mfma_bf16(ad[g][5 + j], bt[g][j], c);
+        }
+        d[g][0] = pack_bf16(relu6(c[0]), relu6(c[1]));
+        d[g][1] = pack_bf16(relu6(c[2]), relu6(c[3]));
+      }
+      const f32x4 o4 = mfma_bf16(apj, u32x4{d[0][0], d[0][1], d[1][0], d[1][1]}, bpj);
+      u32x2 o;
+      o.x = pack_bf16(o4[0], o4[1]);
+      o.y = pack_bf16(o4[2], o4[3]);
+      __builtin_amdgcn_raw_buffer_store_b64(o, osrd, pv ? (p * 16 + 4 * q) * 2 : OOB, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave has left step 3: the stem rows may be overwritten
+  }  // items
+}
+
+}  // namespace
+
+bool front2_bf16_supported(const Layer& ls, const Layer& ld, const Layer& lp) {
+  return ls.kind == L_STEM && ls.cin == 2 && ls.cout == 32 && ls.stride == 2 && ls.relu6 && ls.h_in == HI && ls.h_out == HS &&
+         ld.kind == L_DW && ld.cout == 32 && ld.stride == 1 && ld.h_in == HS && ld.relu6 && lp.kind == L_PW && lp.cin == 32 &&
+         lp.cout == 16 && !lp.relu6 && !lp.residual;
+}
+
+hipError_t launch_front2_bf16(const Layer& ls, const Layer& ld, const Layer& lp, const float* enc_w,
+                              const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B, const float* visual,
+                              unsigned short* y, hipStream_t s) {
+  if (!front2_bf16_supported(ls, ld, lp)) return hipErrorInvalidValue;
+  Front2Args a;
+  a.in = visual;
+  a.out = y;
+  a.wbase = enc_w;
+  a.whbase = enc_wh;
+  a.model_stride = model_stride;
+  a.k0 = k0;
+  a.ws_off = ls.w_off;
+  a.bs_off = ls.b_off;
+  a.wd_off = ld.w_off;
+  a.bd_off = ld.b_off;
+  a.wp_off = lp.w_off;
+  a.bp_off = lp.b_off;
+  a.B = B;
+  a.bands = (HS + RB - 1) / RB;
+  static bool attr_set[64] = {};  // per device: > 64 KB of dynamic LDS needs the opt-in
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(front2_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  // persistent workgroups: two per CU in total (what the LDS footprint admits), each looping over the items of one model
+  int wgs = (2 * device_cu_count() + kc - 1) / kc;
+  if (B * a.bands < 2 * wgs) wgs = B * a.bands;  // small launches: one item per workgroup
+  if (wgs < 1) wgs = 1;
+  hipLaunchKernelGGL(front2_bf16_kernel, dim3(wgs, 1, kc), dim3(256), LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace rip

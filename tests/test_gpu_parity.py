@@ -1505,6 +1505,33 @@ def test_bench_two_ranks_share_one_gpu():
   assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
   assert rec["value"] > 0 and abs(rec["value"] - 2 * 32 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
   assert rec["roofline"]["frac"] is None or 0 < rec["roofline"]["frac"] < 1
+  # N > 1 without --mode (what the driver runs): the same invocation also runs the compositions that need a collective
+  assert rec["rccl"]["ranks_seen"] == 2 and rec["rccl"]["all_reduce_of_ones"] == 2.0
+  for key, collectives in (("candidate_parallel", 1), ("model_parallel", 11)):  # K = 4 over 2 ranks: 10 Adam steps + z_0
+    line = rec[key]
+    assert "error" not in line, line
+    assert line["calls_per_s"] > 0 and line["collectives_per_step"] == collectives, line
+    assert line["max_abs_plan_diff_vs_single_gpu"] <= 1e-4, line
+  assert rec["candidate_parallel"]["candidates_total"] == 2 * 128
+
+
+@pytest.mark.gpu
+def test_bench_two_gpus_over_rccl():
+  """The same default invocation on TWO GPUs over RCCL (backend nccl, one rank per device): skipped — not passed — on
+  a one-GPU box; no scaling figure exists until the driver has a multi-GPU node (multi-GPU)."""
+  import json, subprocess, sys
+  if torch.cuda.device_count() < 2:
+    pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RIP_BENCH_SHARE_GPU", "RIP_BENCH_BACKEND")}
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--obs-batch", "64",
+                        "--no-cpu-baseline", "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-3000:]
+  rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+  assert rec["n_gpus"] == 2 and rec["backend"] == "nccl" and rec["world_size_seen"] == 2
+  assert rec["rccl"] == {"backend": "nccl", "ranks_seen": 2, "all_reduce_of_ones": 2.0, "librccl_mapped": True}
+  for key in ("candidate_parallel", "model_parallel"):
+    assert "error" not in rec[key] and rec[key]["max_abs_plan_diff_vs_single_gpu"] <= 1e-4, rec[key]
 
 
 @pytest.mark.gpu
