@@ -69,18 +69,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, int
 constexpr int OOB = 0x40000000;
 constexpr unsigned ONES = 0x3F803F80u;  // two bf16 1.0
 
-constexpr int RB = 10;            // output rows per workgroup
 constexpr int HI = 100, HS = 50;  // input / stem (= output) map
-constexpr int SR = RB + 2;        // stem rows of a band (halo of the depthwise)
-constexpr int IR = 2 * SR + 1;    // input rows of a band
 constexpr int PADL = 4;           // input column ix sits at word ix + PADL (16-byte aligned staging stores)
 constexpr int IW = HI + 8;        // words per staged input row
 constexpr int SW = HS + 2;        // stem row: zero slot, HS pixels, zero slot
 constexpr int SLD = 40;           // bf16 elements per stem pixel slot (32 channels + 8: odd multiple of 16 bytes)
-constexpr int XS_WORDS = 2 * IR * IW;
-constexpr int SS_EL = SR * SW * SLD;
 constexpr int DUMP_EL = 64;       // where lanes beyond the band's pixels store
-constexpr size_t LDS_BYTES = (size_t)XS_WORDS * 4 + (size_t)(SS_EL + DUMP_EL) * 2;
+template <int RB>                 // RB: output rows per workgroup item
+struct Front2Geom {
+  static constexpr int SR = RB + 2;        // stem rows of a band (halo of the depthwise)
+  static constexpr int IR = 2 * SR + 1;    // input rows of a band
+  static constexpr int XS_WORDS = 2 * IR * IW;
+  static constexpr int SS_EL = SR * SW * SLD;
+  static constexpr size_t LDS_BYTES = (size_t)XS_WORDS * 4 + (size_t)(SS_EL + DUMP_EL) * 2;
+};
 
 struct Front2Args {
   const float* in;       // [B][2][HI][HI] fp32
@@ -94,7 +96,10 @@ struct Front2Args {
   int bands;  // row bands per observation; a workgroup loops over the (observation, band) items of ONE model
 };
 
-__global__ __launch_bounds__(256, 2) void front2_bf16_kernel(Front2Args a) {
+template <int RB, int OCC>
+__global__ __launch_bounds__(256, OCC) void front2_bf16_kernel(Front2Args a) {
+  using Geo = Front2Geom<RB>;
+  constexpr int SR = Geo::SR, IR = Geo::IR, XS_WORDS = Geo::XS_WORDS, SS_EL = Geo::SS_EL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* xs = reinterpret_cast<unsigned*>(smem_raw);                     // [2][IR][IW] (hi | lo << 16), zero borders
   bf16_t* ss = reinterpret_cast<bf16_t*>(smem_raw + (size_t)XS_WORDS * 4);  // [SR][SW][SLD] stem output, zero borders
@@ -207,8 +212,15 @@ __global__ __launch_bounds__(256, 2) void front2_bf16_kernel(Front2Args a) {
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int t = j < 4 ? 2 * j + (q >> 1) : 8;
-    doff[j] = ((t / 3) * SW + (t % 3)) * SLD * 2 + 16 * (q & 1);
+    doff[j] = ((t / 3) * SW + (t % 3)) * SLD * 2 + 32 * (q & 1);
   }
+  // Bank-conflict-free operand reads.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
+  // 28-31} (+32): with pixel n in column n and the two channel halves of a group 16 bytes apart every group hits each
+  // 16-byte bank slot twice (SQ_LDS_BANK_CONFLICT = half of the LDS cycles).  A pixel slot therefore stores its four
+  // 8-channel halves as [g0 h0 | g1 h0 | g0 h1 | g1 h1] (halves 32 bytes apart) and column n of a depthwise tile carries
+  // pixel pm: even pixels in lanes 0-3 / 12-15, odd pixels in lanes 4-11 — the 80-byte pixel pitch then puts every lane of
+  // a group on its own slot.  (The MFMA does not care which pixel a column is; the stores use the same map.)
+  const int pm = n < 4 ? 2 * n : (n < 12 ? 2 * (n - 4) + 1 : 2 * (n - 12) + 8);
   // ---- persistent loop over this model's (observation, band) items: the NEXT item's input is requested before the
   // depthwise phase of the current one, so its HBM latency is covered ----
 #pragma unroll 1
@@ -237,80 +249,105 @@ __global__ __launch_bounds__(256, 2) void front2_bf16_kernel(Front2Args a) {
   }
   __syncthreads();  // the staged band is in place
 
-  // ---- 2. stem rows oy0-1 .. oy0+RB as 16-pixel tiles across rows (rows off the map: results go to the dump slot) ----
+  // ---- 2. stem rows oy0-1 .. oy0+RB as 16-pixel tiles across rows (rows off the map: results go to the dump slot).
+  // Two tiles per trip: the sixteen operand reads of both are issued before the first permute, four independent
+  // three-MFMA chains per trip (the trip count is a run-time value: no unrolling by the compiler). ----
   {
     constexpr int P = SR * HS, NT = (P + 15) / 16;
-    for (int tile = wv; tile < NT; tile += 4) {
-      const int p = 16 * tile + n;
-      const bool pv = p < P;
-      const int pc = pv ? p : P - 1;
-      const int r = (pc * 1311) >> 16, ox = pc - r * HS;  // pc / 50 for pc < 2^15
-      const int sr = oy0 - 1 + r;
-      const bool rok = sr >= 0 && sr < HS;
-      const unsigned* xp = xs + (2 * r) * IW + 2 * ox + (PADL - 1);  // window origin: input row 2 sr - 1, column 2 ox - 1
-      unsigned wd[8];
+    for (int tile0 = wv; tile0 < NT; tile0 += 8) {
+      unsigned wd[2][8];
+      bf16_t* dst[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wd[j] = xp[xoff[j]];
-      u32x4 bh, bl;
-      bh.x = __builtin_amdgcn_perm(wd[1], wd[0], 0x05040100u);
-      bh.y = __builtin_amdgcn_perm(wd[3], wd[2], 0x05040100u);
-      bh.z = __builtin_amdgcn_perm(wd[5], wd[4], 0x05040100u);
-      bh.w = __builtin_amdgcn_perm(wd[7], wd[6], 0x05040100u);
-      bl.x = __builtin_amdgcn_perm(wd[1], wd[0], 0x07060302u);
-      bl.y = __builtin_amdgcn_perm(wd[3], wd[2], 0x07060302u);
-      bl.z = __builtin_amdgcn_perm(wd[5], wd[4], 0x07060302u);
-      bl.w = __builtin_amdgcn_perm(wd[7], wd[6], 0x07060302u);
-      bh.y = (bh.y & keep_y) | ones_q2;
-      bl.y &= keep_y;
-      bf16_t* dst = (pv && rok) ? ss + ((size_t)r * SW + ox + 1) * SLD + 4 * q : ss + SS_EL + 4 * q;
+      for (int u = 0; u < 2; ++u) {
+        const int p = 16 * (tile0 + 4 * u) + n;
+        const bool pv = p < P;
+        const int pc = pv ? p : P - 1;
+        const int r = (pc * 1311) >> 16, ox = pc - r * HS;  // pc / 50 for pc < 2^15
+        const int sr = oy0 - 1 + r;
+        const bool rok = sr >= 0 && sr < HS;
+        const unsigned* xp = xs + (2 * r) * IW + 2 * ox + (PADL - 1);  // window origin: input row 2 sr - 1, column 2 ox - 1
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        f32x4 c = mfma_bf16(ash[ct], bh, f32x4{0.f, 0.f, 0.f, 0.f});
-        c = mfma_bf16(asl[ct], bh, c);
-        c = mfma_bf16(ash[ct], bl, c);
-        u32x2 o;
-        o.x = pack_bf16(relu6(c[0]), relu6(c[1]));
-        o.y = pack_bf16(relu6(c[2]), relu6(c[3]));
-        *reinterpret_cast<u32x2*>(dst + 16 * ct) = o;
+        for (int j = 0; j < 8; ++j) wd[u][j] = xp[xoff[j]];
+        // channels 16 ct + 4q .. + 3 of the pixel: half h = q >> 1 of group ct sits at byte 16 ct + 32 h of the slot
+        dst[u] = ((pv && rok) ? ss + ((size_t)r * SW + ox + 1) * SLD : ss + SS_EL) + 16 * (q >> 1) + 4 * (q & 1);
       }
+      f32x4 c[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 bh, bl;
+        bh.x = __builtin_amdgcn_perm(wd[u][1], wd[u][0], 0x05040100u);
+        bh.y = __builtin_amdgcn_perm(wd[u][3], wd[u][2], 0x05040100u);
+        bh.z = __builtin_amdgcn_perm(wd[u][5], wd[u][4], 0x05040100u);
+        bh.w = __builtin_amdgcn_perm(wd[u][7], wd[u][6], 0x05040100u);
+        bl.x = __builtin_amdgcn_perm(wd[u][1], wd[u][0], 0x07060302u);
+        bl.y = __builtin_amdgcn_perm(wd[u][3], wd[u][2], 0x07060302u);
+        bl.z = __builtin_amdgcn_perm(wd[u][5], wd[u][4], 0x07060302u);
+        bl.w = __builtin_amdgcn_perm(wd[u][7], wd[u][6], 0x07060302u);
+        bh.y = (bh.y & keep_y) | ones_q2;
+        bl.y &= keep_y;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          c[u][ct] = mfma_bf16(ash[ct], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+          c[u][ct] = mfma_bf16(asl[ct], bh, c[u][ct]);
+          c[u][ct] = mfma_bf16(ash[ct], bl, c[u][ct]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          u32x2 o;
+          o.x = pack_bf16(relu6(c[u][ct][0]), relu6(c[u][ct][1]));
+          o.y = pack_bf16(relu6(c[u][ct][2]), relu6(c[u][ct][3]));
+          *reinterpret_cast<u32x2*>(dst[u] + 8 * ct) = o;
+        }
     }
   }
   __syncthreads();
   if (item + (int)gridDim.x < nitems) load_input(item + gridDim.x, vnext);  // lands under step 3
 
-  // ---- 3. depthwise + projection, 16-pixel tiles of the band's rows x HS pixels ----
+  // ---- 3. depthwise + projection, 16-pixel tiles of the band's rows x HS pixels; two tiles per trip (twenty operand
+  // reads up front, four nine-MFMA chains) ----
   {
     const int P = rows * HS, NT = (P + 15) >> 4;
     const __amdgpu_buffer_rsrc_t osrd = make_srd(a.out + (((size_t)k * a.B + b) * HS + oy0) * HS * 16, P * 16 * 2);
     const int ss_base = XS_WORDS * 4;
-    for (int tile = wv; tile < NT; tile += 4) {
-      const int p = 16 * tile + n;
-      const bool pv = p < P;
-      const int pc = pv ? p : P - 1;
-      const int r = (pc * 1311) >> 16, ox = pc - r * HS;
-      const int base = ss_base + (r * SW + ox) * SLD * 2;  // window origin: stem row (output row - 1), slot ox = column - 1
-      u32x4 bt[2][5];
+    for (int tile0 = wv; tile0 < NT; tile0 += 8) {
+      u32x4 bt[2][2][5];
+      int ooff[2];
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int u = 0; u < 2; ++u) {
+        const int p = 16 * (tile0 + 4 * u) + pm;
+        const bool pv = p < P;
+        const int pc = pv ? p : P - 1;
+        const int r = (pc * 1311) >> 16, ox = pc - r * HS;
+        const int base = ss_base + (r * SW + ox) * SLD * 2;  // window origin: stem row (output row - 1), slot ox = column - 1
 #pragma unroll
-        for (int j = 0; j < 5; ++j) bt[g][j] = *reinterpret_cast<const u32x4*>(smem_raw + base + doff[j] + 32 * g);
-      unsigned d[2][2];
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        f32x4 c = mfma_bf16(ad[g][4], bt[g][4], bdw[g]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          c = mfma_bf16(ad[g][j], bt[g][j], c);
-          c = mfma_bf16(ad[g][5 + j], bt[g][j], c);
-        }
-        d[g][0] = pack_bf16(relu6(c[0]), relu6(c[1]));
-        d[g][1] = pack_bf16(relu6(c[2]), relu6(c[3]));
+          for (int j = 0; j < 5; ++j) bt[u][g][j] = *reinterpret_cast<const u32x4*>(smem_raw + base + doff[j] + 16 * g);
+        ooff[u] = pv ? (p * 16 + 4 * q) * 2 : OOB;
       }
-      const f32x4 o4 = mfma_bf16(apj, u32x4{d[0][0], d[0][1], d[1][0], d[1][1]}, bpj);
-      u32x2 o;
-      o.x = pack_bf16(o4[0], o4[1]);
-      o.y = pack_bf16(o4[2], o4[3]);
-      __builtin_amdgcn_raw_buffer_store_b64(o, osrd, pv ? (p * 16 + 4 * q) * 2 : OOB, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        unsigned d[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          f32x4 c = mfma_bf16(ad[g][4], bt[u][g][4], bdw[g]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c = mfma_bf16(ad[g][j], bt[u][g][j], c);
+            c = mfma_bf16(ad[g][5 + j], bt[u][g][j], c);
+          }
+          d[g][0] = pack_bf16(relu6(c[0]), relu6(c[1]));
+          d[g][1] = pack_bf16(relu6(c[2]), relu6(c[3]));
+        }
+        const f32x4 o4 = mfma_bf16(apj, u32x4{d[0][0], d[0][1], d[1][0], d[1][1]}, bpj);
+        u32x2 o;
+        o.x = pack_bf16(o4[0], o4[1]);
+        o.y = pack_bf16(o4[2], o4[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, osrd, ooff[u], 0, 0);
+      }
     }
   }
   __syncthreads();  // every wave has left step 3: the stem rows may be overwritten
@@ -343,13 +380,18 @@ hipError_t launch_front2_bf16(const Layer& ls, const Layer& ld, const Layer& lp,
   a.wp_off = lp.w_off;
   a.bp_off = lp.b_off;
   a.B = B;
-  a.bands = (HS + RB - 1) / RB;
+  // RB = 10 output rows per item (72 KB of LDS, two workgroups per CU).  RB = 5 / three workgroups per CU measured
+  // slower (184 vs 162 us: the halo rows of the stem are 40 % instead of 20 % of its work, and occupancy is not what
+  // limits the kernel), profiles/r4/front2_variants.txt.
+  constexpr int RBv = 10;
+  a.bands = (HS + RBv - 1) / RBv;
+  auto kern = front2_bf16_kernel<RBv, 2>;
+  const size_t lds = Front2Geom<RBv>::LDS_BYTES;
   static bool attr_set[64] = {};  // per device: > 64 KB of dynamic LDS needs the opt-in
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(front2_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
@@ -357,7 +399,7 @@ hipError_t launch_front2_bf16(const Layer& ls, const Layer& ld, const Layer& lp,
   int wgs = (2 * device_cu_count() + kc - 1) / kc;
   if (B * a.bands < 2 * wgs) wgs = B * a.bands;  // small launches: one item per workgroup
   if (wgs < 1) wgs = 1;
-  hipLaunchKernelGGL(front2_bf16_kernel, dim3(wgs, 1, kc), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(wgs, 1, kc), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
