@@ -7,6 +7,18 @@
 
 namespace rip {
 
+// Workgroup barrier for kernels whose waves talk to each other through LDS only.  `__syncthreads()` is a workgroup-scope
+// release / acquire fence over ALL address spaces: the compiler puts `s_waitcnt vmcnt(0)` in front of the s_barrier, so
+// every global load that was meant to stay in flight across the barrier — operand prefetches of the next row / K-step /
+// item — is waited for right there, one memory latency per barrier (round 4: this, not occupancy, is what the row-
+// streaming and GEMM kernels were bound by).  The fences below are restricted to the LDS address space ("local"):
+// `s_waitcnt lgkmcnt(0)` + `s_barrier`, vector-memory operations keep their own counters.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 enum LayerKind { L_STEM = 0, L_DW = 1, L_PW = 2 };
 
 // One conv layer of the BN-folded MobileNetV2 (torchvision v0.6.0 layout; reference call site

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const float* __restrict_
     xs[e] = (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin) ? in[((size_t)b * C + c) * Hin * Hin + (size_t)iy * Hin + ix] : 0.f;
   }
   for (int e = tid; e < 9 * C * 32; e += 256) ws[e] = w[e];
-  __syncthreads();
+  lds_barrier();
   const int rows = min(STEM_ROWS, Ho - oy0);
   for (int e = tid; e < rows * Ho * 4; e += 256) {
     const int oc8 = e & 3, pix = e >> 2;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
         part[wave][ct * PT + pt][lane] = make_float4(acc[ct][pt][0], acc[ct][pt][1], acc[ct][pt][2], acc[ct][pt][3]);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   const int nk = (Cin + 31) / 32;
   load_tiles(0);
   store_tiles(0);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(af[i]), as_bf16x8(bf[j]), acc[i][j], 0, 0, 0);
     if (kt + 1 < nk) store_tiles(buf ^ 1);  // the other buffer was last read before the previous barrier
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- epilogue: bias (+ residual) (+ ReLU6); lane (n, q) holds channels 4q..4q+3 of tile i for pixel n of tile j
@@ -843,8 +843,8 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
                                                               int M, int Cin, int Cout, int relu6,
                                                               size_t act_model_stride_in, size_t act_model_stride_out,
                                                               int n_ptiles) {
-  constexpr int BM = 128, BN = 32 * WN, LD = 40;
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BN + BM) * LD];
+  constexpr int BM = 128, BN = 32 * WN, BK = 32, LD = BK + 8;  // (K-steps of 64 measured slower: 45.8 / 64.8 / 100.4 vs 35.0 / 52.5 / 77.8 us)
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // [2][BN + BM][LD]: 73.7 KB at WN = 4 (dynamic: the launcher opts in)
   auto As = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD; };
   auto Bs = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD + BN * LD; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -858,28 +858,36 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
   const bf16_t* R = res != nullptr ? res + (size_t)k * act_model_stride_out : nullptr;
   bf16_t* O = reinterpret_cast<bf16_t*>(outv) + (size_t)k * act_model_stride_out;
   float* OF = reinterpret_cast<float*>(outv) + (size_t)k * act_model_stride_out;
-  const int nk = (Cin + 31) / 32;
+  const int nk = (Cin + BK - 1) / BK;  // Cin % 32 == 0; a last half step loads clamped (re-read) K columns with zero weight
   const int nt = ((int)blockIdx.x < n_ptiles) ? (n_ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = nt * nk;
   if (total == 0) return;
 
-  constexpr int A_CH = BN * 4 / 256, B_CH = BM * 4 / 256;
+  constexpr int CPR = BK / 8;  // 16-byte chunks per row and step
+  constexpr int A_CH = BN * CPR / 256, B_CH = BM * CPR / 256;
   const u32x4 zero = {0u, 0u, 0u, 0u};
   // load stream position (tile, K-step), advanced once per load_tiles call
   int l_tile = blockIdx.x, l_kt = 0;
+  // Loads are UNCONDITIONAL (rows beyond Cout / M are clamped to the last valid row: their products land in outputs
+  // that are never stored; Cin is a multiple of 32 on this path): a predicated load is a branch, and behind every
+  // control-flow merge the compiler's s_waitcnt falls back to vmcnt(0) — the load requested for two steps ahead was
+  // waited for one step ahead, so a K-step cost one memory latency (~1900 cycles for 272 cycles of MFMAs per wave).
   auto load_tiles = [&](u32x4(&areg)[A_CH], u32x4(&breg)[B_CH]) __attribute__((always_inline)) {
-    const int p0 = l_tile * BM;
+    const int lt = l_tile < n_ptiles ? l_tile : n_ptiles - 1;  // the stream runs past the last step: harmless re-loads
+    const int p0 = lt * BM;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      const int e = tid + 256 * i, row = e >> 2, kk = l_kt * 32 + (e & 3) * 8;
-      const int co = c0 + row;
-      areg[i] = (co < Cout && kk < Cin) ? *reinterpret_cast<const u32x4*>(A + (size_t)co * Cin + kk) : zero;
+      const int e = tid + 256 * i, row = e / CPR, kk = l_kt * BK + (e % CPR) * 8;
+      const int co = min(c0 + row, Cout - 1);
+      // a K column beyond Cin (the second half of a last, half-filled step) is read from column kk - 32 with ZERO weight
+      const u32x4 v = *reinterpret_cast<const u32x4*>(A + (size_t)co * Cin + (kk < Cin ? kk : kk - 32));
+      areg[i] = kk < Cin ? v : zero;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      const int e = tid + 256 * i, row = e >> 2, kk = l_kt * 32 + (e & 3) * 8;
-      const int p = p0 + row;
-      breg[i] = (p < M && kk < Cin) ? *reinterpret_cast<const u32x4*>(X + (size_t)p * Cin + kk) : zero;
+      const int e = tid + 256 * i, row = e / CPR, kk = l_kt * BK + (e % CPR) * 8;
+      const int p = min(p0 + row, M - 1);
+      breg[i] = *reinterpret_cast<const u32x4*>(X + (size_t)p * Cin + (kk < Cin ? kk : kk - 32));
     }
     if (++l_kt == nk) {
       l_kt = 0;
@@ -890,12 +898,12 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int e = tid + 256 * i;
-      *reinterpret_cast<u32x4*>(As(buf) + (e >> 2) * LD + (e & 3) * 8) = areg[i];
+      *reinterpret_cast<u32x4*>(As(buf) + (e / CPR) * LD + (e % CPR) * 8) = areg[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int e = tid + 256 * i;
-      *reinterpret_cast<u32x4*>(Bs(buf) + (e >> 2) * LD + (e & 3) * 8) = breg[i];
+      *reinterpret_cast<u32x4*>(Bs(buf) + (e / CPR) * LD + (e % CPR) * 8) = breg[i];
     }
   };
 
@@ -913,18 +921,23 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
 
   int c_tile = blockIdx.x, c_kt = 0;  // compute stream position
   auto compute = [&](int buf) __attribute__((always_inline)) {
-    u32x4 af[WN], bf[4];
+    u32x4 af[BK / 32][WN], bf[BK / 32][4];
 #pragma unroll
-    for (int i = 0; i < WN; ++i)
-      af[i] = *reinterpret_cast<const u32x4*>(As(buf) + (wc * 16 * WN + 16 * i + n) * LD + 8 * q);
+    for (int kh = 0; kh < BK / 32; ++kh) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      bf[j] = *reinterpret_cast<const u32x4*>(Bs(buf) + (wp * 64 + 16 * j + n) * LD + 8 * q);
-#pragma unroll
-    for (int i = 0; i < WN; ++i)
+      for (int i = 0; i < WN; ++i)
+        af[kh][i] = *reinterpret_cast<const u32x4*>(As(buf) + (wc * 16 * WN + 16 * i + n) * LD + 32 * kh + 8 * q);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(af[i]), as_bf16x8(bf[j]), acc[i][j], 0, 0, 0);
+        bf[kh][j] = *reinterpret_cast<const u32x4*>(Bs(buf) + (wp * 64 + 16 * j + n) * LD + 32 * kh + 8 * q);
+    }
+#pragma unroll
+    for (int kh = 0; kh < BK / 32; ++kh)
+#pragma unroll
+      for (int i = 0; i < WN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(af[kh][i]), as_bf16x8(bf[kh][j]), acc[i][j], 0, 0, 0);
     if (++c_kt == nk) {  // tile finished: bias (+ residual) (+ ReLU6), store, restart the accumulators
       const int p0 = c_tile * BM;
 #pragma unroll
@@ -966,21 +979,30 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
     }
   };
 
-  u32x4 a0[A_CH], b0[B_CH], a1[A_CH], b1[B_CH];
+  // Operands are requested THREE steps ahead (three register sets; the loop is unrolled by six = lcm of the register
+  // and the LDS rotation) and every load is issued whether or not a step s + 3 exists (clamped: see load_tiles), so the
+  // loop body has no branch between a load and its use and the waits are vmcnt(8) instead of vmcnt(0).
+  u32x4 a0[A_CH], b0[B_CH], a1[A_CH], b1[B_CH], a2[A_CH], b2[B_CH];
   load_tiles(a0, b0);
-  if (total > 1) load_tiles(a1, b1);
+  load_tiles(a1, b1);
+  load_tiles(a2, b2);
+  int s = 0;
+#define GEMM_STEP(buf_, ar_, br_)   \
+  store_tiles(buf_, ar_, br_);      \
+  load_tiles(ar_, br_);             \
+  lds_barrier();                    \
+  compute(buf_);                    \
+  if (++s >= total) return;
 #pragma unroll 1
-  for (int s = 0; s < total; s += 2) {
-    store_tiles(0, a0, b0);
-    __syncthreads();
-    if (s + 2 < total) load_tiles(a0, b0);
-    compute(0);
-    if (s + 1 >= total) break;
-    store_tiles(1, a1, b1);
-    __syncthreads();
-    if (s + 3 < total) load_tiles(a1, b1);
-    compute(1);
+  for (;;) {
+    GEMM_STEP(0, a0, b0)
+    GEMM_STEP(1, a1, b1)
+    GEMM_STEP(0, a2, b2)
+    GEMM_STEP(1, a0, b0)
+    GEMM_STEP(0, a1, b1)
+    GEMM_STEP(1, a2, b2)
   }
+#undef GEMM_STEP
 }
 
 template <int WN, bool POOL>
@@ -992,7 +1014,16 @@ void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w
   if (px > n_ptiles) px = n_ptiles;
   if (px < 1) px = 1;
   const size_t sout = POOL ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
-  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN, POOL>), dim3(px, n_slices, kc), dim3(256), 0, s, in, enc_wh, enc_w, ms,
+  constexpr size_t lds = (size_t)2 * (32 * WN + 128) * (32 + 8) * sizeof(bf16_t);
+  static bool attr_set[64] = {};  // per device (one static per template instance): > 64 KB of dynamic LDS needs the opt-in
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 && dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_bf16_kernel<WN, POOL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN, POOL>), dim3(px, n_slices, kc), dim3(256), lds, s, in, enc_wh, enc_w, ms,
                      k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, sout, n_ptiles);
 }
 

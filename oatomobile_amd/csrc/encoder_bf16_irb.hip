@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
   }
 
   if (WLDS) {
-    __syncthreads();
+    lds_barrier();
     for (int e = threadIdx.x; e < 9 * NW * CW; e += NW * 64) {
       const int t = e / (NW * CW), c = e - t * (NW * CW);
       wl[e] = c < HID ? W[a.wd_off + (size_t)t * HID + c] : 0.f;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
   };
 
   const int oy0 = band * a.band_rows, oy1 = min(H_out, oy0 + a.band_rows);
-  __syncthreads();  // LDS zeroed
+  lds_barrier();  // LDS zeroed
 
   // prologue: rows oy0*S-1 .. oy0*S+1-S are expanded here, the remaining S rows of the first window in the loop
   u32x4 xr[STRIDE][NPT];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
       }
     }
     if (!APREG) load_ap();
-    __syncthreads();  // every chunk of ds[buf] is in place
+    lds_barrier();  // every chunk of ds[buf] is in place
     // 3. projection tiles of this wave over the full hidden K
     const __amdgpu_buffer_rsrc_t ysrd = row_srd(yout + (size_t)oy * H_out * COUT, H_out * COUT * 2);
     const __amdgpu_buffer_rsrc_t rsrd = row_srd(xin + (size_t)oy * H_in * CIN, a.residual ? x_row_bytes : 0);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
     }
     if (!APREG) load_ap();
     IRB2_TICK(1);
-    __syncthreads();  // every group of ds[buf] is in place
+    lds_barrier();  // every group of ds[buf] is in place (LDS-only fence: the operand prefetches stay in flight)
     IRB2_TICK(2);
     // 3. projection tiles of this wave over the full hidden K
     const __amdgpu_buffer_rsrc_t ysrd = row_srd(yout + (size_t)oy * H_OUT * COUT, H_OUT * COUT * 2);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   // zero both E buffers once: the padding columns are never written again
   if (!(RIP_TILE_ABL & 8))
     for (int e = tid; e < 2 * Geo::E_ROWS * LD / 8; e += 512) reinterpret_cast<u32x4*>(Ebuf)[e] = zero4;
-  __syncthreads();
+  lds_barrier();
 
   if (w < 4) {
     // ================= matrix waves: expand + project =================
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     for (int s = 0; s < nch; ++s) {  // steps with an expansion
       if (mx_on) expand(s);
       if (s >= 2 && mx_on) project(s - 2);
-      __syncthreads();
+      lds_barrier();
     }
     // drain: the last two projections; the epilogue's operands (bias, residual = block input) are requested first
     float4 bpj[NCT];
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
                                                 : u32x2{0u, 0u};
     }
     if (nch >= 2 && mx_on) project(nch - 2);
-    __syncthreads();
+    lds_barrier();
     if (mx_on) project(nch - 1);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
       const int p = 16 * (wpix + WP * t) + n;
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       if (s >= 1 && s <= nch && dw_on && !(RIP_TILE_ABL & 1))
         depthwise(Ebuf + (size_t)Geo::E_ROWS * LD, Dbuf + (size_t)Geo::D_ROWS * LD, wt[1], bd[1]);
       if (s + 1 < nch && !(RIP_TILE_ABL & 4)) load_taps(s + 1, wt[1], bd[1]);
-      __syncthreads();
+      lds_barrier();
       if (s + 1 >= nch + 2) break;
       // odd step s+1: depthwise of chunk s (even buffers)
       if (s + 1 <= nch && dw_on && !(RIP_TILE_ABL & 1)) depthwise(Ebuf, Dbuf, wt[0], bd[0]);
       if (s + 2 < nch && !(RIP_TILE_ABL & 4)) load_taps(s + 2, wt[0], bd[0]);
-      __syncthreads();
+      lds_barrier();
     }
   }
 }
