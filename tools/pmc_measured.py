@@ -6,7 +6,7 @@ correction of MI355X_MICROARCH.md's HBM / rocprofv3 section: the counter's unit 
 """
 import csv, json, re, sys
 
-ENC = re.compile(r"^(cls_|dw_|front_|gemm_|irb_|merger|transform|pw_|stem)")
+ENC = re.compile(r"^(cls_|dw_|front|gemm_|irb|merger|transform|pw_|stem)")
 SEARCH = re.compile(r"^search_(phase|split)\w*kernel<false")
 
 
@@ -24,7 +24,7 @@ def main():
                     "algorithm": cfg[6] or "WCM"}}
   steps = None
   if search:
-    k = max(search, key=lambda n: by[n]["FETCH_SIZE"][1])
+    k = max(search, key=lambda n: by[n]["FETCH_SIZE"][0])  # (the operand-range fallback launch of flow_phase.hip moves ~0 bytes)
     f, w = by[k]["FETCH_SIZE"], by[k].get("WRITE_SIZE", (0.0, 0, 0.0))
     steps = f[1]
     out["search"] = {"kernel": k, "fetch_KiB": f[0], "write_KiB": w[0], "traffic_bytes": (2.0 * f[0] + w[0]) * 1024.0}
