@@ -724,9 +724,11 @@ def _bench_replay(args, agent, dev, B, C):
     el = time.perf_counter() - t0
     # BASELINE configs[4] at its size from the packed cache (replay.pack_cache: uint8 codes + float table, expanded in
     # the transform kernel): the 256 datums packed once, tiled to 10 000 observations, replayed with the [30,3] plans
+    # the packing rate is taken over the 4096-file list (the 256 files 16 times: one worker process per CPU has
+    # seconds of work, as with a real episode directory); the first 256 rows are the 256 distinct datums
     t0 = time.perf_counter()
-    small = replay.pack_cache(ep.files(), os.path.join(tmp, "cache256"))
-    pack_rate = nfiles / (time.perf_counter() - t0)
+    small = replay.pack_cache(files, os.path.join(tmp, "cache4k"))
+    pack_rate = len(files) / (time.perf_counter() - t0)
     n10k = 10000
     big_dir = os.path.join(tmp, "cache10k")
     os.makedirs(big_dir)
@@ -748,7 +750,8 @@ def _bench_replay(args, agent, dev, B, C):
     same = bool(np.array_equal(plans[:nfiles], plans[nfiles:2 * nfiles]))  # the tiling repeats: so must the plans
     cache_line = {"observations_per_s": n10k / cache_el, "observations": n10k, "batch": B, "seconds": cache_el,
                   "bytes_per_observation": int(np.prod(cache.codes.shape[1:])) + 4 * (5 + 2 * cache.goal.shape[1]),
-                  "pack_datums_per_s": pack_rate, "repeats_consistent": same,
+                  "pack_datums_per_s": pack_rate, "pack_datums": len(files), "pack_processes": replay.effective_cpus(),
+                  "repeats_consistent": same,
                   "note": "10 000 observations from the packed cache -> pinned staging -> H2D -> rip_encode_raw_u8 + search "
                           "+ R11 -> [30,3] float64 plans on the host; one process, no decode workers"}
     return {"observations_per_s": n_done / el, "decode_processes": workers, "files": len(files), "batch": B,

@@ -22,7 +22,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel time per step: %.2f ms over 6 steps" % (tot / 6e6))
-for r in rows[:28]:
+for r in rows[:int(__import__("os").environ.get("TOPN", "28"))]:
   n = r["Name"].replace("void rip::(anonymous namespace)::", "").replace("rip::(anonymous namespace)::", "")[:70]
   print("%-72s calls/step %6.1f  avg %8.1f us  per step %8.1f us  %5.1f%%" % (n, int(r["Calls"]) / 6, float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 6e3, float(r["Percentage"])))
 PY
+[ -n "$TIMELINE" ] && python tools/dev/train_timeline.py $O/t "$TIMELINE"
