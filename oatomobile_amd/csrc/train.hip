@@ -338,6 +338,9 @@ __device__ __forceinline__ float4 dw_taps4(const float* __restrict__ w, int c4, 
   const float* p = w + (size_t)(4 * c4) * 9 + t;
   return make_float4(p[0], p[9], p[18], p[27]);
 }
+// Branch-free: a branch around a tap off the image makes the compiler wait for every outstanding load at the merge
+// (`s_waitcnt vmcnt(0)`: nine memory round trips in sequence), so all nine loads go out first, from clamped addresses,
+// and a tap off the image enters the FMA chain as +0 (acc + 0 * w == acc: same sums as skipping it).
 __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int B,
                               int C, int Hi, int Ho, int stride) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,28 +350,40 @@ __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restri
   const int c4 = idx % C4;
   const size_t p = idx / C4;
   const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)b * Hi * Hi * C4 + c4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[9];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = stride * oy - 1 + ky;
-    if (iy < 0 || iy >= Hi) continue;
+    const int iyc = min(max(iy, 0), Hi - 1);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = stride * ox - 1 + kx;
-      if (ix < 0 || ix >= Hi) continue;
-      const float4 v = x4[(((size_t)b * Hi + iy) * Hi + ix) * C4 + c4];
+      const int ixc = min(max(ix, 0), Hi - 1);
+      v[ky * 3 + kx] = x4[((size_t)iyc * Hi + ixc) * C4];
+    }
+  }
+  float4 acc = zero;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = stride * oy - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = stride * ox - 1 + kx;
+      const bool ok = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Hi;
+      const float4 vv = ok ? v[ky * 3 + kx] : zero;
       const float4 wv = dw_taps4(w, c4, ky * 3 + kx);
-      acc.x = fmaf(v.x, wv.x, acc.x);
-      acc.y = fmaf(v.y, wv.y, acc.y);
-      acc.z = fmaf(v.z, wv.z, acc.z);
-      acc.w = fmaf(v.w, wv.w, acc.w);
+      acc.x = fmaf(vv.x, wv.x, acc.x);
+      acc.y = fmaf(vv.y, wv.y, acc.y);
+      acc.z = fmaf(vv.z, wv.z, acc.z);
+      acc.w = fmaf(vv.w, wv.w, acc.w);
     }
   }
   reinterpret_cast<float4*>(out)[idx] = acc;
 }
 
-// dx[b,iy,ix,c] += sum_{ky,kx} dpre[b,oy,ox,c] w[c,ky,kx] with stride*oy - 1 + ky == iy
+// dx[b,iy,ix,c] += sum_{ky,kx} dpre[b,oy,ox,c] w[c,ky,kx] with stride*oy - 1 + ky == iy  (branch-free like the forward)
 __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ dx,
                                 int B, int C, int Hi, int Ho, int stride) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,30 +393,37 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __r
   const int c4 = idx % C4;
   const size_t p = idx / C4;
   const int ix = p % Hi, iy = (p / Hi) % Hi, b = p / ((size_t)Hi * Hi);
-  const float4* g4 = reinterpret_cast<const float4*>(dpre);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* g4 = reinterpret_cast<const float4*>(dpre) + (size_t)b * Ho * Ho * C4 + c4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* d4 = reinterpret_cast<float4*>(dx) + idx;
+  float4 o = *d4;
+  float4 g[9];
+  bool ok[9];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int ty = iy + 1 - ky;
-    if (ty < 0 || ty % stride != 0) continue;
-    const int oy = ty / stride;
-    if (oy >= Ho) continue;
+    const int oy = stride == 1 ? ty : ty >> 1;
+    const bool oky = ty >= 0 && (stride == 1 || (ty & 1) == 0) && oy < Ho;
+    const int oyc = min(max(oy, 0), Ho - 1);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int tx = ix + 1 - kx;
-      if (tx < 0 || tx % stride != 0) continue;
-      const int ox = tx / stride;
-      if (ox >= Ho) continue;
-      const float4 g = g4[(((size_t)b * Ho + oy) * Ho + ox) * C4 + c4];
-      const float4 wv = dw_taps4(w, c4, ky * 3 + kx);
-      acc.x = fmaf(g.x, wv.x, acc.x);
-      acc.y = fmaf(g.y, wv.y, acc.y);
-      acc.z = fmaf(g.z, wv.z, acc.z);
-      acc.w = fmaf(g.w, wv.w, acc.w);
+      const int ox = stride == 1 ? tx : tx >> 1;
+      ok[ky * 3 + kx] = oky && tx >= 0 && (stride == 1 || (tx & 1) == 0) && ox < Ho;
+      const int oxc = min(max(ox, 0), Ho - 1);
+      g[ky * 3 + kx] = g4[((size_t)oyc * Ho + oxc) * C4];
     }
   }
-  float4* d4 = reinterpret_cast<float4*>(dx) + idx;
-  float4 o = *d4;
+  float4 acc = zero;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float4 gv = ok[t] ? g[t] : zero;
+    const float4 wv = dw_taps4(w, c4, t);
+    acc.x = fmaf(gv.x, wv.x, acc.x);
+    acc.y = fmaf(gv.y, wv.y, acc.y);
+    acc.z = fmaf(gv.z, wv.z, acc.z);
+    acc.w = fmaf(gv.w, wv.w, acc.w);
+  }
   o.x += acc.x;
   o.y += acc.y;
   o.z += acc.z;
@@ -432,15 +454,15 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     const int c4 = item % C4, ox = item / C4;
     const int ix0 = STRIDE * ox - 1;
     const bool okl = ix0 >= 0, okr = ix0 + 2 < Hi;  // the centre column always lies inside
+    // branch-free (clamped addresses, then selects): a branch around a load costs a full wait at the merge
+    const int xl = okl ? 0 : 1, xr = okr ? 2 : 1;
     auto load_row = [&](int iy, float4(&r)[3]) {
-      if (iy < 0 || iy >= Hi) {
-        r[0] = r[1] = r[2] = zero;
-        return;
-      }
-      const float4* p = x4 + ((size_t)iy * Hi + ix0) * C4 + c4;
-      r[0] = okl ? p[0] : zero;
-      r[1] = p[C4];
-      r[2] = okr ? p[2 * C4] : zero;
+      const bool oky = iy >= 0 && iy < Hi;
+      const float4* p = x4 + ((size_t)min(max(iy, 0), Hi - 1) * Hi + ix0) * C4 + c4;
+      const float4 a = p[xl * C4], m = p[C4], c = p[xr * C4];
+      r[0] = (oky && okl) ? a : zero;
+      r[1] = oky ? m : zero;
+      r[2] = (oky && okr) ? c : zero;
     };
     float4 acc[9];
 #pragma unroll
