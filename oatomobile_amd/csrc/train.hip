@@ -263,25 +263,52 @@ hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int l
 // direct convolutions (3x3, pad 1)
 // ------------------------------------------------------------------------------------------------------------
 // stem: in NCHW [B,C,Hin,Hin] -> out NHWC [B,Ho,Ho,Co]; w [Co][C][3][3] (reference layout)
+// Branch-free like the depthwise kernels below: the C*9 window values are loaded first from clamped addresses (the 32
+// `oc` lanes of a pixel read the same words), a tap off the image enters the chain as +0; CT = C when it is 2 or 4
+// (fully unrolled), 0 = any C.
+template <int CT>
 __global__ void stem_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
-                                int B, int C, int Hin, int Ho, int Co) {
+                                int B, int C_, int Hin, int Ho, int Co) {
+  const int C = CT > 0 ? CT : C_;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * Ho * Ho * Co;
   if (idx >= total) return;
   const int oc = idx % Co;
   const size_t p = idx / Co;
   const int ox = p % Ho, oy = (p / Ho) % Ho, b = p / ((size_t)Ho * Ho);
-  float acc = 0.f;
-  for (int c = 0; c < C; ++c)
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = 2 * oy - 1 + ky;
-      if (iy < 0 || iy >= Hin) continue;
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = 2 * ox - 1 + kx;
-        if (ix < 0 || ix >= Hin) continue;
-        acc = fmaf(in[(((size_t)b * C + c) * Hin + iy) * Hin + ix], w[((oc * C + c) * 3 + ky) * 3 + kx], acc);
-      }
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * ox - 1 + kx;
+      ok[ky * 3 + kx] = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+      off[ky * 3 + kx] = min(max(iy, 0), Hin - 1) * Hin + min(max(ix, 0), Hin - 1);
     }
+  }
+  const float* ib = in + (size_t)b * C * Hin * Hin;
+  const float* wb = w + (size_t)oc * C * 9;
+  float acc = 0.f;
+  if (CT > 0) {
+    float v[(CT > 0 ? CT : 1) * 9], wv[(CT > 0 ? CT : 1) * 9];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        v[c * 9 + t] = ib[(size_t)c * Hin * Hin + off[t]];
+        wv[c * 9 + t] = wb[c * 9 + t];
+      }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(ok[t] ? v[c * 9 + t] : 0.f, wv[c * 9 + t], acc);
+  } else {
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(ok[t] ? ib[(size_t)c * Hin * Hin + off[t]] : 0.f, wb[c * 9 + t], acc);
+  }
   out[idx] = acc;
 }
 
@@ -318,8 +345,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int ix = 2 * ox - 1 + kx;
-            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin)
-              acc[c * 9 + ky * 3 + kx] = fmaf(g, in[(((size_t)b * C + c) * Hin + iy) * Hin + ix], acc[c * 9 + ky * 3 + kx]);
+            const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;  // clamped load + select: no branch
+            const float v = in[(((size_t)b * C + c) * Hin + min(max(iy, 0), Hin - 1)) * Hin + min(max(ix, 0), Hin - 1)];
+            acc[c * 9 + ky * 3 + kx] = fmaf(g, ok ? v : 0.f, acc[c * 9 + ky * 3 + kx]);
           }
         }
       }
@@ -1057,8 +1085,15 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     float* post = A(t->post, i);
     const float* x = i == 0 ? visual : A(t->post, i - 1);
     if (l.kind == L_STEM) {
-      hipLaunchKernelGGL(stem_fwd_kernel, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in, l.h_out,
-                         l.cout);
+      if (l.cin == 2)
+        hipLaunchKernelGGL(stem_fwd_kernel<2>, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in,
+                           l.h_out, l.cout);
+      else if (l.cin == 4)
+        hipLaunchKernelGGL(stem_fwd_kernel<4>, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in,
+                           l.h_out, l.cout);
+      else
+        hipLaunchKernelGGL(stem_fwd_kernel<0>, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in,
+                           l.h_out, l.cout);
     } else if (l.kind == L_DW) {
       hipLaunchKernelGGL(dw_fwd_kernel, dim3(nblk(total / 4)), dim3(256), 0, s, x, params + q.w, pre, B, l.cout, l.h_in, l.h_out,
                          l.stride);
