@@ -413,7 +413,7 @@ __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restri
 
 // dx[b,iy,ix,c] += sum_{ky,kx} dpre[b,oy,ox,c] w[c,ky,kx] with stride*oy - 1 + ky == iy  (branch-free like the forward)
 __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ dx,
-                                int B, int C, int Hi, int Ho, int stride) {
+                                int B, int C, int Hi, int Ho, int stride, int accumulate) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int C4 = C >> 2;
   const size_t total = (size_t)B * Hi * Hi * C4;
@@ -424,7 +424,8 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __r
   const float4* g4 = reinterpret_cast<const float4*>(dpre) + (size_t)b * Ho * Ho * C4 + c4;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   float4* d4 = reinterpret_cast<float4*>(dx) + idx;
-  float4 o = *d4;
+  float4 o = zero;
+  if (accumulate) o = *d4;
   float4 g[9];
   bool ok[9];
 #pragma unroll
@@ -706,13 +707,13 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ pre, const float* __
   post[idx] = v;
 }
 
-// g = dpost masked by the ReLU6 derivative (in place into gbuf), res_grad += dpost for residual layers
+// g = dpost masked by the ReLU6 derivative (in place into gbuf), res_grad = dpost for residual layers
 __global__ void act_bwd_kernel(const float* __restrict__ dpost, const float* __restrict__ post, float* __restrict__ g,
                                float* __restrict__ dres, size_t total, int relu6) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const float d = dpost[idx];
-  if (dres != nullptr) dres[idx] += d;
+  if (dres != nullptr) dres[idx] = d;  // the residual branch is the FIRST writer of the block input's gradient
   float v = d;
   if (relu6) {
     const float y = post[idx];
@@ -752,11 +753,7 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
     for (size_t r = r0 + rl; r < r1; r += RL) {
       const size_t e = r * C4 + c4;
       const float4 d = d4[e];
-      if (dres != nullptr) {
-        float4 o = r4[e];
-        o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
-        r4[e] = o;
-      }
+      if (dres != nullptr) r4[e] = d;  // the residual branch is the FIRST writer of the block input's gradient
       float4 v = d;
       if (relu6) {
         const float4 y = p4[e];
@@ -816,7 +813,7 @@ __global__ void pool_drop_bwd_kernel(const float* __restrict__ dpooled, const fl
   const int c = idx % C;
   const int b = idx / ((size_t)P * C);
   const float d = dpooled[(size_t)b * C + c] * (mask != nullptr ? mask[(size_t)b * C + c] : 1.f);
-  dpost[idx] += d / (float)P;
+  dpost[idx] = d / (float)P;  // the only writer of the last layer's gradient
 }
 // x[r, 0..n) = act(x + bias)
 __global__ void bias_act_kernel(float* __restrict__ x, int ld, const float* __restrict__ bias, int rows, int n, int relu) {
@@ -1071,7 +1068,6 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
   const bool forward_only = grads == nullptr;  // evaluate_step: loss and z only, no gradient buffers touched
   if (!forward_only) {
     TRY(hipMemsetAsync(grads, 0, t->numel * sizeof(float), s));
-    TRY(hipMemsetAsync(t->dpost, 0, Bz * t->act_per_image * sizeof(float), s));
   }
   // ================================== forward ==================================
   size_t st_off = 0;
@@ -1187,6 +1183,9 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
   hipLaunchKernelGGL(pool_drop_bwd_kernel, dim3(nblk(Bz * P * LAST_C)), dim3(256), 0, s, dpooled, dropout_mask,
                      A(t->dpost, nl - 1), B, P, LAST_C);
   // ---- conv stack, last layer first ----
+  std::vector<char> res_writer(nl, 0);
+  for (int i = 0; i < nl; ++i)
+    if (t->tl[i].block_in >= 0) res_writer[t->tl[i].block_in] = 1;
   for (int i = nl - 1; i >= 0; --i) {
     const Layer& l = t->plan.layers[i];
     const TrainLayer& q = t->tl[i];
@@ -1195,6 +1194,10 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     const float* mean = t->stats + stat_off[i];
     const float* invstd = mean + l.cout;
     float* dres = q.block_in >= 0 ? A(t->dpost, q.block_in) : nullptr;
+    // dpost[i - 1] has at most two writers and no memset: the residual branch of the block that starts at layer i
+    // (its projection layer, handled EARLIER in this loop, stores) and this layer's input gradient (adds to it, or
+    // stores when there is no residual branch)
+    const int acc_in = i > 0 && res_writer[i - 1] ? 1 : 0;
     float* sums_b = t->sums + stat_off[i];
     int rpb, ld;
     const dim3 sgrid = stat_grid(M, l.cout, &rpb, &ld);
@@ -1232,10 +1235,10 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
                            grads + q.w, B, l.cout, l.h_in, l.h_out, bands);
       const size_t tin = Bz * l.h_in * l.h_in * l.cout;
       hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nblk(tin / 4)), dim3(256), 0, s, t->dpre, params + q.w, A(t->dpost, i - 1), B, l.cout,
-                         l.h_in, l.h_out, l.stride);
+                         l.h_in, l.h_out, l.stride, acc_in);
     } else {
       TRY(gemm(true, false, t->dpre, l.cout, x, l.cin, grads + q.w, l.cin, l.cout, l.cin, (int)M, 1, s));  // grads are zero: add
-      TRY(gemm(false, false, t->dpre, l.cout, params + q.w, l.cin, A(t->dpost, i - 1), l.cin, (int)M, l.cin, l.cout, 1, s));
+      TRY(gemm(false, false, t->dpre, l.cout, params + q.w, l.cin, A(t->dpost, i - 1), l.cin, (int)M, l.cin, l.cout, acc_in, s));
     }
   }
   return hipGetLastError();
