@@ -233,7 +233,9 @@ hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int l
   const long tiles = (long)grid.x * grid.y;
   // (weight gradients, `ta`: from K = 1024 — the 4x4 stage's K = 2048 with 45-100 output tiles ran as that many
   // workgroups of 64 serial chunks, 68 us a layer)
-  if (K >= (ta ? 1024 : 4096) && tiles < 512) {
+  // forward / input gradients of the same stage (M = 2048 rows, 96 output tiles, K = 960: 30 serial chunks, 35-45 us):
+  // from K = 512 when fewer than 128 tiles
+  if ((K >= (ta ? 1024 : 4096) && tiles < 512) || (!ta && K >= 512 && tiles < 128)) {
     // ~1024 workgroups (4 per CU), chunks of at least 256: with 1024-long chunks the 13x13 / 7x7 weight gradients
     // (K = 21632 / 6272, a handful of output tiles) ran as 60-120 workgroups of 30+ serial iterations each (68 us)
     int splits = (int)std::min<long>((1024 + tiles - 1) / tiles, (K + 255) / 256);
