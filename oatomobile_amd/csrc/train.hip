@@ -41,6 +41,13 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int FEAT = 128, LAST_C = 1280, VEC = 5, HID = 64;
+// x[c] + x[c + 16] + x[c + 32] + x[c + 48] in every one of the four lanes (two swaps on the VALU, no LDS)
+__device__ __forceinline__ float q4_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
 constexpr float BN_EPS = 1e-5f, BN_MOMENTUM = 0.1f;
 
 // ------------------------------------------------------------------------------------------------------------
@@ -544,6 +551,101 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(&dw[i], sm[i]);
 }
 
+// The same reduction for the small maps (13x13, 7x7, 4x4: an observation is a few hundred (column, 4 channels) items,
+// so (observation, band) blocks are 128 long blocks on a 256-CU chip, each ending in C * 9 atomics).  Here a block owns
+// 64 channels (blockIdx.x) of G observations (blockIdx.y); thread = (4-channel group, slot), the 16 slots walk the
+// (observation, column) pairs, every pair down the whole map, with the sums kept in registers across pairs:
+// ~500 blocks, 64 * 9 atomics each.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_wgrad_small_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
+                                                             float* __restrict__ dw, int B, int C, int Hi, int Ho, int G) {
+  __shared__ float sm[64 * 9];
+  for (int i = threadIdx.x; i < 64 * 9; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int C4 = C >> 2;
+  const int c4l = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int c4 = (int)blockIdx.x * 16 + c4l;
+  const int b0 = (int)blockIdx.y * G, nb = min(G, B - b0);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero;
+  if (c4 < C4) {
+    for (int pair = slot; pair < nb * Ho; pair += 16) {
+      const int bl = pair / Ho, ox = pair - bl * Ho;
+      const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)(b0 + bl) * Hi * Hi * C4;
+      const float4* g4 = reinterpret_cast<const float4*>(dpre) + (size_t)(b0 + bl) * Ho * Ho * C4;
+      const int ix0 = STRIDE * ox - 1;
+      const bool okl = ix0 >= 0, okr = ix0 + 2 < Hi;
+      const int xl = okl ? 0 : 1, xr = okr ? 2 : 1;
+      auto load_row = [&](int iy, float4(&r)[3]) {
+        const bool oky = iy >= 0 && iy < Hi;
+        const float4* p = x4 + ((size_t)min(max(iy, 0), Hi - 1) * Hi + ix0) * C4 + c4;
+        const float4 a = p[xl * C4], m = p[C4], c = p[xr * C4];
+        r[0] = (oky && okl) ? a : zero;
+        r[1] = oky ? m : zero;
+        r[2] = (oky && okr) ? c : zero;
+      };
+      float4 win[3][3];
+      load_row(-1, win[0]);
+      if (STRIDE == 1) load_row(0, win[1]);
+#pragma unroll 4
+      for (int oy = 0; oy < Ho; ++oy) {
+        if (STRIDE == 1) {
+          load_row(oy + 1, win[2]);
+        } else {
+          load_row(2 * oy, win[1]);
+          load_row(2 * oy + 1, win[2]);
+        }
+        const float4 g = g4[((size_t)oy * Ho + ox) * C4 + c4];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            float4& a = acc[ky * 3 + kx];
+            const float4 v = win[ky][kx];
+            a.x = fmaf(g.x, v.x, a.x);
+            a.y = fmaf(g.y, v.y, a.y);
+            a.z = fmaf(g.z, v.z, a.z);
+            a.w = fmaf(g.w, v.w, a.w);
+          }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if (STRIDE == 1) {
+            win[0][kx] = win[1][kx];
+            win[1][kx] = win[2][kx];
+          } else {
+            win[0][kx] = win[2][kx];
+          }
+        }
+      }
+    }
+  }
+  // the four slots of a wave that share a channel group (lanes c, c + 16, c + 32, c + 48) are added on the VALU first:
+  // same-address float atomics in LDS serialise (36 of them per thread were 27 of this kernel's 38 us)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc[t].x = q4_sum(acc[t].x);
+    acc[t].y = q4_sum(acc[t].y);
+    acc[t].z = q4_sum(acc[t].z);
+    acc[t].w = q4_sum(acc[t].w);
+  }
+  if (c4 < C4 && slot % 4 == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      atomicAdd(&sm[(4 * c4l + 0) * 9 + t], acc[t].x);
+      atomicAdd(&sm[(4 * c4l + 1) * 9 + t], acc[t].y);
+      atomicAdd(&sm[(4 * c4l + 2) * 9 + t], acc[t].z);
+      atomicAdd(&sm[(4 * c4l + 3) * 9 + t], acc[t].w);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 9; i += 256) {
+    const int ch = (int)blockIdx.x * 64 + i / 9;
+    if (ch < C) atomicAdd(&dw[(size_t)ch * 9 + i % 9], sm[i]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // BatchNorm (train mode), NHWC [M, C]
 // ------------------------------------------------------------------------------------------------------------
@@ -556,7 +658,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 //   STAT_BWD      out[c] += sum g,  out[C + c] += sum g * xhat,  xhat = (y - mean[c]) * invstd[c]   (x = g, y = pre)
 constexpr int STAT_GROUPS = 16;  // 4-channel groups per block of the reduction kernels (64 channels)
 // block-level sums of the reduction kernels: sm[0 .. 4 cgl) = S1, sm[4 cgl .. 8 cgl) = S2 of the block's channel chunk
-__device__ __forceinline__ void stat_block_add(float* sm, int cgl, int gl, const float4& s1, const float4& s2) {
+__device__ __forceinline__ void stat_block_add(float* sm, int cgl, int gl, float4 s1, float4 s2, bool active) {
+  if (cgl == STAT_GROUPS) {  // lanes c, c + 16, c + 32, c + 48 share the group: added on the VALU (whole waves take part)
+    s1.x = q4_sum(s1.x); s1.y = q4_sum(s1.y); s1.z = q4_sum(s1.z); s1.w = q4_sum(s1.w);
+    s2.x = q4_sum(s2.x); s2.y = q4_sum(s2.y); s2.z = q4_sum(s2.z); s2.w = q4_sum(s2.w);
+    active = active && (threadIdx.x & 63) < 16;
+  }
+  if (!active) return;
   atomicAdd(&sm[4 * gl + 0], s1.x); atomicAdd(&sm[4 * gl + 1], s1.y);
   atomicAdd(&sm[4 * gl + 2], s1.z); atomicAdd(&sm[4 * gl + 3], s1.w);
   atomicAdd(&sm[4 * (cgl + gl) + 0], s2.x); atomicAdd(&sm[4 * (cgl + gl) + 1], s2.y);
@@ -593,10 +701,11 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     const int c4 = (int)blockIdx.y * cgl + gl;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const float4* y4 = reinterpret_cast<const float4*>(y);
-    if (c4 < C4 && rl < RL) {
+    const bool active = c4 < C4 && rl < RL;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (active) {
       const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);  // STAT_SHIFTED: the shift k[c]
       const float4 is = MODE == STAT_BWD ? *reinterpret_cast<const float4*>(invstd + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 4
       for (size_t r = r0 + rl; r < r1; r += RL) {
         const float4 v = x4[r * C4 + c4];
@@ -613,8 +722,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
           s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
         }
       }
-      stat_block_add(sm, cgl, gl, s1, s2);
     }
+    stat_block_add(sm, cgl, gl, s1, s2, active);
     __syncthreads();
     stat_block_flush(sm, cgl, (int)blockIdx.y, C, part, ld);
     return;
@@ -749,10 +858,11 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
   const float4* y4 = reinterpret_cast<const float4*>(pre);
   float4* g4 = reinterpret_cast<float4*>(g);
   float4* r4 = reinterpret_cast<float4*>(dres);
-  if (c4 < C4 && rl < RL) {
+  const bool active = c4 < C4 && rl < RL;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (active) {
     const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
     const float4 is = *reinterpret_cast<const float4*>(invstd + 4 * c4);
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 4
     for (size_t r = r0 + rl; r < r1; r += RL) {
       const size_t e = r * C4 + c4;
@@ -774,8 +884,8 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
       s2.z = fmaf(v.z, (yy.z - mu.z) * is.z, s2.z);
       s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
     }
-    stat_block_add(sm, cgl, gl, s1, s2);
   }
+  stat_block_add(sm, cgl, gl, s1, s2, active);
   __syncthreads();
   stat_block_flush(sm, cgl, (int)blockIdx.y, C, part, ld);
 }
@@ -1231,7 +1341,17 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     } else if (l.kind == L_DW) {
       // (observation, row band) blocks: enough bands for ~2 blocks per CU, at least 4 rows each
       int bands = std::max(1, std::min(l.h_out / 4, (int)((512 + B - 1) / B)));
-      if (l.stride == 1)
+      if (l.h_out <= 13) {
+        const int chunks = (l.cout / 4 + 15) / 16;
+        const int G = std::max(1, std::min(8, (int)((long)B * chunks / 512)));  // ~512 blocks
+        const dim3 grid(chunks, (B + G - 1) / G);
+        if (l.stride == 1)
+          hipLaunchKernelGGL(dw_wgrad_small_kernel<1>, grid, dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in,
+                             l.h_out, G);
+        else
+          hipLaunchKernelGGL(dw_wgrad_small_kernel<2>, grid, dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in,
+                             l.h_out, G);
+      } else if (l.stride == 1)
         hipLaunchKernelGGL(dw_wgrad_kernel<1>, dim3(B * bands), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
                            grads + q.w, B, l.cout, l.h_in, l.h_out, bands);
       else
