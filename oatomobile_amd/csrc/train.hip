@@ -363,9 +363,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         }
       }
     }
+    // Co == 32: lanes oc and oc + 32 of a wave hold the same output channel — added with one swap before the LDS
+    // atomics (same-address float atomics in LDS serialise)
+    const bool pair = Co == 32 && groups == 8;
 #pragma unroll
-    for (int t = 0; t < CMAX * 9; ++t)
-      if (t < taps) atomicAdd(&sm[oc * taps + t], acc[t]);
+    for (int t = 0; t < CMAX * 9; ++t) {
+      float v = acc[t];
+      if (pair) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+      if (t < taps && (!pair || (threadIdx.x & 32) == 0)) atomicAdd(&sm[oc * taps + t], v);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < Co * taps; i += 256) atomicAdd(&dw[i], sm[i]);
@@ -471,101 +480,30 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __r
   *d4 = o;
 }
 
-// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c].  A block owns (observation, band of output
-// rows); a thread owns (output column, 4 channels) and walks DOWN the band with a 3x3 register window of 16-byte x
-// values (three new loads per row at stride 1, six at stride 2) and one 16-byte dpre value per row: 36 FMAs per 4-7
-// loads, no index arithmetic in the loop.  The 36 partial sums per thread meet in LDS, then one global atomic per
-// (block, channel, tap) (dw zeroed by the caller).  (The first version walked pixel chunks with scalar loads and a
-// div / mod per pixel: 289 us per layer on average, 4.9 ms of a 26 ms step.)
+// dw[c][tap] = sum_{b,oy,ox} dpre[b,oy,ox,c] x[b, s*oy-1+ky, s*ox-1+kx, c].  A block owns 64 channels (blockIdx.x) of G
+// observations x one band of output rows (blockIdx.y); thread = (4-channel group, slot): the 16 slots walk the
+// (observation, column) pairs, every pair DOWN the band with a 3x3 register window of 16-byte x values (three new
+// loads per row at stride 1, six at stride 2; clamped addresses and selects, no branch around a load) and one 16-byte
+// dpre value per row: 36 FMAs per 4-7 loads.  The 36 sums stay in registers across pairs; at the end the four lanes
+// of a wave that share a channel group are added with permlane swaps (same-address float atomics in LDS serialise:
+// they were 27 of 38 us), one lane in four adds into LDS, and the block ends in 64 * 9 global atomics (dw zeroed by
+// the caller).  ~500-1000 blocks for every layer shape: the 4x4 / 7x7 maps take G > 1 observations per block, the
+// 50x50 / 25x25 maps several bands per observation.  (History: a first version walked pixel chunks with scalar loads
+// and a div / mod per pixel — 289 us per layer, 4.9 ms of a 26 ms step; an (observation, band) x all-channels version
+// ended every block in C * 9 atomics after 36 LDS atomics per item.)
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
-                                                       float* __restrict__ dw, int B, int C, int Hi, int Ho, int bands) {
-  extern __shared__ float sm[];  // [C * 9]
-  for (int i = threadIdx.x; i < C * 9; i += 256) sm[i] = 0.f;
-  __syncthreads();
-  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
-  const int rows = (Ho + bands - 1) / bands;
-  const int oy0 = band * rows, oy1 = min(Ho, oy0 + rows);
-  const int C4 = C >> 2;
-  const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)b * Hi * Hi * C4;
-  const float4* g4 = reinterpret_cast<const float4*>(dpre) + (size_t)b * Ho * Ho * C4;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int item = threadIdx.x; item < Ho * C4; item += 256) {
-    const int c4 = item % C4, ox = item / C4;
-    const int ix0 = STRIDE * ox - 1;
-    const bool okl = ix0 >= 0, okr = ix0 + 2 < Hi;  // the centre column always lies inside
-    // branch-free (clamped addresses, then selects): a branch around a load costs a full wait at the merge
-    const int xl = okl ? 0 : 1, xr = okr ? 2 : 1;
-    auto load_row = [&](int iy, float4(&r)[3]) {
-      const bool oky = iy >= 0 && iy < Hi;
-      const float4* p = x4 + ((size_t)min(max(iy, 0), Hi - 1) * Hi + ix0) * C4 + c4;
-      const float4 a = p[xl * C4], m = p[C4], c = p[xr * C4];
-      r[0] = (oky && okl) ? a : zero;
-      r[1] = oky ? m : zero;
-      r[2] = (oky && okr) ? c : zero;
-    };
-    float4 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = zero;
-    float4 win[3][3];
-    load_row(STRIDE * oy0 - 1, win[0]);
-    if (STRIDE == 1) load_row(oy0, win[1]);
-    for (int oy = oy0; oy < oy1; ++oy) {
-      if (STRIDE == 1) {
-        load_row(oy + 1, win[2]);
-      } else {
-        load_row(2 * oy, win[1]);
-        load_row(2 * oy + 1, win[2]);
-      }
-      const float4 g = g4[((size_t)oy * Ho + ox) * C4 + c4];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          float4& a = acc[ky * 3 + kx];
-          const float4 v = win[ky][kx];
-          a.x = fmaf(g.x, v.x, a.x);
-          a.y = fmaf(g.y, v.y, a.y);
-          a.z = fmaf(g.z, v.z, a.z);
-          a.w = fmaf(g.w, v.w, a.w);
-        }
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        if (STRIDE == 1) {
-          win[0][kx] = win[1][kx];
-          win[1][kx] = win[2][kx];
-        } else {
-          win[0][kx] = win[2][kx];
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      atomicAdd(&sm[(4 * c4 + 0) * 9 + t], acc[t].x);
-      atomicAdd(&sm[(4 * c4 + 1) * 9 + t], acc[t].y);
-      atomicAdd(&sm[(4 * c4 + 2) * 9 + t], acc[t].z);
-      atomicAdd(&sm[(4 * c4 + 3) * 9 + t], acc[t].w);
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(&dw[i], sm[i]);
-}
-
-// The same reduction for the small maps (13x13, 7x7, 4x4: an observation is a few hundred (column, 4 channels) items,
-// so (observation, band) blocks are 128 long blocks on a 256-CU chip, each ending in C * 9 atomics).  Here a block owns
-// 64 channels (blockIdx.x) of G observations (blockIdx.y); thread = (4-channel group, slot), the 16 slots walk the
-// (observation, column) pairs, every pair down the whole map, with the sums kept in registers across pairs:
-// ~500 blocks, 64 * 9 atomics each.
-template <int STRIDE>
-__global__ __launch_bounds__(256) void dw_wgrad_small_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
-                                                             float* __restrict__ dw, int B, int C, int Hi, int Ho, int G) {
+                                                       float* __restrict__ dw, int B, int C, int Hi, int Ho, int G, int bands) {
   __shared__ float sm[64 * 9];
   for (int i = threadIdx.x; i < 64 * 9; i += 256) sm[i] = 0.f;
   __syncthreads();
   const int C4 = C >> 2;
   const int c4l = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int c4 = (int)blockIdx.x * 16 + c4l;
-  const int b0 = (int)blockIdx.y * G, nb = min(G, B - b0);
+  const int grp = (int)blockIdx.y / bands, band = (int)blockIdx.y - grp * bands;
+  const int b0 = grp * G, nb = min(G, B - b0);
+  const int rows = (Ho + bands - 1) / bands;
+  const int oy0 = band * rows, oy1 = min(Ho, oy0 + rows);
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc[9];
 #pragma unroll
@@ -587,10 +525,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_small_kernel(const float* __rest
         r[2] = (oky && okr) ? c : zero;
       };
       float4 win[3][3];
-      load_row(-1, win[0]);
-      if (STRIDE == 1) load_row(0, win[1]);
-#pragma unroll 4
-      for (int oy = 0; oy < Ho; ++oy) {
+      load_row(STRIDE * oy0 - 1, win[0]);
+      if (STRIDE == 1) load_row(oy0, win[1]);
+      for (int oy = oy0; oy < oy1; ++oy) {
         if (STRIDE == 1) {
           load_row(oy + 1, win[2]);
         } else {
@@ -659,10 +596,19 @@ __global__ __launch_bounds__(256) void dw_wgrad_small_kernel(const float* __rest
 constexpr int STAT_GROUPS = 16;  // 4-channel groups per block of the reduction kernels (64 channels)
 // block-level sums of the reduction kernels: sm[0 .. 4 cgl) = S1, sm[4 cgl .. 8 cgl) = S2 of the block's channel chunk
 __device__ __forceinline__ void stat_block_add(float* sm, int cgl, int gl, float4 s1, float4 s2, bool active) {
-  if (cgl == STAT_GROUPS) {  // lanes c, c + 16, c + 32, c + 48 share the group: added on the VALU (whole waves take part)
-    s1.x = q4_sum(s1.x); s1.y = q4_sum(s1.y); s1.z = q4_sum(s1.z); s1.w = q4_sum(s1.w);
-    s2.x = q4_sum(s2.x); s2.y = q4_sum(s2.y); s2.z = q4_sum(s2.z); s2.w = q4_sum(s2.w);
-    active = active && (threadIdx.x & 63) < 16;
+  if (cgl == STAT_GROUPS || cgl == 8 || cgl == 4) {
+    // lanes c, c + cgl, c + 2 cgl, ... of a wave share the group: added in registers first (whole waves take part;
+    // strides 16 and 32 with permlane swaps, 4 and 8 through the bpermute crossbar)
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = q4_sum(v[j]);
+      if (cgl <= 8) v[j] += __shfl_xor(v[j], 8);
+      if (cgl == 4) v[j] += __shfl_xor(v[j], 4);
+    }
+    s1 = make_float4(v[0], v[1], v[2], v[3]);
+    s2 = make_float4(v[4], v[5], v[6], v[7]);
+    active = active && (int)(threadIdx.x & 63) < cgl;
   }
   if (!active) return;
   atomicAdd(&sm[4 * gl + 0], s1.x); atomicAdd(&sm[4 * gl + 1], s1.y);
@@ -1340,23 +1286,19 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
                            l.h_out, l.cout, ppb);
     } else if (l.kind == L_DW) {
       // (observation, row band) blocks: enough bands for ~2 blocks per CU, at least 4 rows each
-      int bands = std::max(1, std::min(l.h_out / 4, (int)((512 + B - 1) / B)));
-      if (l.h_out <= 13) {
-        const int chunks = (l.cout / 4 + 15) / 16;
-        const int G = std::max(1, std::min(8, (int)((long)B * chunks / 512)));  // ~512 blocks
-        const dim3 grid(chunks, (B + G - 1) / G);
-        if (l.stride == 1)
-          hipLaunchKernelGGL(dw_wgrad_small_kernel<1>, grid, dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in,
-                             l.h_out, G);
-        else
-          hipLaunchKernelGGL(dw_wgrad_small_kernel<2>, grid, dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in,
-                             l.h_out, G);
-      } else if (l.stride == 1)
-        hipLaunchKernelGGL(dw_wgrad_kernel<1>, dim3(B * bands), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
-                           grads + q.w, B, l.cout, l.h_in, l.h_out, bands);
+      // ~512-1024 blocks: bands of at least 4 rows when one observation per block leaves the chip idle, several
+      // observations per block when (observations x 64-channel chunks) alone is already more than that
+      const int chunks = (l.cout / 4 + 15) / 16;
+      const int G = std::max(1, std::min(8, (int)((long)B * chunks / 512)));
+      const int groups = (B + G - 1) / G;
+      const int bands = std::max(1, std::min(l.h_out / 4, (int)(1024 / ((long)groups * chunks))));
+      const dim3 grid(chunks, groups * bands);
+      if (l.stride == 1)
+        hipLaunchKernelGGL(dw_wgrad_kernel<1>, grid, dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in, l.h_out, G,
+                           bands);
       else
-        hipLaunchKernelGGL(dw_wgrad_kernel<2>, dim3(B * bands), dim3(256), (size_t)l.cout * 9 * sizeof(float), s, x, t->dpre,
-                           grads + q.w, B, l.cout, l.h_in, l.h_out, bands);
+        hipLaunchKernelGGL(dw_wgrad_kernel<2>, grid, dim3(256), 0, s, x, t->dpre, grads + q.w, B, l.cout, l.h_in, l.h_out, G,
+                           bands);
       const size_t tin = Bz * l.h_in * l.h_in * l.cout;
       hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nblk(tin / 4)), dim3(256), 0, s, t->dpre, params + q.w, A(t->dpost, i - 1), B, l.cout,
                          l.h_in, l.h_out, l.stride, acc_in);
