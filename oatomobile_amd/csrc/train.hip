@@ -278,9 +278,16 @@ hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int l
 // `oc` lanes of a pixel read the same words), a tap off the image enters the chain as +0; CT = C when it is 2 or 4
 // (fully unrolled), 0 = any C.
 template <int CT>
-__global__ void stem_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
-                                int B, int C_, int Hin, int Ho, int Co) {
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       float* __restrict__ out, int B, int C_, int Hin, int Ho, int Co) {
   const int C = CT > 0 ? CT : C_;
+  // the weights [Co][C*9] as ws[tap][oc] (CT > 0, Co <= 64): a lane reads its 18 / 36 words at consecutive addresses
+  // across the oc lanes instead of 72-byte-strided global loads
+  __shared__ float ws[(CT > 0 ? CT : 1) * 9 * 64];
+  if (CT > 0) {
+    for (int i = threadIdx.x; i < Co * CT * 9; i += 256) ws[(i % (CT * 9)) * 64 + i / (CT * 9)] = w[i];
+    __syncthreads();
+  }
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * Ho * Ho * Co;
   if (idx >= total) return;
@@ -303,18 +310,15 @@ __global__ void stem_fwd_kernel(const float* __restrict__ in, const float* __res
   const float* wb = w + (size_t)oc * C * 9;
   float acc = 0.f;
   if (CT > 0) {
-    float v[(CT > 0 ? CT : 1) * 9], wv[(CT > 0 ? CT : 1) * 9];
+    float v[(CT > 0 ? CT : 1) * 9];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        v[c * 9 + t] = ib[(size_t)c * Hin * Hin + off[t]];
-        wv[c * 9 + t] = wb[c * 9 + t];
-      }
+      for (int t = 0; t < 9; ++t) v[c * 9 + t] = ib[(size_t)c * Hin * Hin + off[t]];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc = fmaf(ok[t] ? v[c * 9 + t] : 0.f, wv[c * 9 + t], acc);
+      for (int t = 0; t < 9; ++t) acc = fmaf(ok[t] ? v[c * 9 + t] : 0.f, ws[(c * 9 + t) * 64 + oc], acc);
   } else {
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -902,8 +906,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   __shared__ float part[8][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
   float s = 0.f;
-  if (c < n)
-    for (int r = rg; r < rows; r += 8) s += x[(size_t)r * ld + c];
+  if (c < n) {
+#pragma unroll 8
+    for (int r = rg; r < rows; r += 8) s += x[(size_t)r * ld + c];  // unrolled: eight loads in flight, same sum order
+  }
   part[rg][threadIdx.x & 31] = s;
   __syncthreads();
   if (rg == 0 && c < n) {
@@ -1141,10 +1147,10 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     float* post = A(t->post, i);
     const float* x = i == 0 ? visual : A(t->post, i - 1);
     if (l.kind == L_STEM) {
-      if (l.cin == 2)
+      if (l.cin == 2 && l.cout <= 64)
         hipLaunchKernelGGL(stem_fwd_kernel<2>, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in,
                            l.h_out, l.cout);
-      else if (l.cin == 4)
+      else if (l.cin == 4 && l.cout <= 64)
         hipLaunchKernelGGL(stem_fwd_kernel<4>, dim3(nblk(total)), dim3(256), 0, s, x, params + q.w, pre, B, l.cin, l.h_in,
                            l.h_out, l.cout);
       else

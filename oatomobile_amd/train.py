@@ -95,7 +95,7 @@ class DIMTrainer:
     target = batch["player_future"][..., :2].to(torch.float32)
     _lib.expect_shape(target, (B, arch.T, 2), "player_future[..., :2]")
     if y is None:
-      y = torch.normal(mean=target, std=torch.ones_like(target) * self._noise) if train else target  # train.py:184-189
+      y = torch.normal(mean=target, std=float(self._noise)) if train else target  # train.py:184-189 (one launch)
     y = y.to(self._device, torch.float32).contiguous()
     if train and dropout_mask is None:
       keep = torch.rand(B, arch.LAST_CHANNELS, device=self._device) >= DROPOUT_P
