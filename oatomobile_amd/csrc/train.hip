@@ -621,7 +621,8 @@ __device__ __forceinline__ void stat_block_add(float* sm, int cgl, int gl, float
   atomicAdd(&sm[4 * (cgl + gl) + 2], s2.z); atomicAdd(&sm[4 * (cgl + gl) + 3], s2.w);
 }
 // a block's sums go to its own column of the partial table part[2 C][ld] (plain stores: no contended atomics, and the
-// second stage adds the columns in a fixed order, so a step is reproducible bit for bit)
+// second stage adds the columns in a fixed order: the statistics are the same bits on every run — the weight gradients
+// still end in float atomics)
 __device__ __forceinline__ void stat_block_flush(const float* sm, int cgl, int chunk, int C, float* __restrict__ part, int ld) {
   const int w = 4 * cgl;
   for (int i = threadIdx.x; i < 2 * w; i += 256) {
