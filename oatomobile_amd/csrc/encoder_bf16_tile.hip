@@ -66,7 +66,7 @@ __device__ __forceinline__ f32x2 relu6_2(f32x2 v) {
 }
 
 // development only (tools/dev/tile_abl.sh rebuilds with -DRIP_TILE_ABL=<bits>; wrong results): 1 = no depthwise,
-// 2 = no matrix work, 4 = no tap loads, 8 = no LDS zeroing, 16 = no epilogue stores
+// 2 = no matrix work, 4 = no tap loads, 8 = no LDS zeroing, 16 = no epilogue stores, 32 = pointwise weights of chunk 0 only
 #ifndef RIP_TILE_ABL
 #define RIP_TILE_ABL 0
 #endif
@@ -90,10 +90,14 @@ struct TileGeom {
   static constexpr int HOUT = STRIDE == 1 ? HIN : (HIN + 1) / 2;
   static constexpr int HWI = HIN * HIN, HWO = HOUT * HOUT;
   static constexpr int PW = HIN + 2;                                  // padded row: zero, HIN pixels, zero
-  static constexpr int E_ROWS = G * HIN * PW;                         // per E buffer
+  static constexpr int E_DUMP = G * HIN * PW;                         // row that takes the stores of lanes without a pixel
+  static constexpr int E_ROWS = E_DUMP + 1;                            // per E buffer
   static constexpr int D_ROWS = ((G * HWO + 15) / 16) * 16;           // per D buffer
   static constexpr int TIN = (G * HWI + 63) / 64, TOUT = (G * HWO + 63) / 64;  // 16-pixel tiles per matrix wave
-  static constexpr size_t LDS_BYTES = (size_t)2 * (E_ROWS + D_ROWS) * LD * sizeof(bf16_t);
+  static constexpr size_t ED_BYTES = (size_t)2 * (E_ROWS + D_ROWS) * LD * sizeof(bf16_t);
+  // + the block's depthwise taps [9][HID] and biases [HID] (fp32): every vector thread of every workgroup used to fetch
+  // its 18 + 2 float4 per chunk from global memory — 73 KB per step through the CU's texture path, 10 us of a 45 us kernel
+  static constexpr size_t lds_bytes(int hid) { return ED_BYTES + (size_t)10 * hid * sizeof(float); }
 };
 
 // G: observations per workgroup at most (G * HOUT * 8 <= 256 depthwise threads); a.G <= G is what the host chose.
@@ -111,11 +115,13 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   constexpr int TIN = (Geo::TIN * 4 + WP - 1) / WP, TOUT = (Geo::TOUT * 4 + WP - 1) / WP;
   constexpr int KSX = CIN / 32, NCT = COUT / 16 / WCH, NHT = HC / 16 / WCH, NKP = HC / 32;
   static_assert((COUT / 16) % WCH == 0 && (HC / 16) % WCH == 0, "channel partitions");
+  constexpr int NPT_IN = (G * HWI + 15) / 16, NPT_OUT = (G * HWO + 15) / 16;  // 16-pixel tiles of a full group
   constexpr int CTG = NCT > 10 ? 10 : NCT;  // channel tiles per projection pass (weights of one pass are live at a time)
   static_assert(NCT % CTG == 0 && (CTG == NCT || !APF), "projection passes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* const Ebuf = reinterpret_cast<bf16_t*>(smem_raw);              // [2][E_ROWS][LD]
   bf16_t* const Dbuf = Ebuf + (size_t)2 * Geo::E_ROWS * LD;              // [2][D_ROWS][LD]
+  float* const Tl = reinterpret_cast<float*>(smem_raw + Geo::ED_BYTES);   // [9][HID] taps, [HID] biases
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = blockIdx.z;
@@ -133,6 +139,14 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   // zero both E buffers once: the padding columns are never written again
   if (!(RIP_TILE_ABL & 8))
     for (int e = tid; e < 2 * Geo::E_ROWS * LD / 8; e += 512) reinterpret_cast<u32x4*>(Ebuf)[e] = zero4;
+  {
+    const int HIDs = a.HID;
+    const float* Wk = a.wbase + (size_t)(a.k0 + blockIdx.z) * a.model_stride;
+    for (int e = tid; e < 9 * HIDs / 4; e += 512)
+      reinterpret_cast<float4*>(Tl)[e] = *reinterpret_cast<const float4*>(Wk + a.wd_off + 4 * e);
+    for (int e = tid; e < HIDs / 4; e += 512)
+      reinterpret_cast<float4*>(Tl + 9 * HIDs)[e] = *reinterpret_cast<const float4*>(Wk + a.bd_off + 4 * e);
+  }
   lds_barrier();
 
   if (w < 4) {
@@ -140,9 +154,8 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     const int n = lane & 15, q = lane >> 4;
     const int wpix = w / WCH, wch = w % WCH;  // this wave's pixel partition / channel partition
     const int ht0 = wch * NHT, ct0w = wch * NCT;
-    const int npt_in = (m_in + 15) >> 4, npt_out = (m_out + 15) >> 4;
     u32x4 xb[TIN][KSX];   // block input, B operands
-    int erow[TIN];        // padded E row of this lane's pixel per tile (-1: beyond the workgroup's pixels)
+    int erow[TIN];        // padded E row of this lane's pixel per tile (the dump row beyond the workgroup's pixels)
 #pragma unroll
     for (int t = 0; t < TIN; ++t) {
       const int px = 16 * (wpix + WP * t) + n;
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       for (int ks = 0; ks < KSX; ++ks)
         xb[t][ks] = px < m_in ? *reinterpret_cast<const u32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q) : zero4;
       const int g = px / HWI, r = px - g * HWI, iy = r / HIN, ix = r - iy * HIN;
-      erow[t] = px < m_in ? g * HIN * PW + iy * PW + ix + 1 : -1;
+      erow[t] = px < m_in ? g * HIN * PW + iy * PW + ix + 1 : Geo::E_DUMP;
     }
     f32x4 acc[TOUT][NCT];
 #pragma unroll
@@ -178,46 +191,67 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     };
     if (AEF) load_ae(0);
     if (APF) load_ap(0, 0);
+    // Both phases are software-pipelined by hand across pixel tiles: the MFMAs of tile t + 1 are issued before the
+    // epilogue (expansion) / behind the operand reads (projection) of tile t.  Left to itself the compiler put every
+    // chain into ONE accumulator tuple: MFMA pair, wait for the result, ten VALU instructions, next pair — the matrix
+    // waves (one per SIMD, nothing else to issue) ran at a quarter of their MFMA time.
+    auto tile_on = [&](int t, int npt) { return !(WP * t + WP - 1 >= npt && wpix + WP * t >= npt); };  // compile-time but for the last t
     auto expand = [&](int c) {  // chunk c -> E[c & 1]
       bf16_t* E = Ebuf + (size_t)(c & 1) * Geo::E_ROWS * LD;
-      if (!AEF) load_ae(c);
+      if (!AEF && !((RIP_TILE_ABL & 32) && c > 0)) load_ae(c);
+      // no run-time branch per tile (a ragged last group's missing pixels are computed on zero operands and stored to
+      // the dump row; only tiles no FULL group has are skipped, which is known at compile time except for the last t)
+      f32x4 v[2][NHT];
+      auto mm = [&](int t, f32x4(&o)[NHT]) {
 #pragma unroll
-      for (int t = 0; t < TIN; ++t) {
-        if (wpix + WP * t >= npt_in) continue;  // wave-uniform
+        for (int ht = 0; ht < NHT; ++ht) o[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+          for (int ht = 0; ht < NHT; ++ht)
+            o[ht] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ae[ht][ks]), as_bf16x8(xb[t][ks]), o[ht], 0, 0, 0);
+      };
+      auto epi = [&](int t, const f32x4(&o)[NHT]) {
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < KSX; ++ks)
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ae[ht][ks]), as_bf16x8(xb[t][ks]), v, 0, 0, 0);
-          u32x2 o;
-          o.x = pack_bf16(relu6_2(f32x2{v[0] + be[ht].x, v[1] + be[ht].y}));
-          o.y = pack_bf16(relu6_2(f32x2{v[2] + be[ht].z, v[3] + be[ht].w}));
-          if (erow[t] >= 0) *reinterpret_cast<u32x2*>(E + (size_t)erow[t] * LD + 16 * (ht0 + ht) + 4 * q) = o;
+          u32x2 w2;
+          w2.x = pack_bf16(relu6_2(f32x2{o[ht][0] + be[ht].x, o[ht][1] + be[ht].y}));
+          w2.y = pack_bf16(relu6_2(f32x2{o[ht][2] + be[ht].z, o[ht][3] + be[ht].w}));
+          *reinterpret_cast<u32x2*>(E + (size_t)erow[t] * LD + 16 * (ht0 + ht) + 4 * q) = w2;
         }
+      };
+      if (tile_on(0, NPT_IN)) mm(0, v[0]);
+#pragma unroll
+      for (int t = 0; t < TIN; ++t) {
+        if (t + 1 < TIN && tile_on(t + 1, NPT_IN)) mm(t + 1, v[(t + 1) & 1]);
+        if (tile_on(t, NPT_IN)) epi(t, v[t & 1]);
       }
-      if (AEF && c + 1 < nch) load_ae(c + 1);  // lands during the projection and the barrier
+      if (AEF && c + 1 < nch && !(RIP_TILE_ABL & 32)) load_ae(c + 1);  // lands during the projection and the barrier
     };
     auto project = [&](int c) {  // chunk c <- D[c & 1]
       const bf16_t* D = Dbuf + (size_t)(c & 1) * Geo::D_ROWS * LD;
 #pragma unroll
       for (int cg = 0; cg < NCT; cg += CTG) {
-        if (!APF) load_ap(c, cg);
-#pragma unroll
-        for (int t = 0; t < TOUT; ++t) {
-          if (wpix + WP * t >= npt_out) continue;  // wave-uniform
-          u32x4 bv[NKP];
+        if (!APF && !((RIP_TILE_ABL & 32) && c > 0)) load_ap(c, cg);
+        u32x4 bv[2][NKP];  // (a ragged group's missing pixels read rows of D nobody wrote: never stored)
+        auto rd = [&](int t, u32x4(&o)[NKP]) {
 #pragma unroll
           for (int ks = 0; ks < NKP; ++ks)
-            bv[ks] = *reinterpret_cast<const u32x4*>(D + (size_t)(16 * (wpix + WP * t) + n) * LD + 32 * ks + 8 * q);
+            o[ks] = *reinterpret_cast<const u32x4*>(D + (size_t)(16 * (wpix + WP * t) + n) * LD + 32 * ks + 8 * q);
+        };
+        if (tile_on(0, NPT_OUT)) rd(0, bv[0]);
 #pragma unroll
-          for (int ct = 0; ct < CTG; ++ct)
+        for (int t = 0; t < TOUT; ++t) {
+          if (t + 1 < TOUT && tile_on(t + 1, NPT_OUT)) rd(t + 1, bv[(t + 1) & 1]);
+          if (!tile_on(t, NPT_OUT)) continue;
 #pragma unroll
-            for (int ks = 0; ks < NKP; ++ks)
-              acc[t][cg + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ap[ct][ks]), as_bf16x8(bv[ks]), acc[t][cg + ct], 0, 0, 0);
+          for (int ks = 0; ks < NKP; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < CTG; ++ct)
+              acc[t][cg + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ap[ct][ks]), as_bf16x8(bv[t & 1][ks]), acc[t][cg + ct], 0, 0, 0);
         }
       }
-      if (APF && c + 1 < nch) load_ap(c + 1, 0);  // projected in the next step
+      if (APF && c + 1 < nch && !(RIP_TILE_ABL & 32)) load_ap(c + 1, 0);  // projected in the next step
     };
     const bool mx_on = !(RIP_TILE_ABL & 2);
 #pragma unroll 1
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     const int d_off = ((dw_on ? dimg : 0) * HWO + dcol) * LD + 8 * c8;
     f32x2 wt[2][9][4], bd[2][4];
     auto load_taps = [&](int c, f32x2(&wt_)[9][4], f32x2(&bd_)[4]) {
-      const float* wd = W + a.wd_off + c * HC + 8 * c8;
+      const float* wd = Tl + c * HC + 8 * c8;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const float4 w0 = *reinterpret_cast<const float4*>(wd + (size_t)t * HID);
@@ -279,8 +313,8 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         wt_[t][2] = f32x2{w1.x, w1.y};
         wt_[t][3] = f32x2{w1.z, w1.w};
       }
-      const float4 b0 = *reinterpret_cast<const float4*>(W + a.bd_off + c * HC + 8 * c8);
-      const float4 b1 = *reinterpret_cast<const float4*>(W + a.bd_off + c * HC + 8 * c8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(Tl + 9 * HID + c * HC + 8 * c8);
+      const float4 b1 = *reinterpret_cast<const float4*>(Tl + 9 * HID + c * HC + 8 * c8 + 4);
       bd_[0] = f32x2{b0.x, b0.y};
       bd_[1] = f32x2{b0.z, b0.w};
       bd_[2] = f32x2{b1.x, b1.y};
@@ -352,11 +386,13 @@ hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)Geo::LDS_BYTES);
+                                       (int)Geo::lds_bytes(6 * CIN));
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G, 1, kc), dim3(512), Geo::LDS_BYTES, s, a);
+  if (a.HID != 6 * CIN) return hipErrorInvalidValue;
+  static_assert(Geo::lds_bytes(6 * CIN) <= 160 * 1024, "LDS budget");
+  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
   return hipGetLastError();
 }
 
