@@ -290,10 +290,15 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
     // 1. expand the S new rows (operands fetched during the previous row), then request the next ones
 #pragma unroll
     for (int i = 0; i < STRIDE; ++i) expand_row(oy * STRIDE + 2 - STRIDE + i, xr[i]);
-    if (oy + 1 < oy1) {
+    // (unconditional: past the band the rows are image rows nobody uses, past the image load_x takes an empty
+    // descriptor — a branch here makes the compiler wait for every load in flight at the merge)
 #pragma unroll
-      for (int i = 0; i < STRIDE; ++i) load_x((oy + 1) * STRIDE + 2 - STRIDE + i, xr[i]);
-    }
+    for (int i = 0; i < STRIDE; ++i) load_x((oy + 1) * STRIDE + 2 - STRIDE + i, xr[i]);
+    // the residual operands of this row's projection tiles are requested here, a depthwise ahead of their use
+    const __amdgpu_buffer_rsrc_t rsrd = row_srd(xin + (size_t)oy * H_in * CIN, a.residual ? x_row_bytes : 0);
+    u32x2 rr[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) rr[t] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, roff[t], 0, 0);  // zeros when there is no residual
     // 2. depthwise for this chunk
     if (WINDOW) {
 #pragma unroll
@@ -359,12 +364,10 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
     lds_barrier();  // every chunk of ds[buf] is in place
     // 3. projection tiles of this wave over the full hidden K
     const __amdgpu_buffer_rsrc_t ysrd = row_srd(yout + (size_t)oy * H_out * COUT, H_out * COUT * 2);
-    const __amdgpu_buffer_rsrc_t rsrd = row_srd(xin + (size_t)oy * H_in * CIN, a.residual ? x_row_bytes : 0);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int tile = w + NW * t;
-      if (tile >= TT) continue;
-      const int pt = tile / n_ct, ct = tile - pt * n_ct;
+      const int tile = w + NW * t;  // (a wave without a tile here multiplies zero weights and stores out of bounds: no branch)
+      const int pt = tile / n_ct;
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
       const bf16_t* brow = drow + (size_t)(16 * pt + n) * DLD + 8 * q;
 #pragma unroll
@@ -373,9 +376,8 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ap[t][ks]), as_bf16x8(bv), c, 0, 0, 0);
       }
       f32x2 v0 = {c[0] + bpj[t].x, c[1] + bpj[t].y}, v1 = {c[2] + bpj[t].z, c[3] + bpj[t].w};
-      const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rsrd, roff[t], 0, 0);  // zeros when there is no residual
-      v0 += bfpair(rr.x);
-      v1 += bfpair(rr.y);
+      v0 += bfpair(rr[t].x);
+      v1 += bfpair(rr[t].y);
       u32x2 o;
       o.x = pack_bf16(v0);
       o.y = pack_bf16(v1);
