@@ -889,10 +889,6 @@ __global__ void bias_act_kernel(float* __restrict__ x, int ld, const float* __re
   if (relu) v = fmaxf(v, 0.f);
   x[(size_t)r * ld + c] = v;
 }
-__global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, int n) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n && !(y[idx] > 0.f)) d[idx] = 0.f;
-}
 __global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows,
                                  int n) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -918,6 +914,58 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 #pragma unroll
     for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
     out[c] = t;
+  }
+}
+// d <- d masked by relu'(y) in place AND out[c] = sum_r d[r][c] (the Linear bias gradient) in one pass
+__global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(float* __restrict__ d, const float* __restrict__ y, int ld,
+                                                              float* __restrict__ out, int rows, int n) {
+  __shared__ float part[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < n) {
+#pragma unroll 8
+    for (int r = rg; r < rows; r += 8) {
+      const size_t e = (size_t)r * ld + c;
+      const float v = y[e] > 0.f ? d[e] : 0.f;
+      d[e] = v;
+      s += v;
+    }
+  }
+  part[rg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rg == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+    out[c] = t;
+  }
+}
+// up to four colsum_kernel launches over column ranges of ONE matrix as one launch (the flow's four bias gradients)
+struct ColsumSegs {
+  int col0[4], n[4], blk0[5];  // segment i: columns col0[i] .. col0[i] + n[i], blocks blk0[i] .. blk0[i + 1]
+  float* out[4];
+};
+__global__ __launch_bounds__(256) void colsum_segs_kernel(const float* __restrict__ x, int ld, int rows, ColsumSegs g) {
+  __shared__ float part[8][32];
+  int seg = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if ((int)blockIdx.x >= g.blk0[i]) seg = i;
+  const int c = ((int)blockIdx.x - g.blk0[seg]) * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  const bool on = c < g.n[seg];
+  float s = 0.f;
+  if (on) {
+    const float* xc = x + g.col0[seg] + c;
+#pragma unroll 8
+    for (int r = rg; r < rows; r += 8) s += xc[(size_t)r * ld];
+  }
+  part[rg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rg == 0 && on) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+    g.out[seg][c] = t;
   }
 }
 __global__ void mean_loss_kernel(const float* __restrict__ q, float* __restrict__ loss, int B) {
@@ -1225,24 +1273,29 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     TRY(gemm(true, false, dgh, ld, hprev, ld, grads + t->f_whh, 64, 192, 64, R, 0, s));
     TRY(gemm(true, false, da1, ld, hh, ld, grads + t->f_w1, 64, 32, 64, R, 0, s));
     TRY(gemm(true, false, dout, ld, ra1, ld, grads + t->f_w2, 32, 4, 32, R, 0, s));
-    hipLaunchKernelGGL(colsum_kernel, dim3((192 + 31) / 32), dim3(256), 0, s, dgi, ld, grads + t->f_bih, R, 192);
-    hipLaunchKernelGGL(colsum_kernel, dim3((192 + 31) / 32), dim3(256), 0, s, dgh, ld, grads + t->f_bhh, R, 192);
-    hipLaunchKernelGGL(colsum_kernel, dim3((32 + 31) / 32), dim3(256), 0, s, da1, ld, grads + t->f_b1, R, 32);
-    hipLaunchKernelGGL(colsum_kernel, dim3((4 + 31) / 32), dim3(256), 0, s, dout, ld, grads + t->f_b2, R, 4);
+    ColsumSegs g;
+    const float* cols[4] = {dgi, dgh, da1, dout};
+    const int ns[4] = {192, 192, 32, 4};
+    float* outs[4] = {grads + t->f_bih, grads + t->f_bhh, grads + t->f_b1, grads + t->f_b2};
+    g.blk0[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+      g.col0[i] = (int)(cols[i] - fb);
+      g.n[i] = ns[i];
+      g.out[i] = outs[i];
+      g.blk0[i + 1] = g.blk0[i] + (ns[i] + 31) / 32;
+    }
+    hipLaunchKernelGGL(colsum_segs_kernel, dim3(g.blk0[4]), dim3(256), 0, s, fb, ld, R, g);
   }
   // ================================== backward ==================================
   // ---- merger / classifier ----
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dz, zz, B * HID);
+  hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dz, zz, HID, grads + t->mrg_b[2], B, HID);
   TRY(gemm(true, false, dz, HID, h2, HID, grads + t->mrg_w[2], HID, HID, HID, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dz, HID, grads + t->mrg_b[2], B, HID);
   TRY(gemm(false, false, dz, HID, params + t->mrg_w[2], HID, dh2, HID, B, HID, HID, 0, s));
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dh2, h2, B * HID);
+  hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dh2, h2, HID, grads + t->mrg_b[1], B, HID);
   TRY(gemm(true, false, dh2, HID, h1, HID, grads + t->mrg_w[1], HID, HID, HID, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dh2, HID, grads + t->mrg_b[1], B, HID);
   TRY(gemm(false, false, dh2, HID, params + t->mrg_w[1], HID, dh1, HID, B, HID, HID, 0, s));
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(Bz * HID)), dim3(256), 0, s, dh1, h1, B * HID);
+  hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dh1, h1, HID, grads + t->mrg_b[0], B, HID);
   TRY(gemm(true, false, dh1, HID, merged, FEAT + VEC, grads + t->mrg_w[0], FEAT + VEC, HID, FEAT + VEC, B, 0, s));
-  hipLaunchKernelGGL(colsum_kernel, dim3((HID + 31) / 32), dim3(256), 0, s, dh1, HID, grads + t->mrg_b[0], B, HID);
   TRY(gemm(false, false, dh1, HID, params + t->mrg_w[0], FEAT + VEC, dmerged, FEAT + VEC, B, FEAT + VEC, HID, 0, s));
   TRY(gemm(true, false, dmerged, FEAT + VEC, pooled, LAST_C, grads + t->cls_w, LAST_C, FEAT, LAST_C, B, 0, s));
   hipLaunchKernelGGL(colsum_kernel, dim3((FEAT + 31) / 32), dim3(256), 0, s, dmerged, FEAT + VEC, grads + t->cls_b, B, FEAT);

@@ -98,8 +98,8 @@ class DIMTrainer:
       y = torch.normal(mean=target, std=float(self._noise)) if train else target  # train.py:184-189 (one launch)
     y = y.to(self._device, torch.float32).contiguous()
     if train and dropout_mask is None:
-      keep = torch.rand(B, arch.LAST_CHANNELS, device=self._device) >= DROPOUT_P
-      dropout_mask = keep.to(torch.float32) / (1.0 - DROPOUT_P)
+      # keep with probability 1 - p, scaled by 1 / (1 - p) (nn.Dropout): two launches
+      dropout_mask = torch.empty(B, arch.LAST_CHANNELS, device=self._device).bernoulli_(1.0 - DROPOUT_P).mul_(1.0 / (1.0 - DROPOUT_P))
     if dropout_mask is not None:
       dropout_mask = dropout_mask.to(self._device, torch.float32).contiguous()
       _lib.expect_shape(dropout_mask, (B, arch.LAST_CHANNELS), "dropout_mask")
