@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "encoder.h"
+#include "flow.h"  // device_cu_count
 
 namespace rip {
 
@@ -128,13 +129,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, q = lane >> 4;
-  const int k = blockIdx.z, b = blockIdx.y, band = blockIdx.x;
+  const int k = blockIdx.z, band = blockIdx.x;
   bf16_t* es = lds + (size_t)w * 3 * EW * ELD;   // this wave's ring: [3][EW][ELD]
   bf16_t* ds = lds + SH::RING_EL;                // [2][16 * NPTO][DLD]
   const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
   const bf16_t* Wh = a.whbase + (size_t)(a.k0 + k) * a.model_stride;
-  const bf16_t* xin = a.x + ((size_t)k * a.B + b) * H_IN * H_IN * CIN;
-  bf16_t* yout = a.y + ((size_t)k * a.B + b) * H_OUT * H_OUT * COUT;
+  // persistent over observations: the wave constants below (expansion / depthwise / projection operands, ~40 loads and
+  // the LDS zeroing) are built once per workgroup, which then walks observations blockIdx.y, + gridDim.y, ...
+  const bf16_t* const xin0 = a.x + (size_t)k * a.B * H_IN * H_IN * CIN;
+  bf16_t* const yout0 = a.y + (size_t)k * a.B * H_OUT * H_OUT * COUT;
+  const bf16_t* xin = xin0;  // this item's observation (set in the item loop; the lambdas below read it by reference)
+  bf16_t* yout = yout0;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int g0 = w * NG;  // first hidden group of this wave
 
@@ -150,13 +155,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
     constexpr bool gv = true;
     const int h = 16 * (g0 + gl) + n;  // the A row of this lane
     {
-      u32x4 v = zero4;
-      if (gv && q < KBE) v = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)h * CIN + 8 * q);
-      if (KE == 1 && gv && q == KBE) v.x = split_bf16(W[a.be_off + h]);
+      // every load of this prologue is unconditional (clamped address, then a select): behind a branch each one is
+      // waited for on its own — the 30-odd constants of a wave were that many memory round trips IN SEQUENCE per
+      // workgroup (`s_waitcnt vmcnt(0)` at every merge), a quarter of the kernel
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)h * CIN + 8 * (q < KBE ? q : KBE - 1));
+      const unsigned bsplit = split_bf16(W[a.be_off + h]);
+      u32x4 v = q < KBE ? wv : zero4;
+      if (KE == 1) v.x = q == KBE ? bsplit : v.x;
       ae[gl][0] = v;
       if (KE == 2) {
         u32x4 v2 = zero4;
-        if (gv && q == 0) v2.x = split_bf16(W[a.be_off + h]);
+        v2.x = q == 0 ? bsplit : 0u;
         ae[gl][KE - 1] = v2;
       }
     }
@@ -168,11 +177,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
       const int half = q >> 1;
       const int tap = kb < 4 ? 2 * kb + half : (kb == 4 ? 8 : 2 * (kb - 5) + half);
       const bool lo = kb > 4 || (kb == 4 && half == 1);
-      unsigned v16 = 0;
-      if (diag) {
-        const unsigned s = split_bf16(W[a.wd_off + (size_t)tap * HID + h]);
-        v16 = lo ? (s >> 16) : (s & 0xffffu);
-      }
+      const unsigned s = split_bf16(W[a.wd_off + (size_t)tap * HID + h]);
+      const unsigned v16 = diag ? (lo ? (s >> 16) : (s & 0xffffu)) : 0u;
       const unsigned dw = v16 << ((pos & 1) * 16);
       u32x4 op;
       op.x = (pos >> 1) == 0 ? dw : 0u;
@@ -201,11 +207,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 32 * ks + 8 * q;
-        ap[t][ks] = (tile < TT && co < COUT && kk < HID) ? *reinterpret_cast<const u32x4*>(Wh + a.wp_off + (size_t)co * HID + kk)
-                                                         : zero4;
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(Wh + a.wp_off + (size_t)(co < COUT ? co : COUT - 1) * HID + (kk < HID ? kk : HID - 8));
+        ap[t][ks] = (tile < TT && co < COUT && kk < HID) ? wv : zero4;
       }
       const int cb = 16 * ct + 4 * q;
-      bpj[t] = (tile < TT && cb < COUT) ? *reinterpret_cast<const float4*>(W + a.bp_off + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv4 = *reinterpret_cast<const float4*>(W + a.bp_off + (cb < COUT ? cb : COUT - 4));
+      bpj[t] = (tile < TT && cb < COUT) ? bv4 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   if (APREG) load_ap();
@@ -266,21 +273,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
 
   const int oy0 = band * a.band_rows, oy1 = min(H_OUT, oy0 + a.band_rows);
   __syncthreads();  // LDS zeroed
-
-  // prologue: rows oy0*S-1 .. oy0*S+1-S are expanded here, the remaining S rows of the first window in the loop
-#pragma unroll
-  for (int i = 0; i < 3 - S; ++i) {
-    u32x4 x0[NPTI];
-    load_x(oy0 * S - 1 + i, x0);
-    expand_row(oy0 * S - 1 + i, x0);
-  }
-  // block-input operands are requested TWO output rows ahead (two register sets, the row loop is unrolled by two): with
-  // the depthwise off the vector unit a row takes less time than a load that misses the L2
   u32x4 xa[S][NPTI], xb[S][NPTI];
-#pragma unroll
-  for (int i = 0; i < S; ++i) load_x(oy0 * S + 2 - S + i, xa[i]);
-#pragma unroll
-  for (int i = 0; i < S; ++i) load_x((oy0 + 1) * S + 2 - S + i, xb[i]);  // (rows past the band / image: zero-byte descriptors)
 
   // depthwise B operand of lane (n, q): pixel slot S*n (+ kx), channel half q & 1; the tap of the pair by q >> 1
   const int lane_dw = (int)(reinterpret_cast<unsigned char*>(es) - smem_raw) + (S * n * ELD + 8 * (q & 1)) * 2;
@@ -359,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tile = w + NW * t;
-      if (tile >= TT) continue;
+      if (NW * t + NW - 1 >= TT && tile >= TT) continue;  // compile-time except for the last t of some waves
       const int pt = tile / NCT;
       f32x4 c = {bpj[t].x, bpj[t].y, bpj[t].z, bpj[t].w};
       const unsigned char* brow = drow + ((16 * pt + n) * DLD + 8 * q) * 2;
@@ -383,9 +376,28 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
     IRB2_TICK(3);
   };
 #pragma unroll 1
-  for (int oy = oy0; oy < oy1; oy += 2) {
-    row(oy, xa, 0);
-    if (oy + 1 < oy1) row(oy + 1, xb, 1);
+  for (int b = blockIdx.y; b < a.B; b += gridDim.y) {
+    xin = xin0 + (size_t)b * H_IN * H_IN * CIN;
+    yout = yout0 + (size_t)b * H_OUT * H_OUT * COUT;
+    // prologue: rows oy0*S-1 .. oy0*S+1-S are expanded here, the remaining S rows of the first window in the loop
+#pragma unroll
+    for (int i = 0; i < 3 - S; ++i) {
+      u32x4 x0[NPTI];
+      load_x(oy0 * S - 1 + i, x0);
+      expand_row(oy0 * S - 1 + i, x0);
+    }
+    // block-input operands are requested TWO output rows ahead (two register sets, the row loop is unrolled by two):
+    // with the depthwise off the vector unit a row takes less time than a load that misses the L2
+#pragma unroll
+    for (int i = 0; i < S; ++i) load_x(oy0 * S + 2 - S + i, xa[i]);
+#pragma unroll
+    for (int i = 0; i < S; ++i) load_x((oy0 + 1) * S + 2 - S + i, xb[i]);  // (rows past the band / image: zero-byte descriptors)
+#pragma unroll 1
+    for (int oy = oy0; oy < oy1; oy += 2) {
+      row(oy, xa, 0);
+      if (oy + 1 < oy1) row(oy + 1, xb, 1);
+    }
+    lds_barrier();  // the last row's projection has read ds before the next observation's depthwise writes it
   }
 #ifdef RIP_IRB2_TICKS
   if (lane == 0) {
@@ -413,7 +425,11 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(bands, B, kc), dim3(NW * 64), SH::LDS_BYTES, s, a);
+  // OCC workgroups per CU stay resident and walk the observations (the wave constants are built once per workgroup)
+  int wgy = (OCC * device_cu_count() + bands * kc - 1) / (bands * kc);
+  if (wgy > B) wgy = B;
+  if (wgy < 1) wgy = 1;
+  hipLaunchKernelGGL(kern, dim3(bands, wgy, kc), dim3(NW * 64), SH::LDS_BYTES, s, a);
 #ifdef RIP_IRB2_TICKS
   {
     unsigned long long t[8];
