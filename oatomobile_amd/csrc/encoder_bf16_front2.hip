@@ -160,11 +160,14 @@ __global__ __launch_bounds__(256, OCC) void front2_bf16_kernel(Front2Args a) {
     for (int j = 0; j < 8; ++j) {
       const int kk = 8 * q + j;
       const int c = kk / 9, t = kk % 9;
-      float wv_ = 0.f;
-      if (kk < 18) wv_ = W[a.ws_off + (size_t)(t * 2 + c) * 32 + oc];
-      unsigned s = split_bf16(wv_);
-      if (kk == 18) s = split_bf16(W[a.bs_off + oc]) & 0xffffu;           // bias hi (the lo operand holds nothing here)
-      if (kk == 19) s = split_bf16(W[a.bs_off + oc]) >> 16;              // bias lo, as a "hi" entry against B = 1.0
+      // unconditional loads (clamped index) + selects: behind a branch every one of these ~50 constants is waited for on
+      // its own, together with the input band requested above — that many memory round trips in sequence at the start of
+      // every workgroup
+      const float wload = W[a.ws_off + (size_t)((kk < 18 ? t : 0) * 2 + (kk < 18 ? c : 0)) * 32 + oc];
+      const unsigned bsp = split_bf16(W[a.bs_off + oc]);
+      unsigned s = split_bf16(kk < 18 ? wload : 0.f);
+      s = kk == 18 ? (bsp & 0xffffu) : s;  // bias hi (the lo operand holds nothing here)
+      s = kk == 19 ? (bsp >> 16) : s;      // bias lo, as a "hi" entry against B = 1.0
       hw[j] = s & 0xffffu;
       lw[j] = kk < 18 ? s >> 16 : 0u;
     }
@@ -187,11 +190,8 @@ __global__ __launch_bounds__(256, OCC) void front2_bf16_kernel(Front2Args a) {
       const int half = q >> 1;
       const int tap = kb < 4 ? 2 * kb + half : (kb == 4 ? 8 : 2 * (kb - 5) + half);
       const bool lo = kb > 4 || (kb == 4 && half == 1);
-      unsigned v16 = 0;
-      if (diag) {
-        const unsigned s = split_bf16(W[a.wd_off + (size_t)tap * 32 + 16 * g + n]);
-        v16 = lo ? (s >> 16) : (s & 0xffffu);
-      }
+      const unsigned s = split_bf16(W[a.wd_off + (size_t)tap * 32 + 16 * g + n]);
+      const unsigned v16 = diag ? (lo ? (s >> 16) : (s & 0xffffu)) : 0u;
       const unsigned dw = v16 << ((pos & 1) * 16);
       ad[g][kb] = u32x4{(pos >> 1) == 0 ? dw : 0u, (pos >> 1) == 1 ? dw : 0u, (pos >> 1) == 2 ? dw : 0u, (pos >> 1) == 3 ? dw : 0u};
     }
