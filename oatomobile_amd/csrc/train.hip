@@ -789,6 +789,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dpost, const float* __r
 // act_bwd_kernel + colstats_kernel<STAT_BWD> in one pass (C % 4 == 0): g = dpost masked by the ReLU6 derivative is
 // written AND reduced (sum g, sum g xhat) where it is produced; same thread <-> rows mapping and accumulation order as
 // colstats_kernel.
+template <bool RELU6, bool DRES>  // compile-time: a run-time branch around the `post` load makes every load of the row loop wait
 __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restrict__ dpost, const float* __restrict__ post,
                                                             const float* __restrict__ pre, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ g,
@@ -818,9 +819,9 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
     for (size_t r = r0 + rl; r < r1; r += RL) {
       const size_t e = r * C4 + c4;
       const float4 d = d4[e];
-      if (dres != nullptr) r4[e] = d;  // the residual branch is the FIRST writer of the block input's gradient
+      if (DRES) r4[e] = d;  // the residual branch is the FIRST writer of the block input's gradient
       float4 v = d;
-      if (relu6) {
+      if (RELU6) {
         const float4 y = p4[e];
         v.x = (y.x > 0.f && y.x < 6.f) ? d.x : 0.f;
         v.y = (y.y > 0.f && y.y < 6.f) ? d.y : 0.f;
@@ -1323,8 +1324,14 @@ hipError_t trainer_step(Trainer* t, float* params, float* grads, const float* vi
     const dim3 sgrid = stat_grid(M, l.cout, &rpb, &ld);
     // NOTE: for residual layers `post` holds bn + res; they carry no ReLU6, so the mask is not needed there
     if ((l.cout & 3) == 0) {
-      hipLaunchKernelGGL(act_bwd_stats_kernel, sgrid, dim3(256), 2 * l.cout * sizeof(float), s, A(t->dpost, i),
-                         A(t->post, i), A(t->pre, i), mean, invstd, t->gbuf, dres, t->partial, ld, M, l.cout, rpb, l.relu6);
+#define ABS_GO(R6_, DR_)                                                                                                  \
+  hipLaunchKernelGGL((act_bwd_stats_kernel<R6_, DR_>), sgrid, dim3(256), 2 * l.cout * sizeof(float), s, A(t->dpost, i), \
+                     A(t->post, i), A(t->pre, i), mean, invstd, t->gbuf, dres, t->partial, ld, M, l.cout, rpb, l.relu6)
+      if (l.relu6 && dres != nullptr) ABS_GO(true, true);
+      else if (l.relu6) ABS_GO(true, false);
+      else if (dres != nullptr) ABS_GO(false, true);
+      else ABS_GO(false, false);
+#undef ABS_GO
     } else {
       hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, A(t->dpost, i), A(t->post, i), t->gbuf, dres,
                          total, l.relu6);
