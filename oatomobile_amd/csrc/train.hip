@@ -41,6 +41,16 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int FEAT = 128, LAST_C = 1280, VEC = 5, HID = 64;
+// a buffer descriptor over [base, base + bytes): loads at a byte offset beyond it return zeros, with no branch
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_srd(const void* base, size_t bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes)), 0x00020000);
+}
+constexpr int GEMM_OOB = 0x7ffffff0;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 // x[c] + x[c + 16] + x[c + 32] + x[c + 48] in every one of the four lanes (two swaps on the VALU, no LDS)
 __device__ __forceinline__ float q4_sum(float x) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -80,6 +90,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // a group = 4 consecutive elements along the stored matrix's contiguous dimension
+  const __amdgpu_buffer_rsrc_t asrd = gemm_srd(A, ((size_t)((TA ? K : M) - 1) * lda + (TA ? M : K)) * sizeof(float));
+  const __amdgpu_buffer_rsrc_t bsrd = gemm_srd(B, ((size_t)((TB ? N : K) - 1) * ldb + (TB ? K : N)) * sizeof(float));
   float4 ra[A4], rb[B4];
   auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -90,7 +102,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const float* p = TA ? A + (size_t)gk * lda + gm : A + (size_t)gm * lda + gk;
       if (VEC) {
-        if (TA ? (gk < ke && gm < M) : (gm < M && gk < ke)) v = *reinterpret_cast<const float4*>(p);
+        // buffer load with an out-of-range offset for groups outside the matrix / the K chunk: zeros, and no branch
+        // (a load behind a branch is waited for at the merge: this prefetch was one memory round trip per group)
+        const bool ok = gm < M && gk < ke;
+        const int off = ok ? (int)(((size_t)(TA ? gk : gm) * lda + (TA ? gm : gk)) * sizeof(float)) : GEMM_OOB;
+        const u32x4_t w4 = __builtin_amdgcn_raw_buffer_load_b128(asrd, off, 0, 0);
+        v = make_float4(__uint_as_float(w4.x), __uint_as_float(w4.y), __uint_as_float(w4.z), __uint_as_float(w4.w));
       } else {
         const int st = TA ? 1 : 1;  // both walk the contiguous dimension
         float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -112,7 +129,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         const int gn = n0 + nn, gk = k0 + k;
         const float* p = TB ? B + (size_t)gn * ldb + gk : B + (size_t)gk * ldb + gn;
         if (VEC) {
-          if (TB ? (gn < N && gk < ke) : (gk < ke && gn < N)) v = *reinterpret_cast<const float4*>(p);
+          const bool ok = gn < N && gk < ke;
+          const int off = ok ? (int)(((size_t)(TB ? gn : gk) * ldb + (TB ? gk : gn)) * sizeof(float)) : GEMM_OOB;
+          const u32x4_t w4 = __builtin_amdgcn_raw_buffer_load_b128(bsrd, off, 0, 0);
+          v = make_float4(__uint_as_float(w4.x), __uint_as_float(w4.y), __uint_as_float(w4.z), __uint_as_float(w4.w));
         } else {
           float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
