@@ -368,13 +368,25 @@ __device__ __forceinline__ void pw_body(const float* __restrict__ in, const floa
    for (int u = 0; u < UNROLL; ++u) {
     const int kc = kc0 + 16 * u;
     const bool kval = kc + 4 * q < kend;  // Cin is a multiple of 8: a lane's float4 is all-valid or all-pad
+    // every load is unconditional (chunk 0 of the row for a lane past the K range — Cin >= 16, so in bounds — then a
+    // select): a load behind a branch is waited for at the merge, which made the CT + PT loads of a chunk that many
+    // memory round trips in sequence instead of one
+    const int kcl = kval ? kc : 0;
     float4 av[CT], bv[PT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-      av[ct] = (kval && aval[ct]) ? *reinterpret_cast<const float4*>(arow[ct] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const float4*>(arow[ct] + kcl);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const float4*>(brow[pt] + kcl);
+    // (component-wise selects: a ternary on the float4 STRUCT is lowered through a stack slot the optimiser does not
+    // always remove — the operand arrays went to scratch that way)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const bool on = kval && aval[ct];
+      av[ct] = make_float4(on ? av[ct].x : 0.f, on ? av[ct].y : 0.f, on ? av[ct].z : 0.f, on ? av[ct].w : 0.f);
+    }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
-      bv[pt] = kval ? *reinterpret_cast<const float4*>(brow[pt] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[pt] = make_float4(kval ? bv[pt].x : 0.f, kval ? bv[pt].y : 0.f, kval ? bv[pt].z : 0.f, kval ? bv[pt].w : 0.f);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -417,12 +429,31 @@ __device__ __forceinline__ void pw_body(const float* __restrict__ in, const floa
         }
       }
   }
-  // C/D layout of the 16x16 MFMA: col = lane & 15 (pixel), row = 4*(lane >> 4) + reg (channel)
+  // C/D layout of the 16x16 MFMA: col = lane & 15 (pixel), row = 4*(lane >> 4) + reg (channel).
+  // The epilogue's operands (bias, residual) are requested here, ALL of them before any is used and none behind a
+  // per-lane branch (clamped addresses): inside the store loop each was waited for on its own.
+  float4 eb[CT], er[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + 4 * q;
+    eb[ct] = HOIST ? hb[ct] : *reinterpret_cast<const float4*>(bias + (co < Cout ? co : Cout - 4));
+  }
+  if (!HOIST && R != nullptr) {  // workgroup-uniform
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = (ctile0 + ct) * 16 + 4 * q;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = (ptile0 + pt) * 16 + n;
+        er[ct][pt] = *reinterpret_cast<const float4*>(R + (size_t)(p < M ? p : M - 1) * Cout + (co < Cout ? co : Cout - 4));
+      }
+    }
+  }
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int co = (ctile0 + ct) * 16 + 4 * q;
     if (co < Cout) {
-      const float4 bb = HOIST ? hb[ct] : *reinterpret_cast<const float4*>(bias + co);
+      const float4 bb = eb[ct];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
@@ -443,7 +474,7 @@ __device__ __forceinline__ void pw_body(const float* __restrict__ in, const floa
           float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                  acc[ct][pt][3] + bb.w);
           if (R != nullptr) {
-            const float4 r = HOIST ? hr[ct][pt] : *reinterpret_cast<const float4*>(R + (size_t)p * Cout + co);
+            const float4 r = HOIST ? hr[ct][pt] : er[ct][pt];
             v.x += r.x;
             v.y += r.y;
             v.z += r.z;
