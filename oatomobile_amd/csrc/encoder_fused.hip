@@ -69,9 +69,12 @@ __global__ __launch_bounds__(NWAVES * 64) void irb_kernel(IrbArgs a) {
     for (int e = tid; e < IP * C4; e += NWAVES * 64) {
       const int c4 = e % C4, ip = e / C4;
       const int iy = iy0 + ip / IW, ix = ip % IW - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < H_in && ix >= 0 && ix < H_in && c4 * 4 < CIN)
-        v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * H_in + ix) * CIN + c4 * 4);
+      // unconditional load from a clamped address + component-wise select (a load behind a branch is waited for at the
+      // merge: one memory round trip per trip of this loop; a ternary on the float4 struct goes through scratch)
+      const bool ok = iy >= 0 && iy < H_in && ix >= 0 && ix < H_in && c4 * 4 < CIN;
+      const int iyc = min(max(iy, 0), H_in - 1), ixc = min(max(ix, 0), H_in - 1), cc = min(c4 * 4, CIN - 4);
+      const float4 ld = *reinterpret_cast<const float4*>(xin + ((size_t)iyc * H_in + ixc) * CIN + cc);
+      const float4 v = make_float4(ok ? ld.x : 0.f, ok ? ld.y : 0.f, ok ? ld.z : 0.f, ok ? ld.w : 0.f);
       *reinterpret_cast<float4*>(xs + (size_t)ip * XLD + c4 * 4) = v;
     }
   }
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(NWAVES * 64) void irb_kernel(IrbArgs a) {
 #pragma unroll
         for (int S = 0; S < NS; ++S) {
           const int c = 16 * S + 4 * q;
-          areg[S] = (c < CIN && h_row < HID)
-                        ? *reinterpret_cast<const float4*>(W + a.we_off + (size_t)h_row * CIN + c)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+          const bool ok = c < CIN && h_row < HID;
+          const float4 ld = *reinterpret_cast<const float4*>(W + a.we_off + (size_t)min(h_row, HID - 1) * CIN + min(c, CIN - 4));
+          areg[S] = make_float4(ok ? ld.x : 0.f, ok ? ld.y : 0.f, ok ? ld.z : 0.f, ok ? ld.w : 0.f);
         }
         const int hb = hc0 + 16 * ht + 4 * q;  // this lane's 4 output channels
-        const float4 bias = hb < HID ? *reinterpret_cast<const float4*>(W + a.be_off + hb)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bld = *reinterpret_cast<const float4*>(W + a.be_off + min(hb, HID - 4));
+        const float4 bias = make_float4(hb < HID ? bld.x : 0.f, hb < HID ? bld.y : 0.f, hb < HID ? bld.z : 0.f, hb < HID ? bld.w : 0.f);
         for (int pt = wave; pt < n_pt; pt += NWAVES) {
           const int p = 16 * pt + n;
           const float* xr = xs + (size_t)min(p, IP - 1) * XLD + 4 * q;
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(NWAVES * 64) void irb_kernel(IrbArgs a) {
         f32x4 c4 = acc[i];
 #pragma unroll
         for (int S = 0; S < HC / 16; ++S) {
-          float4 av = *reinterpret_cast<const float4*>(wr + 16 * S);
-          if (co >= COUT) av = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 avl = *reinterpret_cast<const float4*>(wr + 16 * S);
+          const bool con = co < COUT;
+          const float4 av = make_float4(con ? avl.x : 0.f, con ? avl.y : 0.f, con ? avl.z : 0.f, con ? avl.w : 0.f);
           const float4 bv = *reinterpret_cast<const float4*>(dr + 16 * S);
           c4 = mfma4(av.x, bv.x, c4);
           c4 = mfma4(av.y, bv.y, c4);
@@ -186,6 +190,17 @@ __global__ __launch_bounds__(NWAVES * 64) void irb_kernel(IrbArgs a) {
 
   // ---- epilogue: + bias (+ residual) -> y (NHWC float4) ----
   float* yout = a.y + (size_t)(k * a.B + b) * a.H_out * W_out * COUT;
+  // bias / residual operands of every tile first, from clamped addresses and with no per-lane branch around them
+  float4 ebp[MAXT], eres[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t = min(wave + NWAVES * i, TT - 1);
+    const int ct = t / n_ot, ot = t - ct * n_ot;
+    const int o = min(16 * ot + n, MO - 1), co = min(16 * ct + 4 * q, COUT - 4);
+    ebp[i] = *reinterpret_cast<const float4*>(W + a.bp_off + co);
+    const size_t pix = (size_t)(oy0 + o / W_out) * W_out + o % W_out;
+    if (a.residual) eres[i] = *reinterpret_cast<const float4*>(xin + pix * CIN + co);  // uniform branch
+  }
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t = wave + NWAVES * i;
@@ -193,11 +208,11 @@ __global__ __launch_bounds__(NWAVES * 64) void irb_kernel(IrbArgs a) {
       const int ct = t / n_ot, ot = t - ct * n_ot;
       const int o = 16 * ot + n, co = 16 * ct + 4 * q;
       if (o < MO && co < COUT) {
-        const float4 bp = *reinterpret_cast<const float4*>(W + a.bp_off + co);
+        const float4 bp = ebp[i];
         const size_t pix = (size_t)(oy0 + o / W_out) * W_out + o % W_out;
         float4 v = make_float4(acc[i][0] + bp.x, acc[i][1] + bp.y, acc[i][2] + bp.z, acc[i][3] + bp.w);
         if (a.residual) {  // stride 1, CIN == COUT: same pixel of the block input
-          const float4 r = *reinterpret_cast<const float4*>(xin + pix * CIN + co);
+          const float4 r = eres[i];
           v.x += r.x;
           v.y += r.y;
           v.z += r.z;
