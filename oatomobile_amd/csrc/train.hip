@@ -205,7 +205,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     __syncthreads();
     buf ^= 1;
   }
-  // result tile: lane (n, q), register r <-> row 4 q + r, column n
+  // result tile: lane (n, q), register r <-> row 4 q + r, column n.  `accumulate` (no split): the old values are added
+  // in a first pass of unconditional loads from clamped addresses — inside the per-element branch below each load was
+  // waited for on its own (16 memory round trips in sequence per thread)
+  if (accumulate && gridDim.z == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gm = m0 + wm + i * 16 + 4 * q + r, gn = n0 + wn + j * 16 + n;
+          acc[i][j][r] += C[(size_t)(gm < M ? gm : M - 1) * ldc + (gn < N ? gn : N - 1)];
+        }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -217,8 +230,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
           float* p = C + (size_t)gm * ldc + gn;
           if (gridDim.z > 1)
             atomicAdd(p, acc[i][j][r]);
-          else if (accumulate)
-            *p += acc[i][j][r];
           else
             *p = acc[i][j][r];
         }
@@ -947,7 +958,8 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(float* __restrict_
 #pragma unroll 8
     for (int r = rg; r < rows; r += 8) {
       const size_t e = (size_t)r * ld + c;
-      const float v = y[e] > 0.f ? d[e] : 0.f;
+      const float dv = d[e];  // (loaded whether or not it is kept: no branch around the load)
+      const float v = y[e] > 0.f ? dv : 0.f;
       d[e] = v;
       s += v;
     }
