@@ -157,18 +157,27 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const bf16_t* __restrict__
   }
   constexpr int COLS = (R - 1) * STRIDE + 3;  // input columns the run touches
   const int ix0 = ox0 * STRIDE - 1;
+  // all 3 x COLS loads first, from clamped addresses (a tap off the image is multiplied as zero: acc + 0 * w == acc, the
+  // sums of the skipping form): a branch per tap made every load wait at the merge — nine memory round trips in sequence
+  uint4 v[3][COLS];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iyc = min(max(oy * STRIDE - 1 + ky, 0), Hin - 1);
+    const bf16_t* rowp = ip + (size_t)iyc * Hin * C;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) v[ky][j] = *reinterpret_cast<const uint4*>(rowp + (size_t)min(max(ix0 + j, 0), Hin - 1) * C);
+  }
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = oy * STRIDE - 1 + ky;
-    if (iy < 0 || iy >= Hin) continue;
-    const bf16_t* rowp = ip + (size_t)iy * Hin * C;
+    const bool yok = iy >= 0 && iy < Hin;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
       const int ix = ix0 + j;
-      if (ix < 0 || ix >= Hin) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(rowp + (size_t)ix * C);
-      const float f[8] = {bf2f(v.x & 0xffffu), bf2f(v.x >> 16), bf2f(v.y & 0xffffu), bf2f(v.y >> 16),
-                          bf2f(v.z & 0xffffu), bf2f(v.z >> 16), bf2f(v.w & 0xffffu), bf2f(v.w >> 16)};
+      const bool ok = yok && ix >= 0 && ix < Hin;
+      const unsigned vx = ok ? v[ky][j].x : 0u, vy = ok ? v[ky][j].y : 0u, vz = ok ? v[ky][j].z : 0u, vw = ok ? v[ky][j].w : 0u;
+      const float f[8] = {bf2f(vx & 0xffffu), bf2f(vx >> 16), bf2f(vy & 0xffffu), bf2f(vy >> 16),
+                          bf2f(vz & 0xffffu), bf2f(vz >> 16), bf2f(vw & 0xffffu), bf2f(vw >> 16)};
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int kx = j - r * STRIDE;  // compile-time after unrolling
@@ -413,12 +422,22 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
     for (int u = 0; u < UNROLL; ++u) {
       const int kc = kc0 + 32 * u;
       const bool kval = kc + 8 * q < kend;  // Cin is a multiple of 8: a lane's 8 values are all-valid or all-pad
+      // unconditional loads (a lane past the K range reads the first group of its row), component-wise selects: a load
+      // behind a branch is waited for on its own at the merge, and a ternary on the uint4 STRUCT goes through scratch
+      const int koff = kval ? kc : -8 * q;
       uint4 av[CT], bv[PT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-        av[ct] = (kval && aval[ct]) ? *reinterpret_cast<const uint4*>(arow[ct] + kc) : zero;
+      for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const uint4*>(arow[ct] + koff);
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) bv[pt] = kval ? *reinterpret_cast<const uint4*>(brow[pt] + kc) : zero;
+      for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const uint4*>(brow[pt] + koff);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const bool on = kval && aval[ct];
+        av[ct] = make_uint4(on ? av[ct].x : 0u, on ? av[ct].y : 0u, on ? av[ct].z : 0u, on ? av[ct].w : 0u);
+      }
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        bv[pt] = make_uint4(kval ? bv[pt].x : 0u, kval ? bv[pt].y : 0u, kval ? bv[pt].z : 0u, kval ? bv[pt].w : 0u);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -453,6 +472,28 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
         }
       }
   }
+  // epilogue operands (bias, residual): all requested here, from clamped addresses and with no per-lane branch around
+  // them (inside the store loops each load was waited for on its own: two memory round trips per tile and launch)
+  float4 eb[CT];
+  uint2 er[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int co = (ctile0 + ct) * 16 + 4 * q;
+    eb[ct] = *reinterpret_cast<const float4*>(bias + (co < Cout ? co : Cout - 4));
+  }
+  if (R != nullptr) {  // uniform
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int co = (ctile0 + ct) * 16 + 4 * q;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = (ptile0 + pt) * 16 + n;
+        // (K-split builds: a wave finishes every KSPLIT-th tile only; the others read the first group of R, one cached line)
+        const bool mine = KSPLIT == 1 || ((ct * PT + pt) & (KSPLIT - 1)) == wave;
+        er[ct][pt] = *reinterpret_cast<const uint2*>(R + (mine ? (size_t)(p < M ? p : M - 1) * Cout + (co < Cout ? co : Cout - 4) : (size_t)0));
+      }
+    }
+  }
   if (KSPLIT == 1 && !OUT_F32) {
     // bf16 epilogue through LDS: a lane's MFMA result is 4 channels (8 bytes) of one pixel; writing that straight
     // out gives 32-byte pieces per pixel and tile.  Park the wave's [PT*16 pixels][CT*16 channels] tile in LDS and
@@ -465,14 +506,14 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
     for (int ct = 0; ct < CT; ++ct) {
       const int co = (ctile0 + ct) * 16 + 4 * q;
       const bool cval = co < Cout;
-      const float4 bb = cval ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bb = make_float4(cval ? eb[ct].x : 0.f, cval ? eb[ct].y : 0.f, cval ? eb[ct].z : 0.f, cval ? eb[ct].w : 0.f);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
         float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                acc[ct][pt][3] + bb.w);
         if (R != nullptr && cval && p < M) {
-          const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+          const uint2 r = er[ct][pt];
           v.x += bf2f(r.x & 0xffffu);
           v.y += bf2f(r.x >> 16);
           v.z += bf2f(r.y & 0xffffu);
@@ -509,7 +550,7 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
   for (int ct = 0; ct < CT; ++ct) {
     const int co = (ctile0 + ct) * 16 + 4 * q;
     if (co < Cout) {
-      const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+      const float4 bb = eb[ct];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int p = (ptile0 + pt) * 16 + n;
@@ -531,7 +572,7 @@ __global__ __launch_bounds__(256) void pw_bf16_kernel(const bf16_t* __restrict__
           float4 v = make_float4(acc[ct][pt][0] + bb.x, acc[ct][pt][1] + bb.y, acc[ct][pt][2] + bb.z,
                                  acc[ct][pt][3] + bb.w);
           if (R != nullptr) {
-            const uint2 r = *reinterpret_cast<const uint2*>(R + (size_t)p * Cout + co);
+            const uint2 r = er[ct][pt];
             v.x += bf2f(r.x & 0xffffu);
             v.y += bf2f(r.x >> 16);
             v.z += bf2f(r.y & 0xffffu);
