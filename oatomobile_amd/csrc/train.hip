@@ -630,35 +630,28 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 //   STAT_BWD      out[c] += sum g,  out[C + c] += sum g * xhat,  xhat = (y - mean[c]) * invstd[c]   (x = g, y = pre)
 constexpr int STAT_GROUPS = 16;  // 4-channel groups per block of the reduction kernels (64 channels)
 // block-level sums of the reduction kernels: sm[0 .. 4 cgl) = S1, sm[4 cgl .. 8 cgl) = S2 of the block's channel chunk
-__device__ __forceinline__ void stat_block_add(float* sm, int cgl, int gl, float4 s1, float4 s2, bool active) {
-  if (cgl == STAT_GROUPS || cgl == 8 || cgl == 4) {
-    // lanes c, c + cgl, c + 2 cgl, ... of a wave share the group: added in registers first (whole waves take part;
-    // strides 16 and 32 with permlane swaps, 4 and 8 through the bpermute crossbar)
-    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v[j] = q4_sum(v[j]);
-      if (cgl <= 8) v[j] += __shfl_xor(v[j], 8);
-      if (cgl == 4) v[j] += __shfl_xor(v[j], 4);
-    }
-    s1 = make_float4(v[0], v[1], v[2], v[3]);
-    s2 = make_float4(v[4], v[5], v[6], v[7]);
-    active = active && (int)(threadIdx.x & 63) < cgl;
+// Block-level sums of the reduction kernels, in a FIXED order: every thread parks its eight sums in LDS, then thread
+// i < 8 cgl adds the 256 / cgl row lanes of its (sum, channel) one after the other and stores the total to the block's
+// column of the partial table part[2 C][ld] (plain stores: no atomics anywhere — LDS float atomics on one address
+// serialise, global ones on a few cache lines were the whole kernel — and, given the same input, the same bits on
+// every run; the second stage adds the columns in a fixed order as well).
+__device__ __forceinline__ void stat_block_reduce(float* sall, int cgl, int gl, int rl, float4 s1, float4 s2, int chunk,
+                                                  int C, float* __restrict__ part, int ld) {
+  float4* mine = reinterpret_cast<float4*>(sall + 8 * (rl * cgl + gl));
+  const bool in_block = rl * cgl + gl < 256 && rl < 256 / cgl;  // (cgl = 6: the last four threads have no row lane)
+  if (in_block) {
+    mine[0] = s1;  // zeros for threads outside the tensor
+    mine[1] = s2;
   }
-  if (!active) return;
-  atomicAdd(&sm[4 * gl + 0], s1.x); atomicAdd(&sm[4 * gl + 1], s1.y);
-  atomicAdd(&sm[4 * gl + 2], s1.z); atomicAdd(&sm[4 * gl + 3], s1.w);
-  atomicAdd(&sm[4 * (cgl + gl) + 0], s2.x); atomicAdd(&sm[4 * (cgl + gl) + 1], s2.y);
-  atomicAdd(&sm[4 * (cgl + gl) + 2], s2.z); atomicAdd(&sm[4 * (cgl + gl) + 3], s2.w);
-}
-// a block's sums go to its own column of the partial table part[2 C][ld] (plain stores: no contended atomics, and the
-// second stage adds the columns in a fixed order: the statistics are the same bits on every run — the weight gradients
-// still end in float atomics)
-__device__ __forceinline__ void stat_block_flush(const float* sm, int cgl, int chunk, int C, float* __restrict__ part, int ld) {
-  const int w = 4 * cgl;
+  __syncthreads();
+  const int w = 4 * cgl, RL = 256 / cgl;
   for (int i = threadIdx.x; i < 2 * w; i += 256) {
-    const int c = chunk * w + (i < w ? i : i - w);
-    if (c < C) part[(size_t)((i < w ? 0 : C) + c) * ld + blockIdx.x] = sm[i];
+    const int ci = i < w ? i : i - w;  // channel inside the chunk
+    const float* col = sall + 8 * (ci >> 2) + (i < w ? 0 : 4) + (ci & 3);
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += col[8 * r * cgl];
+    const int c = chunk * w + ci;
+    if (c < C) part[(size_t)((i < w ? 0 : C) + c) * ld + blockIdx.x] = t;
   }
 }
 enum { STAT_SHIFTED = 0, STAT_BWD = 2 };
@@ -667,7 +660,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        float* __restrict__ part, int ld, size_t M, int C,
                                                        int rows_per_block) {
-  extern __shared__ float sm[];  // [2*C]
+  extern __shared__ float sm[];  // [2*C] (scalar fallback path)
+  __shared__ __attribute__((aligned(16))) float sall[256 * 8];
   for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
   __syncthreads();
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
@@ -705,9 +699,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
         }
       }
     }
-    stat_block_add(sm, cgl, gl, s1, s2, active);
-    __syncthreads();
-    stat_block_flush(sm, cgl, (int)blockIdx.y, C, part, ld);
+    stat_block_reduce(sall, cgl, gl, rl, s1, s2, (int)blockIdx.y, C, part, ld);
     return;
   } else {
     for (int c = threadIdx.x; c < C; c += 256) {  // this thread is the only writer of channel c
@@ -826,7 +818,8 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
                                                             const float* __restrict__ invstd, float* __restrict__ g,
                                                             float* __restrict__ dres, float* __restrict__ part, int ld,
                                                             size_t M, int C, int rows_per_block, int relu6) {
-  extern __shared__ float sm[];  // [2*C]
+  extern __shared__ float sm[];  // [2*C] (scalar fallback path)
+  __shared__ __attribute__((aligned(16))) float sall[256 * 8];
   for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
   __syncthreads();
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
@@ -868,9 +861,7 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
       s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
     }
   }
-  stat_block_add(sm, cgl, gl, s1, s2, active);
-  __syncthreads();
-  stat_block_flush(sm, cgl, (int)blockIdx.y, C, part, ld);
+  stat_block_reduce(sall, cgl, gl, rl, s1, s2, (int)blockIdx.y, C, part, ld);
 }
 
 // sums2 = (sum g, sum g * xhat) per channel = (dbeta, dgamma) and

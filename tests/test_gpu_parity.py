@@ -1298,6 +1298,44 @@ def test_g15_train_step_vs_reference(golden, dev):
           np.testing.assert_allclose(params[name], g[key], rtol=1e-4 if step == 0 else 2e-2, atol=2e-6 if step == 0 else 1e-3)
 
 
+def test_train_batch_statistics_are_the_same_bits_on_every_run(dev):
+  """The BatchNorm reductions of the training step are two-stage (per-block partial columns, then a fixed-order sum in
+  double: csrc/train.hip `colstats_kernel` / `stat_reduce_kernel`), not float atomics: two trainers stepping the same
+  batch from the same weights must leave bit-identical running statistics for every layer in front of the first
+  split-K convolution (at this batch size features.12's projection: K = 576 against 20 output tiles; those GEMMs add
+  their K chunks with float atomics, so from there on the INPUTS of the reductions differ in the last place) and
+  statistics / z / loss equal to rounding behind it."""
+  from oatomobile_amd import DIMTrainer
+  B = 12
+  rng = np.random.default_rng(441)
+  obs = [synth_observation(rng) for _ in range(B)]
+  ctx = ctx_tensors(obs, dev)
+  future = torch.from_numpy(np.cumsum(np.abs(rng.normal(size=(B, 4, 3))) * 2.0, axis=1).astype(np.float32))
+  y = future[..., :2] + 1e-2 * torch.from_numpy(rng.normal(size=(B, 4, 2)).astype(np.float32))
+  mask = torch.from_numpy(((rng.random((B, 1280)) >= 0.2) / 0.8).astype(np.float32))
+  results = []
+  for _ in range(2):
+    tr = DIMTrainer(hip_model(34, dev), lr=1e-3, max_batch=16, device=dev)
+    loss = tr.backward(dict(ctx, player_future=future.to(dev)), y=y, dropout_mask=mask, train=True)
+    sd = tr.state_dict()
+    stats = {k: v.cpu() for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    results.append((float(loss), tr.z.cpu().clone(), stats))
+    tr.close()
+  (l0, z0, s0), (l1, z1, s1) = results
+  assert len(s0) == 104  # 52 BatchNorm layers
+  np.testing.assert_allclose(l0, l1, rtol=1e-6)
+  np.testing.assert_allclose(z0.numpy(), z1.numpy(), rtol=1e-4, atol=1e-5)
+  exact = 0
+  for k in s0:
+    block = int(k.split("features.")[1].split(".")[0])
+    if block <= 11:
+      assert torch.equal(s0[k], s1[k]), k
+      exact += 1
+    else:
+      np.testing.assert_allclose(s0[k].numpy(), s1[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+  assert exact >= 60
+
+
 @pytest.mark.parametrize("train", [True, False])
 def test_train_backward_vs_oracle_same_kinks(dev, train):
   """The backward kernels, per element: the CPU oracle back-propagates with the ReLU6 kink decisions of the HIP forward
