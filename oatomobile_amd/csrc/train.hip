@@ -529,9 +529,7 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dpre, const float* __r
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
                                                        float* __restrict__ dw, int B, int C, int Hi, int Ho, int G, int bands) {
-  __shared__ float sm[64 * 9];
-  for (int i = threadIdx.x; i < 64 * 9; i += 256) sm[i] = 0.f;
-  __syncthreads();
+  __shared__ float sm[4][64 * 9];  // one row per wave: added in a fixed order at the end, no LDS atomics
   const int C4 = C >> 2;
   const int c4l = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int c4 = (int)blockIdx.x * 16 + c4l;
@@ -602,19 +600,20 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     acc[t].z = q4_sum(acc[t].z);
     acc[t].w = q4_sum(acc[t].w);
   }
-  if (c4 < C4 && slot % 4 == 0) {
+  if (slot % 4 == 0) {  // lanes 0..15 of each wave (zeros for a group past the tensor)
+    float* row = sm[threadIdx.x >> 6];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      atomicAdd(&sm[(4 * c4l + 0) * 9 + t], acc[t].x);
-      atomicAdd(&sm[(4 * c4l + 1) * 9 + t], acc[t].y);
-      atomicAdd(&sm[(4 * c4l + 2) * 9 + t], acc[t].z);
-      atomicAdd(&sm[(4 * c4l + 3) * 9 + t], acc[t].w);
+      row[(4 * c4l + 0) * 9 + t] = acc[t].x;
+      row[(4 * c4l + 1) * 9 + t] = acc[t].y;
+      row[(4 * c4l + 2) * 9 + t] = acc[t].z;
+      row[(4 * c4l + 3) * 9 + t] = acc[t].w;
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 9; i += 256) {
     const int ch = (int)blockIdx.x * 64 + i / 9;
-    if (ch < C) atomicAdd(&dw[(size_t)ch * 9 + i % 9], sm[i]);
+    if (ch < C) atomicAdd(&dw[(size_t)ch * 9 + i % 9], ((sm[0][i] + sm[1][i]) + sm[2][i]) + sm[3][i]);
   }
 }
 
