@@ -449,7 +449,8 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
   // bands: enough workgroups for ~3 per CU, but bands re-expand their halo rows, so keep them >= 6 rows
   int bands = (int)((768 + (long)B * kc - 1) / ((long)B * kc));
   if (const char* e = getenv("RIP_IRB_BANDS")) bands = atoi(e);  // tuning hook
-  if (bands > a.H_out / 6) bands = a.H_out / 6;
+  const int min_rows = (long)B * kc <= 16 ? 2 : 6;  // a handful of observations: a latency chain, short bands (as irb2)
+  if (bands > a.H_out / min_rows) bands = a.H_out / min_rows;
   if (bands < 1) bands = 1;
   a.band_rows = (a.H_out + bands - 1) / bands;
   bands = (a.H_out + a.band_rows - 1) / a.band_rows;
