@@ -2,6 +2,7 @@
 frame transforms, loud failure without a device."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -89,6 +90,32 @@ def test_docs_quote_the_header_and_the_tests_as_they_are():
     text = open(os.path.join(ROOT, doc)).read()
     for name in set(re.findall(r"`(test_[a-z0-9_]+)`", text)):
       assert name in defined or any(d.startswith(name.rstrip("_")) for d in defined), (doc, name)
+
+
+def test_hot_kernels_keep_their_loads_in_flight_and_use_no_scratch():
+  """Static check of the gfx950 assembly of the kernels the headline and the training step spend their time in
+  (tools/dev/scan_waits.py; DESIGN §4.2's two compiler findings): (a) no private-segment (scratch) use — a ternary on
+  HIP's float4 / uint4 STRUCT can put an operand array there —, (b) at most a handful of vector-memory loads that are
+  followed by `s_waitcnt vmcnt(0)` within eight instructions, i.e. waited for on their own: a load behind a per-lane
+  branch is, and a prologue or row loop built from such loads is that many memory round trips in sequence."""
+  sys.path.insert(0, os.path.join(ROOT, "tools", "dev"))
+  import scan_waits
+  res = scan_waits.scan({"flow_split.hip", "encoder_bf16_front2.hip", "encoder_bf16_irb2.hip", "encoder_bf16_tile.hip",
+                         "train.hip"})
+  assert res, "hipcc produced no assembly"
+  hot = {"search_split_kernelILb0ELi4E": (8, 0), "front2_bf16_kernel": (2, 0), "irb2_bf16_kernel": (2, 0),
+         "irb_tile_bf16_kernel": (6, 32),  # (the 96 -> 96 block spills 24 bytes: 250+ registers)
+         "dw_fwd_kernel": (2, 0), "dw_dgrad_kernel": (2, 0), "dw_wgrad_kernel": (3, 0), "act_bwd_stats_kernel": (2, 0),
+         "colstats_kernel": (5, 0), "gemm_f32_kernelILb0ELb1ELi64ELi64ELi32ELi2ELb1E": (2, 0),
+         "gemm_f32_kernelILb1ELb0ELi64ELi64ELi32ELi2ELb1E": (2, 0), "gemm_f32_kernelILb0ELb0ELi64ELi64ELi32ELi2ELb1E": (2, 0)}
+  seen = set()
+  for (src, kern), (alone, loads, scratch) in res.items():
+    for tag, (max_alone, max_scratch) in hot.items():
+      if tag in kern:
+        seen.add(tag)
+        assert scratch <= max_scratch, (kern, "scratch bytes", scratch)
+        assert alone <= max_alone, (kern, "%d of %d loads are waited for on their own" % (alone, loads))
+  assert seen == set(hot), set(hot) - seen
 
 
 def test_no_cpu_fallback():

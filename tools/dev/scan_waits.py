@@ -10,15 +10,19 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as G  # noqa: E402
 
 
-def main():
-  min_count = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+def scan(sources=None):
+  """{(source, kernel): (loads waited for on their own, loads, scratch bytes)} for every kernel of `sources`
+  (file names under csrc/; None = all)."""
   out = tempfile.mkdtemp(prefix="rip_asm_")
   procs = []
   for src in sorted(glob.glob(os.path.join(G.CSRC, "*.hip"))):
     name = os.path.basename(src)
+    if sources is not None and name not in sources:
+      continue
     flags = [f for f in G.FLAGS if f != "-fPIC"] + G.SOURCE_FLAGS.get(name, [])
     procs.append((name, subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-S", "--cuda-device-only", "-o",
                                          os.path.join(out, name + ".s"), src], stderr=subprocess.DEVNULL)))
+  result = {}
   for name, pr in procs:
     pr.wait()
     path = os.path.join(out, name + ".s")
@@ -53,11 +57,19 @@ def main():
       if m:
         cur = m.group(1)
       m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", l)
-      if m and cur and int(m.group(1)) > 0:
+      if m and cur:
         scratch[cur] = int(m.group(1))
     for k, (a, b) in stats.items():
-      if a >= min_count or k in scratch:
-        print("%-26s %3d of %3d loads waited for on their own, scratch %4d B  %s" % (name, a, b, scratch.get(k, 0), k[:100]))
+      if k in scratch:  # kernels only (device functions have no metadata entry)
+        result[(name, k)] = (a, b, scratch[k])
+  return result
+
+
+def main():
+  min_count = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+  for (name, k), (a, b, sc) in sorted(scan().items()):
+    if a >= min_count or sc > 0:
+      print("%-26s %3d of %3d loads waited for on their own, scratch %4d B  %s" % (name, a, b, sc, k[:100]))
 
 
 if __name__ == "__main__":
