@@ -681,21 +681,38 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     if (active) {
       const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);  // STAT_SHIFTED: the shift k[c]
       const float4 is = MODE == STAT_BWD ? *reinterpret_cast<const float4*>(invstd + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-      for (size_t r = r0 + rl; r < r1; r += RL) {
-        const float4 v = x4[r * C4 + c4];
+      // Rows in batches of four with ALL the batch's loads issued before the first use (`#pragma unroll 4` on the plain
+      // loop kept a bounds test, i.e. a branch, between the iterations: every load was waited for on its own — one row
+      // in flight per thread); the sums are taken in the same row order as before.
+      auto add_row = [&](const float4& v, const float4& yy) {
         if (MODE == STAT_SHIFTED) {
           const float4 d = make_float4(v.x - mu.x, v.y - mu.y, v.z - mu.z, v.w - mu.w);
           s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
           s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
         } else {
-          const float4 yy = y4[r * C4 + c4];
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x = fmaf(v.x, (yy.x - mu.x) * is.x, s2.x);
           s2.y = fmaf(v.y, (yy.y - mu.y) * is.y, s2.y);
           s2.z = fmaf(v.z, (yy.z - mu.z) * is.z, s2.z);
           s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
         }
+      };
+      size_t r = r0 + rl;
+      for (; r + 3 * (size_t)RL < r1; r += 4 * (size_t)RL) {
+        float4 v[4], yy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[u] = x4[(r + u * (size_t)RL) * C4 + c4];
+          if (MODE == STAT_BWD) yy[u] = y4[(r + u * (size_t)RL) * C4 + c4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add_row(v[u], yy[u]);
+      }
+      for (; r < r1; r += RL) {
+        const float4 v = x4[r * C4 + c4];
+        float4 yy = v;
+        if (MODE == STAT_BWD) yy = y4[r * C4 + c4];
+        add_row(v, yy);
       }
     }
     stat_block_reduce(sall, cgl, gl, rl, s1, s2, (int)blockIdx.y, C, part, ld);
@@ -838,26 +855,47 @@ __global__ __launch_bounds__(256) void act_bwd_stats_kernel(const float* __restr
   if (active) {
     const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
     const float4 is = *reinterpret_cast<const float4*>(invstd + 4 * c4);
-#pragma unroll 4
-    for (size_t r = r0 + rl; r < r1; r += RL) {
-      const size_t e = r * C4 + c4;
-      const float4 d = d4[e];
-      if (DRES) r4[e] = d;  // the residual branch is the FIRST writer of the block input's gradient
-      float4 v = d;
+    // rows in batches of four, all loads of a batch first (see colstats_kernel); same row order.  Native vector types for
+    // the batch (arrays of HIP's float4 STRUCT were lowered load by load, each waited for on its own)
+    const f32x4* d4v = reinterpret_cast<const f32x4*>(dpost);
+    const f32x4* p4v = reinterpret_cast<const f32x4*>(post);
+    const f32x4* y4v = reinterpret_cast<const f32x4*>(pre);
+    f32x4* g4v = reinterpret_cast<f32x4*>(g);
+    f32x4* r4v = reinterpret_cast<f32x4*>(dres);
+    auto do_row = [&](size_t e, const f32x4 d, const f32x4 y, const f32x4 yy) {
+      if (DRES) r4v[e] = d;  // the residual branch is the FIRST writer of the block input's gradient
+      f32x4 v = d;
       if (RELU6) {
-        const float4 y = p4[e];
-        v.x = (y.x > 0.f && y.x < 6.f) ? d.x : 0.f;
-        v.y = (y.y > 0.f && y.y < 6.f) ? d.y : 0.f;
-        v.z = (y.z > 0.f && y.z < 6.f) ? d.z : 0.f;
-        v.w = (y.w > 0.f && y.w < 6.f) ? d.w : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (y[j] > 0.f && y[j] < 6.f) ? d[j] : 0.f;
       }
-      g4[e] = v;
-      const float4 yy = y4[e];
-      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-      s2.x = fmaf(v.x, (yy.x - mu.x) * is.x, s2.x);
-      s2.y = fmaf(v.y, (yy.y - mu.y) * is.y, s2.y);
-      s2.z = fmaf(v.z, (yy.z - mu.z) * is.z, s2.z);
-      s2.w = fmaf(v.w, (yy.w - mu.w) * is.w, s2.w);
+      g4v[e] = v;
+      s1.x += v[0]; s1.y += v[1]; s1.z += v[2]; s1.w += v[3];
+      s2.x = fmaf(v[0], (yy[0] - mu.x) * is.x, s2.x);
+      s2.y = fmaf(v[1], (yy[1] - mu.y) * is.y, s2.y);
+      s2.z = fmaf(v[2], (yy[2] - mu.z) * is.z, s2.z);
+      s2.w = fmaf(v[3], (yy[3] - mu.w) * is.w, s2.w);
+    };
+    size_t r = r0 + rl;
+    for (; r + 3 * (size_t)RL < r1; r += 4 * (size_t)RL) {
+      f32x4 d[4], y[4], yy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t e = (r + u * (size_t)RL) * C4 + c4;
+        d[u] = d4v[e];
+        y[u] = RELU6 ? p4v[e] : d[u];
+        yy[u] = y4v[e];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from sinking the loads to their uses again
+#pragma unroll
+      for (int u = 0; u < 4; ++u) do_row((r + u * (size_t)RL) * C4 + c4, d[u], y[u], yy[u]);
+    }
+    for (; r < r1; r += RL) {
+      const size_t e = r * C4 + c4;
+      const f32x4 d = d4v[e];
+      const f32x4 y = RELU6 ? p4v[e] : d;
+      const f32x4 yy = y4v[e];
+      do_row(e, d, y, yy);
     }
   }
   stat_block_reduce(sall, cgl, gl, rl, s1, s2, (int)blockIdx.y, C, part, ld);
