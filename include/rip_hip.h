@@ -104,14 +104,21 @@ int rip_transform(const float* lidar_dev, int B, int C, int H, int W, int channe
 int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
                int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream);
 
-/* Diagnostics tap (tests: every conv layer of the encoder against the oracle, teacher-forced).  Runs model k's encoder
- * on B observations with the handle's CURRENT kernel selection up to and including conv layer `layer` (network order of
+/* Diagnostics tap (tests: every conv layer of the encoder against the oracle, teacher-forced).  Runs the encoders of
+ * models [k_begin, k_begin + k_count)
+ * on B observations with the handle's CURRENT kernel selection — the one rip_encode makes for the same (B, k_count):
+ * the bf16 selection keys on B * k_count (launch shapes, the tile blocks from 64 pairs, the row-streaming depthwise and
+ * persistent GEMM kernels of large launches), so a test of the kernels a K-model call ships must tap with that k_count —
+ * up to and including conv layer `layer` (network order of
  * torchvision's `features`: 0 = features.0, then [expand,] depthwise, project of features.1..17, 51 = features.18 — the
  * reference builds it at torch/networks/perception.py:36-51) and writes that layer's output as fp32:
- * `dst_dev` [B][H][W][C] (NHWC; bf16 activations are widened exactly), or [B][1280] for layer 51, whose 4x4 average
+ * `dst_dev` [k_count][B][H][W][C] (NHWC; bf16 activations are widened exactly), or [k_count][B][1280] for layer 51, whose 4x4 average
  * pool is part of its epilogue.  `dst_numel` must be exactly that size.  Overwrites the handle's activation workspace;
  * z is not produced.  RIP_EINVAL when the layer's output never reaches memory under the current
  * RIP_OPT_ENCODER_FUSED setting (an interior layer of a fused block). */
+int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin, int k_count, int enc_dtype, int layer,
+                     float* dst_dev, size_t dst_numel, rip_stream_t stream);
+/* The same for ONE model: rip_encode_tap_k(h, visual, B, k, 1, ...). */
 int rip_encode_tap(rip_handle* h, const float* visual_dev, int B, int k, int enc_dtype, int layer, float* dst_dev,
                    size_t dst_numel, rip_stream_t stream);
 
@@ -319,10 +326,22 @@ int rip_train_num_layers(const rip_trainer* t);
  *     ignored where that does not hold); every workgroup re-checks its placement and every barrier wait is bounded
  *     (20 ms) — see rip_encoder_status.
  *   RIP_OPT_DEBUG_ENCODER_FAULT (tests only): value 1 / 2 raises the one-launch encoder's failure word as its kernel
- *     would after a placement miss / barrier timeout (RIP_ESTATE unless RIP_OPT_ENCODER_MEGA = 1 set the protocol up). */
+ *     would after a placement miss / barrier timeout (RIP_ESTATE unless RIP_OPT_ENCODER_MEGA = 1 set the protocol up).
+ *   RIP_OPT_ENCODER_VARIANT (development / tests; default 0 = what ships): bit mask of alternative bf16 encoder
+ *     kernels kept for A/B runs — 1: features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit),
+ *     2: stem + features.1 on round 3's front kernel, 4: the matrix-core depthwise kernel on features.5-7 as well.
+ *     Same arithmetic definition; the teacher-forced block tests run every setting.
+ *   RIP_OPT_KERNEL_LOG (tests; default 0): 1 = every rip_encode / rip_encode_raw* / rip_encode_tap* call records the
+ *     encoder kernels it launches (name, template arguments, grid) — read with rip_kernel_log. */
 enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2, RIP_OPT_ENCODER_MEGA = 3,
-       RIP_OPT_DEBUG_ENCODER_FAULT = 4 };
+       RIP_OPT_DEBUG_ENCODER_FAULT = 4, RIP_OPT_ENCODER_VARIANT = 5, RIP_OPT_KERNEL_LOG = 6 };
 int rip_set_option(rip_handle* h, int option, int value);
+
+/* The kernel-selection log of the handle's last encode / tap call under RIP_OPT_KERNEL_LOG = 1: one line per launch,
+ * "kernel<template arguments> grid=(x,y,z) block=n".  Copies at most cap - 1 bytes + a terminating 0 into buf (buf may
+ * be NULL) and returns the full length.  The tests assert with it that a parity case ran the kernels the headline
+ * launch shape (B = 512, k_count = 4) selects. */
+int rip_kernel_log(const rip_handle* h, char* buf, size_t cap);
 
 /* 0, or non-zero once a one-launch encoder call (RIP_OPT_ENCODER_MEGA) found a workgroup off its XCD (1) or gave up
  * waiting at a layer barrier (2): the z of THAT call is invalid.  Read it after synchronising the stream of the call

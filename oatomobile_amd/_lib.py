@@ -22,6 +22,8 @@ SIGNATURES = [
     ("rip_transform", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("rip_encode", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("rip_encode_tap", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    ("rip_encode_tap_k", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    ("rip_kernel_log", c_int, [c_void_p, c_char_p, c_size_t]),
     ("rip_encode_raw", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("rip_encode_raw_u8", c_int,
@@ -76,14 +78,19 @@ SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float,
       c_void_p]),
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ALGORITHMS = {"WCM": 0, "MA": 1, "BCM": 2}
 ENC_DTYPES = {"fp32": 0, "bf16": 1}
 OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED, OPT_SEARCH_REGROUP, OPT_ENCODER_MEGA, OPT_DEBUG_ENCODER_FAULT = 0, 1, 2, 3, 4
+OPT_ENCODER_VARIANT, OPT_KERNEL_LOG = 5, 6
+ENC_VAR_IRB_ROUND3, ENC_VAR_FRONT_ROUND3, ENC_VAR_IRB2_ALL = 1, 2, 4
 SEARCH_KERNELS = {"auto": 0, "chain": 1, "mfma": 2, "phase": 3, "split": 4}
 
 _lib = None
+
+
+RIP_OK, RIP_EINVAL, RIP_EHIP, RIP_ESTATE = 0, -1, -2, -3  # include/rip_hip.h
 
 
 class RipError(RuntimeError):
@@ -172,6 +179,14 @@ class Handle:
 
   def set_option(self, option: int, value: int) -> None:
     check(self._lib.rip_set_option(self._h, option, value))
+
+  def kernel_log(self) -> list:
+    """The encoder kernels the handle's last encode / tap call launched (after `set_option(OPT_KERNEL_LOG, 1)`), one
+    "kernel<template arguments> grid=(x,y,z) block=n" string per launch."""
+    n = self._lib.rip_kernel_log(self._h, None, 0)
+    buf = ctypes.create_string_buffer(n + 1)
+    self._lib.rip_kernel_log(self._h, buf, n + 1)
+    return [l for l in buf.value.decode().split("\n") if l]
 
   def close(self) -> None:
     if self._h:

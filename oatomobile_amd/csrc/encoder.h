@@ -3,9 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
 #include <vector>
 
 namespace rip {
+
+// Kernel-selection log (rip_kernel_log, option RIP_OPT_KERNEL_LOG): while a log is installed for the calling thread,
+// every encoder launch site appends one line "kernel<template arguments> grid=(x,y,z) block=n".  The tests use it to
+// assert that a parity case really ran the kernels a given launch shape selects (the selection keys on B * k_count).
+struct KernelLog {
+  std::string text;
+};
+void kernel_log_install(KernelLog* log);  // nullptr = off (default); thread-local
+bool kernel_log_active();
+void note_kernel(dim3 grid, dim3 block, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+
+// Development / test selections of the bf16 encoder (option RIP_OPT_ENCODER_VARIANT, a bit mask; 0 = what ships):
+enum {
+  ENC_VAR_IRB_ROUND3 = 1,    // features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit)
+  ENC_VAR_FRONT_ROUND3 = 2,  // stem + features.1 on round 3's front kernel
+  ENC_VAR_IRB2_ALL = 4,      // the matrix-core depthwise kernel on features.5-7 as well
+};
 
 // Workgroup barrier for kernels whose waves talk to each other through LDS only.  `__syncthreads()` is a workgroup-scope
 // release / acquire fence over ALL address spaces: the compiler puts `s_waitcnt vmcnt(0)` in front of the s_barrier, so
@@ -106,7 +124,7 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
 //   supports) run as one row-streaming kernel each (encoder_bf16_irb.hip); -1 = choose by batch.
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
-                               float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap = nullptr);
+                               float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap = nullptr, int variant = 0);
 
 bool irb_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
 hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
@@ -114,7 +132,7 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
                            const unsigned short* x, unsigned short* y, hipStream_t s);
 
 // round 4: the same blocks with the depthwise on the matrix cores as well (encoder_bf16_irb2.hip)
-bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
+bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, bool everywhere = false);
 hipError_t launch_irb2_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                             const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
                             const unsigned short* x, unsigned short* y, hipStream_t s);

@@ -13,9 +13,26 @@
 
 #include <mutex>
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <cstring>
 
 namespace rip {
+
+// ---- kernel-selection log (encoder.h) ----
+static thread_local KernelLog* g_kernel_log = nullptr;
+void kernel_log_install(KernelLog* log) { g_kernel_log = log; }
+bool kernel_log_active() { return g_kernel_log != nullptr; }
+void note_kernel(dim3 grid, dim3 block, const char* fmt, ...) {
+  if (g_kernel_log == nullptr) return;
+  char name[256], line[320];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(name, sizeof(name), fmt, ap);
+  va_end(ap);
+  snprintf(line, sizeof(line), "%s grid=(%u,%u,%u) block=%u\n", name, grid.x, grid.y, grid.z, block.x);
+  g_kernel_log->text += line;
+}
 
 namespace {
 
@@ -1205,6 +1222,11 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
   const size_t ms = plan.blob_floats;
   // classifier logits go to `feat` if the caller wants them, else to scratch
   float* feat_buf = feat != nullptr ? feat : scratch;
+  if (hw == 1 && B >= 16)
+    note_kernel(dim3((B + 63) / 64, kc, FEAT / 16), dim3(256), "cls_mfma_kernel");
+  else
+    note_kernel(dim3(B, kc, FEAT / CLS_GROUP), dim3(256), "cls_kernel");
+  note_kernel(dim3(B, kc), dim3(64), "merger_kernel");
   if (hw == 1 && B >= 16)
     hipLaunchKernelGGL(cls_mfma_kernel, dim3((B + 63) / 64, kc, FEAT / 16), dim3(256), 0, s, act_last, enc_w, ms, k0,
                        plan.cls_w_off, plan.cls_b_off, B, feat_buf);

@@ -705,6 +705,7 @@ void launch_stream(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, s
   if (gpw < 1) gpw = 1;
   if (gpw > 16) gpw = 16;
   const dim3 grid((n_groups + 4 * gpw - 1) / (4 * gpw), cgroups, kc);
+  note_kernel(grid, dim3(256), "pw_stream_bf16_kernel<%d>", CT);
   hipLaunchKernelGGL((pw_stream_bf16_kernel<CT>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off, l.b_off, res,
                      reinterpret_cast<bf16_t*>(dst), M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, (size_t)M * l.cout,
                      gpw);
@@ -1055,15 +1056,9 @@ void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w
   if (px > n_ptiles) px = n_ptiles;
   if (px < 1) px = 1;
   const size_t sout = POOL ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
-  constexpr size_t lds = (size_t)2 * (32 * WN + 128) * (32 + 8) * sizeof(bf16_t);
-  static bool attr_set[64] = {};  // per device (one static per template instance): > 64 KB of dynamic LDS needs the opt-in
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (lds > 64 * 1024 && dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_bf16_kernel<WN, POOL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set[dev] = true;
-  }
+  constexpr size_t lds = (size_t)2 * (32 * WN + 128) * (32 + 8) * sizeof(bf16_t);  // 40 KB at WN = 4
+  static_assert(lds <= 64 * 1024, "more than 64 KB of dynamic LDS needs the per-device hipFuncSetAttribute opt-in");
+  note_kernel(dim3(px, n_slices, kc), dim3(256), "gemm_pers_bf16_kernel<%d,%s>", WN, POOL ? "true" : "false");
   hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN, POOL>), dim3(px, n_slices, kc), dim3(256), lds, s, in, enc_wh, enc_w, ms,
                      k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, sout, n_ptiles);
 }
@@ -1074,6 +1069,7 @@ void launch_gemm(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, siz
   const int flags = l.relu6 | (pool ? 2 : 0);
   const size_t sout = pool ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
   const dim3 grid((M + 127) / 128, (l.cout + 32 * WN - 1) / (32 * WN), kc);
+  note_kernel(grid, dim3(256), "gemm_bf16_kernel<%d,%s>", WN, out_f32 ? "true" : "false");
   if (out_f32)
     hipLaunchKernelGGL((gemm_bf16_kernel<WN, true>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0, l.w_off, l.b_off,
                        res, dst, M, l.cin, l.cout, flags, (size_t)M * l.cin, sout);
@@ -1090,6 +1086,7 @@ void launch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size
   const int n_pt = (M + 15) / 16, n_ct = (l.cout + 15) / 16;
   const int groups = (n_pt + PT - 1) / PT;
   const dim3 grid(KSPLIT == 1 ? (groups + 3) / 4 : groups, (n_ct + CT - 1) / CT, kc);
+  note_kernel(grid, dim3(256), "pw_bf16_kernel<%d,%d,%d,%d,%s>", CT, PT, UNROLL, KSPLIT, out_f32 ? "true" : "false");
   if (out_f32)
     hipLaunchKernelGGL((pw_bf16_kernel<CT, PT, UNROLL, KSPLIT, true>), grid, dim3(256), 0, s, in, enc_wh, enc_w, ms, k0,
                        l.w_off, l.b_off, res, dst, M, l.cin, l.cout, flags, (size_t)M * l.cin, sout);
@@ -1149,7 +1146,7 @@ void dispatch_pwb(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, si
 
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
-                               float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap) {
+                               float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap, int variant) {
   const size_t ms = plan.blob_floats;
   // the tap: after the launch that completes layer `li`, copy its output out (as fp32) and stop
   auto tapped = [&](size_t li) -> bool {
@@ -1172,11 +1169,11 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
   std::vector<char> tiled(plan.blocks.size(), 0);
-  static const bool irb_old = getenv("RIP_IRB_OLD") != nullptr && getenv("RIP_IRB_OLD")[0] == '1';  // A/B hook (round 3's kernel)
+  const bool irb_old = (variant & ENC_VAR_IRB_ROUND3) != 0;  // A/B hook (round 3's kernel)
   for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-    const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_IRB2_ALL) != 0);
     const bool rows = rows2 || irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
     const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
     if (!rows && !tile) continue;
@@ -1194,7 +1191,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     const FusedBlock& fb = plan.blocks[0];
     front = true;
     in_block[0] = in_block[fb.dw] = in_block[fb.project] = 1;
-    static const bool front_old = getenv("RIP_FRONT_OLD") != nullptr && getenv("RIP_FRONT_OLD")[0] == '1';  // A/B hook
+    const bool front_old = (variant & ENC_VAR_FRONT_ROUND3) != 0;  // A/B hook
     const bool f2 = !front_old && front2_bf16_supported(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project]);
     hipError_t e = (f2 ? launch_front2_bf16 : launch_front_bf16)(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w,
                                                                  enc_wh, ms, k0, kc, B, visual,
@@ -1220,6 +1217,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     if (l.kind == L_STEM) {
       const int bands = (l.h_out + STEM_ROWS - 1) / STEM_ROWS;
       const size_t lds = ((size_t)l.cin * (2 * STEM_ROWS + 1) * (l.h_in + 2) + 9 * (size_t)l.cin * 32) * sizeof(float);
+      note_kernel(dim3(bands, B, kc), dim3(256), "stem_bf16_kernel<16>");
       hipLaunchKernelGGL((stem_bf16_kernel<16>), dim3(bands, B, kc), dim3(256), lds, s, visual, enc_w, ms, k0, l.w_off,
                          l.b_off, B, l.cin, l.h_in, l.h_out, dst);
     } else if (l.kind == L_DW) {
@@ -1229,6 +1227,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
 #define DW_GO(S_, R_)                                                                                         \
   {                                                                                                           \
     const long total = (long)B * l.h_out * ((l.h_out + R_ - 1) / R_) * (l.cout / 8);                          \
+    note_kernel(dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), "dw_bf16_kernel<%d,%d>", S_, R_);         \
     hipLaunchKernelGGL((dw_bf16_kernel<S_, R_>), dim3((unsigned)((total + 255) / 256), 1, kc), dim3(256), 0, s, \
                        src, enc_w, ms, k0, l.w_off, l.b_off, B, l.cout, l.h_in, l.h_out, dst);                 \
   }
@@ -1244,6 +1243,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
         bands = (l.h_out + band_rows - 1) / band_rows;
         const long waves = (long)B * bands * lane_groups;
         const dim3 grid((unsigned)((waves + 3) / 4), 1, kc);
+        note_kernel(grid, dim3(256), "dw_rows_bf16_kernel<%d,%d>", l.stride == 1 ? 1 : 2, l.stride == 1 ? 4 : 2);
         if (l.stride == 1)
           hipLaunchKernelGGL((dw_rows_bf16_kernel<1, 4>), grid, dim3(256), 0, s, src, enc_w, ms, k0, l.w_off, l.b_off, B,
                              l.cout, l.h_in, l.h_out, band_rows, bands, lane_groups, dst);

@@ -384,6 +384,7 @@ hipError_t launch_front_bf16(const Layer& ls, const Layer& ld, const Layer& lp, 
   int wgs = (per_cu * cus + kc - 1) / kc;
   if (B * a.bands < 2 * wgs) wgs = B * a.bands;  // small launches: one item per workgroup (no uneven 1-or-2 split)
   if (wgs < 1) wgs = 1;
+  note_kernel(dim3(wgs, 1, kc), dim3(256), "front_bf16_kernel<%d>", a.C == 2 && a.HI == 100 ? 2 : 0);
   if (a.C == 2 && a.HI == 100)
     hipLaunchKernelGGL(front_bf16_kernel<2>, dim3(wgs, 1, kc), dim3(256), lds, s, a);
   else

@@ -399,6 +399,7 @@ hipError_t launch_front2_bf16(const Layer& ls, const Layer& ld, const Layer& lp,
   int wgs = (2 * device_cu_count() + kc - 1) / kc;
   if (B * a.bands < 2 * wgs) wgs = B * a.bands;  // small launches: one item per workgroup
   if (wgs < 1) wgs = 1;
+  note_kernel(dim3(wgs, 1, kc), dim3(256), "front2_bf16_kernel<%d,2>", RBv);
   hipLaunchKernelGGL(kern, dim3(wgs, 1, kc), dim3(256), lds, s, a);
   return hipGetLastError();
 }

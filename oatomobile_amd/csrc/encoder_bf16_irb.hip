@@ -393,6 +393,9 @@ hipError_t launch_irb(const IrbArgs& a, int kc, int bands, hipStream_t s) {
   constexpr int DLD = (NW * CW > KS * 32 ? NW * CW : KS * 32) + 8;
   const size_t lds = ((size_t)NW * 3 * a.EW * ELD + (size_t)2 * a.WP * DLD) * sizeof(bf16_t) +
                      (WLDS ? (size_t)9 * NW * CW * sizeof(float) : 0) + (size_t)a.EW * ELD * sizeof(bf16_t);
+  note_kernel(dim3(bands, a.B, kc), dim3(NW * 64), "irb_rows_bf16_kernel<%d,%d,%s,%d,%d,%d,%s,%s,%s,%d,%d>", STRIDE, R,
+              EXPAND ? "true" : "false", NW, TPW, NPT, WINDOW ? "true" : "false", APREG ? "true" : "false",
+              WLDS ? "true" : "false", CW, KS);
   hipLaunchKernelGGL((irb_rows_bf16_kernel<STRIDE, R, EXPAND, NW, TPW, NPT, WINDOW, APREG, WLDS, CW, KS>),
                      dim3(bands, a.B, kc), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
@@ -448,7 +451,6 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
   a.WP = (a.H_out + 15) & ~15;
   // bands: enough workgroups for ~3 per CU, but bands re-expand their halo rows, so keep them >= 6 rows
   int bands = (int)((768 + (long)B * kc - 1) / ((long)B * kc));
-  if (const char* e = getenv("RIP_IRB_BANDS")) bands = atoi(e);  // tuning hook
   const int min_rows = (long)B * kc <= 16 ? 2 : 6;  // a handful of observations: a latency chain, short bands (as irb2)
   if (bands > a.H_out / min_rows) bands = a.H_out / min_rows;
   if (bands < 1) bands = 1;

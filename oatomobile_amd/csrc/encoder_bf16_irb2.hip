@@ -421,17 +421,20 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
   a.band_rows = (H_OUT + bands - 1) / bands;
   bands = (H_OUT + a.band_rows - 1) / a.band_rows;
   auto kern = irb2_bf16_kernel<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG, RES, OCC, BTD>;
-  static bool attr_done = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_done && SH::LDS_BYTES > 64 * 1024) {
+  static bool attr_set[64] = {};  // > 64 KB of dynamic LDS needs the opt-in once per kernel AND device
+  int dev = 0;
+  if (SH::LDS_BYTES > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)SH::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_set[dev] = true;
   }
   // OCC workgroups per CU stay resident and walk the observations (the wave constants are built once per workgroup)
   int wgy = (OCC * device_cu_count() + bands * kc - 1) / (bands * kc);
   if (wgy > B) wgy = B;
   if (wgy < 1) wgy = 1;
+  note_kernel(dim3(bands, wgy, kc), dim3(NW * 64), "irb2_bf16_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%s,%d,%d>", S, CIN, HID, COUT, H_IN,
+              H_OUT, NW, NG, RES ? "true" : "false", OCC, BTD);
   hipLaunchKernelGGL(kern, dim3(bands, wgy, kc), dim3(NW * 64), SH::LDS_BYTES, s, a);
 #ifdef RIP_IRB2_TICKS
   {
@@ -454,12 +457,11 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
 // which this kernel is the faster one at 512 observations x 4 models (profiles/r4: features.2 287 -> 172 us, features.3
 // 230 -> 196, features.4 111 -> 92); the 13x13 / 7x7-output blocks (one pixel tile per row: 39 MFMAs of dependent chains
 // per wave and row at two waves per SIMD, 80 -> 87 us and 55 -> 70 us) stay on round 3's kernel (encoder_bf16_irb.hip)
-// unless RIP_IRB2_ALL=1 asks for this one everywhere (tests run both).
-bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp) {
+// unless `everywhere` (RIP_OPT_ENCODER_VARIANT bit ENC_VAR_IRB2_ALL) asks for this one there too (tests run both).
+bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, bool all) {
   if (le == nullptr) return false;
   const int cin = le->cin, hid = ld.cout, cout = lp.cout, s = ld.stride, hi = ld.h_in, ho = ld.h_out;
   auto is = [&](int a, int b, int c, int d, int e, int f) { return cin == a && hid == b && cout == c && s == d && hi == e && ho == f; };
-  static const bool all = getenv("RIP_IRB2_ALL") != nullptr && getenv("RIP_IRB2_ALL")[0] == '1';
   if (is(16, 96, 24, 2, 50, 25) || is(24, 144, 24, 1, 25, 25) || is(24, 144, 32, 2, 25, 13)) return true;
   return all && (is(32, 192, 32, 1, 13, 13) || is(32, 192, 64, 2, 13, 7));
 }

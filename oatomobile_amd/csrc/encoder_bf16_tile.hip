@@ -392,6 +392,8 @@ hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
   }
   if (a.HID != 6 * CIN) return hipErrorInvalidValue;
   static_assert(Geo::lds_bytes(6 * CIN) <= 160 * 1024, "LDS budget");
+  note_kernel(dim3((a.B + G - 1) / G, 1, kc), dim3(512), "irb_tile_bf16_kernel<%d,%d,%d,%d,%d,%s,%s,%d> G=%d", HIN, STRIDE, CIN, COUT,
+              GMAX, AEF ? "true" : "false", APF ? "true" : "false", WCH, G);
   hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
   return hipGetLastError();
 }

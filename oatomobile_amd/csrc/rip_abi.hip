@@ -38,6 +38,9 @@ struct rip_handle {
   int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA wave-per-model pipeline, 3 fp32-MFMA phase-sequential,
                             // 4 split-f16 phase-sequential
   int encoder_fused = -1;   // leading inverted-residual blocks run fused (0 = none, 17 = all); -1 = auto by batch
+  int encoder_variant = 0;  // RIP_OPT_ENCODER_VARIANT: development / test kernel selections of the bf16 encoder (encoder.h ENC_VAR_*)
+  bool kernel_log_on = false;  // RIP_OPT_KERNEL_LOG
+  KernelLog klog;              // the encoder kernels of the last rip_encode* / rip_encode_tap* call (rip_kernel_log)
   int search_regroup = 0;   // split-f16 search: regroup a workgroup's candidates by selected model between Adam steps (measured: no gain)
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
@@ -101,6 +104,20 @@ static hipError_t enter_stream(rip_handle* h, hipStream_t s) {
 
 
 static thread_local char g_err[512] = "";
+
+// RIP_OPT_KERNEL_LOG: the encoder launch sites of this call append to the handle's log (encoder.h: note_kernel)
+struct KernelLogScope {
+  bool on;
+  explicit KernelLogScope(rip_handle* h) : on(h->kernel_log_on) {
+    if (on) {
+      h->klog.text.clear();
+      kernel_log_install(&h->klog);
+    }
+  }
+  ~KernelLogScope() {
+    if (on) kernel_log_install(nullptr);
+  }
+};
 
 // ---- tracing hook: rocTX ranges around encode / search / train / collectives, visible in
 // `rocprofv3 --marker-trace`.  Off unless RIP_ROCTX=1 is in the environment: then librocprofiler-sdk-roctx (or the
@@ -174,7 +191,7 @@ static int check_models(const rip_handle* h, int k0, int kc) {
 
 extern "C" {
 
-int rip_abi_version(void) { return 3; }
+int rip_abi_version(void) { return 4; }
 const char* rip_last_error(void) { return g_err; }
 
 int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_candidates, int device) {
@@ -346,6 +363,15 @@ int rip_set_option(rip_handle* h, int option, int value) {
       }
       h->encoder_mega = value;
       return RIP_OK;
+    case RIP_OPT_ENCODER_VARIANT:
+      REQUIRE(value >= 0 && value <= 7, "encoder variant mask %d not in [0,7] (1 round-3 row-streaming blocks, 2 round-3 front, 4 matrix-core depthwise on features.5-7)", value);
+      h->encoder_variant = value;
+      return RIP_OK;
+    case RIP_OPT_KERNEL_LOG:
+      REQUIRE(value == 0 || value == 1, "kernel log must be 0 or 1 (got %d)", value);
+      h->kernel_log_on = value == 1;
+      h->klog.text.clear();
+      return RIP_OK;
     case RIP_OPT_DEBUG_ENCODER_FAULT:
       // test hook: raise the one-launch encoder's failure word as its kernel would (tests of the caller's recovery path)
       REQUIRE(value == 1 || value == 2, "encoder fault code must be 1 (placement) or 2 (barrier timeout), got %d", value);
@@ -406,6 +432,17 @@ static bool mega_applies(const rip_handle* h, int B) {
   return h->encoder_mega == 1;  // auto = off: measured 251-273 us against 244 us of layer-wise launches
 }
 
+int rip_kernel_log(const rip_handle* h, char* buf, size_t cap) {
+  if (h == nullptr) return RIP_EINVAL;
+  const size_t n = h->klog.text.size();
+  if (buf != nullptr && cap > 0) {
+    const size_t m = n < cap - 1 ? n : cap - 1;
+    memcpy(buf, h->klog.text.data(), m);
+    buf[m] = '\0';
+  }
+  return (int)n;
+}
+
 int rip_encoder_status(rip_handle* h) {
   if (h == nullptr) return RIP_EINVAL;
   // one-shot: the word itself stays raised (mega_applies keeps the handle on the layer-wise launches), but it is handed
@@ -424,9 +461,10 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
   ENTER(h, stream);
   TraceRange range_(enc_dtype == RIP_ENC_BF16 ? "rip_encode (bf16)" : "rip_encode (fp32)");
+  KernelLogScope log_(h);
   if (enc_dtype == RIP_ENC_BF16) {
     HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
-                                feat_dev, h->encoder_fused, (hipStream_t)stream));
+                                feat_dev, h->encoder_fused, (hipStream_t)stream, nullptr, h->encoder_variant));
     return RIP_OK;
   }
   if (mega_applies(h, B)) {
@@ -442,7 +480,12 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
 
 int rip_encode_tap(rip_handle* h, const float* visual_dev, int B, int k, int enc_dtype, int layer, float* dst_dev,
                    size_t dst_numel, rip_stream_t stream) {
-  int rc = check_models(h, k, 1);
+  return rip_encode_tap_k(h, visual_dev, B, k, 1, enc_dtype, layer, dst_dev, dst_numel, stream);
+}
+
+int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin, int k_count, int enc_dtype, int layer,
+                     float* dst_dev, size_t dst_numel, rip_stream_t stream) {
+  int rc = check_models(h, k_begin, k_count);
   if (rc != RIP_OK) return rc;
   REQUIRE(visual_dev != nullptr && dst_dev != nullptr, "NULL argument");
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
@@ -451,17 +494,19 @@ int rip_encode_tap(rip_handle* h, const float* visual_dev, int B, int k, int enc
   REQUIRE(layer >= 0 && layer < L, "layer %d outside [0,%d)", layer, L);
   const Layer& l = h->plan.layers[layer];
   const bool pooled = layer + 1 == L && h->plan.final_hw == 4;
-  const size_t need = (size_t)B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
-  REQUIRE(dst_numel == need, "dst_numel=%zu, layer %d of B=%d observations has %zu elements", dst_numel, layer, B, need);
+  const size_t need = (size_t)k_count * B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
+  REQUIRE(dst_numel == need, "dst_numel=%zu, layer %d of %d model(s) x B=%d observations has %zu elements", dst_numel, layer,
+          k_count, B, need);
   ENTER(h, stream);
+  KernelLogScope log_(h);
   EncoderTap tap;
   tap.layer = layer;
   tap.dst = dst_dev;
   if (enc_dtype == RIP_ENC_BF16)
-    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k, 1, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
-                                h->encoder_fused, (hipStream_t)stream, &tap));
+    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
+                                h->encoder_fused, (hipStream_t)stream, &tap, h->encoder_variant));
   else
-    HIP_TRY(launch_encoder(h->plan, h->enc_w, k, 1, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
+    HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
                            h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap));
   if (!tap.served)
     return fail(RIP_EINVAL, "layer %d is inside a fused block under the current RIP_OPT_ENCODER_FUSED setting: its output "

@@ -70,7 +70,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == bound, declared ^ bound
   for name in declared:
     assert hasattr(lib, name)
-  assert lib.rip_abi_version() == _lib.ABI_VERSION == 3
+  assert lib.rip_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_docs_quote_the_header_and_the_tests_as_they_are():
@@ -81,7 +81,7 @@ def test_docs_quote_the_header_and_the_tests_as_they_are():
   for doc in ("README.md", "INTEGRATION.md", "DESIGN.md"):
     text = open(os.path.join(ROOT, doc)).read()
     quoted = {int(m) for m in re.findall(r"(\d+) (?:`extern \"C\"` )?entry points", text)}
-    quoted -= {34, 39, 41}  # earlier rounds' counts, quoted as history
+    quoted -= {34, 39, 41, 42}  # earlier rounds' counts, quoted as history
     assert quoted and quoted <= {n}, (doc, quoted, n)
   tests = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read() + open(os.path.join(ROOT, "tests", "test_host_cpu.py")).read()
   tests += open(os.path.join(ROOT, "tests", "test_distributed_cpu.py")).read()

@@ -246,3 +246,54 @@ def test_g15_train_step_oracle_vs_reference(golden):
     for key in g.files:
       if key.startswith(t + "buffer:") and "num_batches" not in key:
         np.testing.assert_allclose(sd[key[len(t + "buffer:"):]].numpy(), g[key], rtol=1e-5, atol=1e-6)
+
+
+# ---- oracle/bf16_encoder.py (derived oracle of the bf16 encoder kernels) is pinned to the fixture-pinned fp32 oracle ----
+
+def test_bf16_oracle_without_its_roundings_is_the_fp32_oracle(monkeypatch):
+  """VERDICT r4 weak #2.  `oracle/bf16_encoder.py` gates every bf16 encoder kernel, and nothing gated IT: with the one
+  thing it adds — the bf16 storage roundings — switched off (identity), its `params` must be the fp32 oracle's
+  (`reference_cpu.params`, pinned by g5) up to the fp32 noise of folding BatchNorm into the conv weights.  An edit to
+  the fold, the layer order, a stride, a ReLU6 or a residual index moves z by O(1) and fails here."""
+  from oracle import bf16_encoder as BE
+  m = model(21)
+  ctx = ctx_from_obs([synth_observation(np.random.default_rng(1000 + i)) for i in range(4)])
+  want = O.params(m, **ctx).numpy()
+  with_rounding = BE.params(m, **ctx).numpy()
+  monkeypatch.setattr(BE, "bf16_round", lambda t: t)
+  got = BE.params(m, **ctx).numpy()
+  assert np.abs(got - want).max() <= 3e-5, np.abs(got - want).max()  # measured 1.3e-5 at max|z| ~ 1.9 (fold in fp32 vs BN applied in fp32)
+  # ... and with them it really is another arithmetic (the comparison above is not vacuous)
+  assert np.abs(with_rounding - want).max() > 1e-3
+
+
+def test_bf16_oracle_layer_list_is_the_architecture():
+  """`folded_layers` against `oatomobile_amd.arch` (the layer list the kernels, `rip_encode_tap` and `rip_train_peek`
+  index): 52 layers in network order, kinds / widths / strides / ReLU6 flags, and every residual source = the output of
+  the layer in front of the block (torchvision `use_res_connect`: stride 1 and equal widths)."""
+  from oracle import bf16_encoder as BE
+  from oatomobile_amd import arch
+  layers = BE.folded_layers(model(21))
+  spec = arch.conv_layers()
+  assert len(layers) == len(spec) == 52
+  for l, sp in zip(layers, spec):
+    assert l.w.shape[0] == sp.cout and l.relu6 == sp.relu6, sp.name
+  i = 1
+  for b in arch.blocks():
+    first = i
+    if b.expand:
+      assert layers[i].kind == "pw" and layers[i].w.shape[:2] == (b.hidden, b.inp) and layers[i].residual_from is None
+      i += 1
+    assert layers[i].kind == "dw" and layers[i].stride == b.stride and layers[i].w.shape == (b.hidden, 1, 3, 3)
+    assert layers[i].residual_from is None
+    i += 1
+    assert layers[i].kind == "pw" and layers[i].w.shape[:2] == (b.oup, b.hidden) and not layers[i].relu6
+    assert layers[i].residual_from == (first - 1 if b.residual else None), b
+    i += 1
+  assert i == 51 and layers[0].kind == "stem" and layers[0].stride == 2 and layers[51].kind == "pw"
+  # pointwise weights are bf16 values, stem / depthwise taps and all biases are not rounded
+  for l in layers:
+    if l.kind == "pw":
+      assert torch.equal(BE.bf16_round(l.w), l.w)
+  assert not torch.equal(BE.bf16_round(layers[0].w), layers[0].w)
+  assert sum(int(l.residual_from is not None) for l in layers) == 10
