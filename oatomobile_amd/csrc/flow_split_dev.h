@@ -2,10 +2,23 @@
 //
 // The GRU / head contractions of flow_phase.hip, moved from v_mfma_f32_16x16x4_f32 (32 cycles, K = 4) to
 // v_mfma_f32_16x16x32_f16 (16 cycles, K = 32) without giving up fp32-grade results: both operands are carried as two
-// binary16 terms, x ~= hi + lo' * 2^-11 with hi = f16(x), lo' = f16((x - hi) * 2^11), and a product is three MFMAs
-//     W x ~= Whi xhi + 2^-11 (Whi xlo' + Wlo' xhi)        (the dropped Wlo xlo term is 2^-22 relative)
-// with the two groups in separate fp32 accumulators (binary16 products are exact in fp32; accumulation is fp32).
-// 22 significant bits per operand instead of 24: the teacher-forced 1e-4 tests are the gate (tests/test_gpu_parity.py).
+// binary16 terms, x ~= hi + lo with hi = f16(x), lo ~ x - hi, and a product is three MFMAs, fp32 accumulation,
+//     W x ~= Whi xhi + Whi xlo + Wlo xhi        (the dropped Wlo xlo term is 2^-22 relative)
+// (binary16 products are exact in fp32).  22 significant bits per operand instead of 24: the teacher-forced 1e-4 tests
+// are the gate (tests/test_gpu_parity.py).
+// Round 5, FORWARD side (hidden states, |h| <= max(1, |z|), forward weight rows): all three products of a tile go into
+// ONE accumulator.  The weight rows keep lo' = f16((w - hi) 2^11) (weights are small: an unscaled residual would sit in
+// the subnormal range of binary16, quantised at 2^-24 absolute — measured: 3x the fp32 kernel's error at |z| ~ 1e3 and
+// O(1) gradient errors where the search amplifies rounding 1e5-fold), and the 2^-11 moves to the other operand: the
+// (Wlo' x hi) product uses hs = hi * 2^-11, an exact binary16 scaling (v_pk_mul_f16, four instructions per K block).
+// The state's own low term is lo = f16(x - hi), unscaled: for |x| < 1/8 it is subnormal, quantised at 2^-24, i.e. at most
+// 2^-25 |W| per product — below the fp32 accumulation error of the sum it joins (the f16 matrix pipe takes subnormal
+// inputs as they are; tools/micro/split_f16.hip checks).  Gone: the second accumulator of every tile, its
+// `a + l * 2^-11` combine and one multiply per split pair — a wave's time here is the SUM of its matrix-pipe cycles,
+// 4 cycles per vector instruction and 16 per transcendental (MFMAs and vector work of ONE wave do not overlap,
+// DESIGN_HISTORY §4.1), so instructions are what there is to remove.  (Packing the r / z rows pre-multiplied by -log2(e)
+// saves two more multiplies per unit pair and measured no faster: 2.654 vs 2.640 ms; not kept.)  The ADJOINT side keeps
+// round 3's two accumulators, see LO_SCALE below.
 // The weights are split on the host (flow_split_pack.h); activations / gradients are split here, per candidate:
 //   * hidden states (|h| <= max(1, |z|)) and the head's hidden layer are split as they are;
 //   * adjoint quantities (unbounded either way) are first scaled by a per-candidate power of two that puts the
@@ -27,8 +40,6 @@ using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr float LO_SCALE = 2048.0f;
-constexpr float LO_INV = 1.0f / 2048.0f;
 constexpr int T = 4;
 constexpr int CB = 16;  // candidates per wave
 
@@ -49,10 +60,19 @@ __device__ __forceinline__ float4 as_f4(uint4 u) {
 // B operands of a 64-unit vector (or of any 16 values per lane): two K blocks, two terms each
 struct BSplit {
   h16x8 hi[2], lo[2];
+  h16x8 hs[2];  // hi * 2^-11 (forward states only): the B operand of the (Wlo' x hi) product, see the head of this file
 };
 
-// 8 fp32 -> (hi, lo') packed halves.  `s` = a power-of-two pre-scale (1 for bounded quantities).
-// Per pair: v_pk_mul (s), v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add, v_pk_mul (2^11), v_cvt_pk_f16_f32.
+// ADJOINT operands keep round 3's scaled low term, lo' = f16((x - hi) 2^11) on both sides (transposed weight rows, gate
+// gradients), with the two lo' products in a second accumulator: a gradient vector is scaled by ONE power of two per
+// candidate and its entries span many binades (saturated gates: r (1 - r) from 0.25 down to 1e-30) — entries 2^-14 below
+// the largest would keep only their hi bits without the 2^11, and at |z| ~ 100, where the search amplifies rounding
+// by ~1e5 (the fp32 kernel is at 4e-3 there), that showed as O(1) gradient errors (test_split_kernel_operand_ranges).
+constexpr float LO_SCALE = 2048.0f;
+constexpr float LO_INV = 1.0f / 2048.0f;
+
+// 8 fp32 -> (hi, lo) packed halves.  SCALED (adjoint quantities): `s` = a power-of-two pre-scale and lo' = lo * 2^11.
+// Per pair: [v_pk_mul (s)], v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add, [v_pk_mul (2^11)], v_cvt_pk_f16_f32.
 template <bool SCALED>
 __device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8& lo) {
   u32x4 uh, ul;
@@ -62,8 +82,7 @@ __device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8
     if (SCALED) x = x * f32x2{s, s};
     const h16x2 h = __builtin_convertvector(x, h16x2);
     const f32x2 back = __builtin_convertvector(h, f32x2);
-    const f32x2 r = (x - back) * f32x2{LO_SCALE, LO_SCALE};
-    const h16x2 l = __builtin_convertvector(r, h16x2);
+    const h16x2 l = __builtin_convertvector(SCALED ? (x - back) * f32x2{LO_SCALE, LO_SCALE} : x - back, h16x2);
     uh[p] = __builtin_bit_cast(unsigned, h);
     ul[p] = __builtin_bit_cast(unsigned, l);
   }
@@ -73,6 +92,10 @@ __device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8
 __device__ __forceinline__ void split16(const float (&v)[16], BSplit& b) {
   split8<false>(&v[0], 1.f, b.hi[0], b.lo[0]);
   split8<false>(&v[8], 1.f, b.hi[1], b.lo[1]);
+  const _Float16 k = (_Float16)LO_INV;  // exact; v_pk_mul_f16 on the packed halves, four instructions per K block
+  const h16x8 k8 = {k, k, k, k, k, k, k, k};
+  b.hs[0] = b.hi[0] * k8;
+  b.hs[1] = b.hi[1] * k8;
 }
 
 // max |.| over the 4 q-lanes of a candidate (lanes c, c+16, c+32, c+48): two swaps on the VALU, no LDS
@@ -96,11 +119,9 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
 #ifndef RIP_PRIO
 #define RIP_PRIO 1
 #endif
+
 #define SPLIT_PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define SPLIT_PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
-#ifndef RIP_SPLIT_MERGE_LO
-#define RIP_SPLIT_MERGE_LO 1  // both lo' products of a tile share one accumulator (0: one each, as first built)
-#endif
 #ifndef RIP_PIPE_VALU
 #define RIP_PIPE_VALU 5  // vector instructions scheduled behind each matrix instruction in the one-wave-per-SIMD build
 #endif
@@ -172,30 +193,28 @@ __device__ __forceinline__ void gru_gates(const f32x4& ar, const f32x4& az, cons
 template <int SAVE, bool PIPE = false>
 __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit& hs, float yp0, float yp1, int q,
                                          unsigned lane, float4* __restrict__ tape, StepTape* tr, float (&o)[4]) {
+  (void)PIPE;  // (round 3's tile pipelining: MFMAs and vector work of one wave do not overlap, removed in round 5)
   const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
   unsigned loff = lane * 16u;
   asm volatile("" : "+v"(loff));  // flow_phase.hip: keeps the tape addressing scalar base + one lane offset
   const float4 wxr = as_f4(wl[48 * 64]), wxz = as_f4(wl[49 * 64]), wxg = as_f4(wl[50 * 64]), wxh = as_f4(wl[51 * 64]);
   const float wxra[4] = {wxr.x, wxr.y, wxr.z, wxr.w}, wxza[4] = {wxz.x, wxz.y, wxz.z, wxz.w};
   const float wxga[4] = {wxg.x, wxg.y, wxg.z, wxg.w}, wxha[4] = {wxh.x, wxh.y, wxh.z, wxh.w};
-  // operand rows of item (up, kb, g): hi row ((g * 4 + up) * 2 + kb) * 2, lo' row behind it.  An item is 3 MFMAs into
-  // three DIFFERENT accumulators (Whi xhi -> a, Whi xlo' -> l1, Wlo' xhi -> l2: no back-to-back dependency), its two
-  // rows are requested PF items (3 PF MFMAs) ahead of their use; head rows follow the last item.
-  constexpr int PF = 3, NIT = 24;
-  auto row_of = [](int it, int term) {  // it = (up * 2 + kb) * 3 + g
-    const int g = it % 3, kb = (it / 3) & 1, up = it / 6;
+  // Operand rows of group gk = up * 2 + kb (one K block of one unit tile): hi row of gate g at
+  // ((g * 4 + up) * 2 + kb) * 2, lo row behind it.  A group is nine MFMAs into the tile's three accumulators, ordered
+  // (hi hi) r z n, (hi lo) r z n, (lo hi) r z n so that an accumulator is touched every THIRD instruction (back-to-back
+  // MFMAs on one accumulator wait for each other).  The hi rows of group gk + 1 are requested at the top of group gk
+  // (also across tiles: they land under the gate math), the lo rows of gk at its top (six MFMAs ahead of their use).
+  auto row_of = [](int gk, int g, int term) {
+    const int up = gk >> 1, kb = gk & 1;
     return (((g * 4 + up) * 2 + kb) * 2 + term) * 64;
   };
-  uint4 rh[PF], rl[PF];
+  uint4 RH[2][3], RL[3];
 #pragma unroll
-  for (int e = 0; e < PF; ++e) {
-    rh[e] = wl[row_of(e, 0)];
-    rl[e] = wl[row_of(e, 1)];
-  }
+  for (int g = 0; g < 3; ++g) RH[0][g] = wl[row_of(0, g, 0)];
   float Hn[16];
-  // Accumulators of one unit tile: three gates x (Whi xhi | Whi xlo' | Wlo' xhi) + gi_n.
   struct TileAcc {
-    f32x4 a[3], l1[3], l2[3], agn;  // (RIP_SPLIT_MERGE_LO: l2 unused, both lo' products accumulate into l1)
+    f32x4 a[3], agn;  // pre_r, pre_z, gh_n; gi_n
   };
   auto issue = [&](int up, TileAcc& t) __attribute__((always_inline)) {
     SPLIT_PRIO_BURST();
@@ -204,37 +223,31 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
     t.agn = mfma4(wxga[up], bin, zero4());
     t.a[2] = mfma4(wxha[up], bin, zero4());
 #pragma unroll
-    for (int g = 0; g < 3; ++g) t.l1[g] = t.l2[g] = zero4();
-#pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const h16x8 bh = hs.hi[kb], bl = hs.lo[kb];
+      const int gk = up * 2 + kb;
+      const h16x8 bh = hs.hi[kb], bl = hs.lo[kb], bs = hs.hs[kb];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const int it = (up * 2 + kb) * 3 + g;
-        const uint4 wh = rh[it % PF], wo = rl[it % PF];
-        if (it + PF < NIT) {
-          rh[it % PF] = wl[row_of(it + PF, 0)];
-          rl[it % PF] = wl[row_of(it + PF, 1)];
-          if (!PIPE) __builtin_amdgcn_sched_barrier(0);
-        }
-        t.a[g] = mfmah(as_h8(wh), bh, t.a[g]);
-        t.l1[g] = mfmah(as_h8(wh), bl, t.l1[g]);
-        if (RIP_SPLIT_MERGE_LO)
-          t.l1[g] = mfmah(as_h8(wo), bh, t.l1[g]);
-        else
-          t.l2[g] = mfmah(as_h8(wo), bh, t.l2[g]);
+      for (int g = 0; g < 3; ++g) RL[g] = wl[row_of(gk, g, 1)];
+      if (gk + 1 < 8) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) RH[(gk + 1) & 1][g] = wl[row_of(gk + 1, g, 0)];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) t.a[g] = mfmah(as_h8(RH[gk & 1][g]), bh, t.a[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) t.a[g] = mfmah(as_h8(RH[gk & 1][g]), bl, t.a[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) t.a[g] = mfmah(as_h8(RL[g]), bs, t.a[g]);
     }
     SPLIT_PRIO_VALU();
   };
   auto finish = [&](int up, const TileAcc& t) __attribute__((always_inline)) {
-    const f32x4 ar = t.a[0] + (RIP_SPLIT_MERGE_LO ? t.l1[0] : t.l1[0] + t.l2[0]) * LO_INV;
-    const f32x4 az = t.a[1] + (RIP_SPLIT_MERGE_LO ? t.l1[1] : t.l1[1] + t.l2[1]) * LO_INV;
-    const f32x4 ahn = t.a[2] + (RIP_SPLIT_MERGE_LO ? t.l1[2] : t.l1[2] + t.l2[2]) * LO_INV;
+    const f32x4 ahn = t.a[2];
     float rr[4], zz[4], nn[4];
-    gru_gates(ar, az, t.agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
+    gru_gates(t.a[0], t.a[1], t.agn, ahn, &H[up * 4], &Hn[up * 4], rr, zz, nn);
     // pin the tile's gate math HERE: it has no side effect, and left alone it sinks below the MFMAs of ALL later tiles
-    // (to its first use), which keeps four tiles of accumulators alive (160 registers)
+    // (to its first use), which keeps four tiles of accumulators alive
     asm volatile("" : "+v"(Hn[up * 4]), "+v"(Hn[up * 4 + 1]), "+v"(Hn[up * 4 + 2]), "+v"(Hn[up * 4 + 3]));
     if (SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) {
       tape_st(trow(tape, up * 4 + 0, loff), rr[0], rr[1], rr[2], rr[3]);
@@ -253,66 +266,35 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
       }
     }
   };
-  if (PIPE) {
-    // one wave per SIMD: tile up+1's MFMAs are issued before tile up's gate math, so that the VALU work of a tile can run
-    // in the shadow of the next tile's matrix instructions (two tiles of accumulators live)
-    TileAcc t[2];
-    issue(0, t[0]);
+  // tile by tile (two waves per SIMD: the partner wave's MFMAs cover this wave's gate math; one wave: nothing does)
 #pragma unroll
-    for (int up = 0; up < 4; ++up) {
-      if (up < 3) issue(up + 1, t[(up + 1) & 1]);
-      finish(up, t[up & 1]);
-      if (up < 3) {
-        // the region's schedule: behind every matrix instruction of tile up+1, RIP_PIPE_VALU vector instructions of tile
-        // up's gate math (and the operand reads of the tile after) — the VALU work issues while the matrix pipe runs
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // a DS read
-          __builtin_amdgcn_sched_group_barrier(0x002, RIP_PIPE_VALU, 0);  // VALU
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, RIP_PIPE_VALU, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    // two waves per SIMD (256 registers each): tile by tile — the partner wave's MFMAs cover this wave's gate math
-#pragma unroll
-    for (int up = 0; up < 4; ++up) {
-      TileAcc t;
-      issue(up, t);
-      finish(up, t);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  for (int up = 0; up < 4; ++up) {
+    TileAcc t;
+    issue(up, t);
+    finish(up, t);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) H[i] = Hn[i];
   split16(H, hs);  // the head's B operands == the next step's
-  // ---- head: rows 52..59 = W1 ((tile mt, kb) x (hi, lo')), 60..62 fp32: (b1 t0, b1 t1, W2 k0, k1), W2 k2..5, (k6, k7, b2) ----
+  // ---- head: rows 52..59 = W1 ((tile mt, kb) x (hi, lo)), 60..62 fp32: (b1 t0, b1 t1, W2 k0, k1), W2 k2..5, (k6, k7, b2) ----
   const float bone = q == 2 ? 1.f : 0.f;
   const float4 t60 = as_f4(wl[60 * 64]), t61 = as_f4(wl[61 * 64]), t62 = as_f4(wl[62 * 64]);
   SPLIT_PRIO_BURST();
   f32x4 a0 = mfma4(t60.x, bone, zero4()), a1 = mfma4(t60.y, bone, zero4());
   {
-    // rows 52 + (mt * 2 + kb) * 2 + term; 12 MFMAs into six accumulators
-    f32x4 a0l = zero4(), a1l = zero4(), a0m = zero4(), a1m = zero4();
+    // rows 52 + (mt * 2 + kb) * 2 + term; 12 MFMAs, the two tiles' accumulators alternate
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const uint4 w0h = wl[(52 + kb * 2) * 64], w0l = wl[(53 + kb * 2) * 64];
       const uint4 w1h = wl[(56 + kb * 2) * 64], w1l = wl[(57 + kb * 2) * 64];
       a0 = mfmah(as_h8(w0h), hs.hi[kb], a0);
       a1 = mfmah(as_h8(w1h), hs.hi[kb], a1);
-      a0l = mfmah(as_h8(w0h), hs.lo[kb], a0l);
-      a1l = mfmah(as_h8(w1h), hs.lo[kb], a1l);
-      a0m = mfmah(as_h8(w0l), hs.hi[kb], a0m);
-      a1m = mfmah(as_h8(w1l), hs.hi[kb], a1m);
+      a0 = mfmah(as_h8(w0h), hs.lo[kb], a0);
+      a1 = mfmah(as_h8(w1h), hs.lo[kb], a1);
+      a0 = mfmah(as_h8(w0l), hs.hs[kb], a0);
+      a1 = mfmah(as_h8(w1l), hs.hs[kb], a1);
     }
-    a0 = a0 + (a0l + a0m) * LO_INV;
-    a1 = a1 + (a1l + a1m) * LO_INV;
   }
   if (SAVE != SAVE_NONE) {
     unsigned m = 0;
@@ -494,7 +476,8 @@ __device__ __forceinline__ float amax8(const float* v, float m) {
 // One step t of the adjoint (flow_phase.hip:adj_step with split-f16 contractions).
 //   dh_t = W1^T da1_t [12 f16 MFMAs, own scale] + W_hh^T (dpr, dpz, dgh_n)_{t+1} [72 f16 MFMAs, `gs` from step t+1]
 //   du_t = W_ih^T (dpr, dpz, dpn)_t [18 f16 MFMAs, the scale of this step's gate gradients]
-// + 2 (W2^T) + 4 (gi_n) fp32 MFMAs: 1824 matrix-pipe cycles (flow_phase.hip: 278 x 32 = 8896).
+// + 2 (W2^T) + 4 (gi_n) fp32 MFMAs: 1824 matrix-pipe cycles (flow_phase.hip: 278 x 32 = 8896).  Adjoint operands keep the
+// 2^11-scaled low terms (above): (hi hi) into one accumulator, both lo' products into a second one.
 // tw: this lane's column of the transposed rows; wtab: this lane's entry (q * 2 + (c & 1)) of the W_ih^T table, one
 // group of 8 entries per (kb, term); wl: the forward rows (gi_n's k-step).  LASTSTEP (t = 1): nothing consumes the
 // gate gradients as W_hh^T operands any more.
@@ -588,69 +571,58 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     h16x8 ah, al;
     split8<true>(da1r, sa, ah, al);
     SPLIT_PRIO_BURST();
-    f32x4 a[4], l1[4], l2[4];
+    // rows 1 + ut * 2 (hi), 2 + ut * 2 (lo'); term by term, so that an accumulator is touched every fourth MFMA
+    f32x4 a[4], l[4];
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) {
-      const uint4 wh = tw[(1 + ut * 2) * 64], wo = tw[(2 + ut * 2) * 64];
-      a[ut] = mfmah(as_h8(wh), ah, zero4());
-      l1[ut] = mfmah(as_h8(wh), al, zero4());
-      if (RIP_SPLIT_MERGE_LO)
-        l1[ut] = mfmah(as_h8(wo), ah, l1[ut]);
-      else
-        l2[ut] = mfmah(as_h8(wo), ah, zero4());
-    }
+    for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(tw[(1 + ut * 2) * 64]), ah, zero4());
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(tw[(1 + ut * 2) * 64]), al, zero4());
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(tw[(2 + ut * 2) * 64]), ah, l[ut]);
     SPLIT_PRIO_VALU();
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + (RIP_SPLIT_MERGE_LO ? l1[ut] : l1[ut] + l2[ut]) * LO_INV) * ia;
+    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + l[ut] * LO_INV) * ia;
   }
   // ---- part 2: W_hh^T (dpr, dpz, dgh_n)_{t+1}: 6 K blocks x 4 unit tiles, rows 9 + (kb * 4 + ut) * 2 + term ----
   if (!FIRST) {
     // dh'_{t+1} z_{t+1} joins here, before the big contraction, so that its 16 registers are free during it
 #pragma unroll
     for (int i = 0; i < 16; ++i) dh[i >> 2][i & 3] += dhz[i];
-    // item (half, kb, u): unit tile ut = 2 half + u, hi row 9 + (kb * 4 + ut) * 2, lo' row behind it; 3 MFMAs into three
-    // different accumulators; two unit tiles at a time (24 accumulator registers instead of 48); rows requested PF
-    // items ahead
-    constexpr int PF = 3, NIT = 24;
-    auto row_of = [](int it, int term) {
-      const int u = it & 1, kb = (it >> 1) % 6, half = it / 12;
+    // group (half, kb): unit tiles ut = 2 half + u (u = 0, 1), hi row 9 + (kb * 4 + ut) * 2, lo' row behind it; six
+    // MFMAs (hi hi) u0 u1 -> a, (hi lo') u0 u1 and (lo' hi) u0 u1 -> l: accumulators alternate.  The hi rows of the next group are requested at the top of a group, its own lo rows as well.
+    auto row_of = [](int gi, int u, int term) {
+      const int half = gi / 6, kb = gi % 6;
       return (9 + (kb * 4 + 2 * half + u) * 2 + term) * 64;
     };
     const float ig = gs.inv;
-    uint4 rh[PF], rl[PF];
+    uint4 RH[2][2], RL[2];
     SPLIT_PRIO_BURST();
-#pragma unroll
-    for (int e = 0; e < PF; ++e) {
-      rh[e] = tw[row_of(e, 0)];
-      rl[e] = tw[row_of(e, 1)];
-    }
+    RH[0][0] = tw[row_of(0, 0, 0)];
+    RH[0][1] = tw[row_of(0, 1, 0)];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      f32x4 a[2] = {zero4(), zero4()}, l1[2] = {zero4(), zero4()}, l2[2] = {zero4(), zero4()};
+      f32x4 a[2] = {zero4(), zero4()}, l[2] = {zero4(), zero4()};
 #pragma unroll
       for (int kb = 0; kb < 6; ++kb) {
+        const int gi = half * 6 + kb;
         const h16x8 bh = kb < 4 ? gs.rz_hi[kb < 4 ? kb : 0] : gs.gn_hi[kb < 4 ? 0 : kb - 4];
         const h16x8 bl = kb < 4 ? gs.rz_lo[kb < 4 ? kb : 0] : gs.gn_lo[kb < 4 ? 0 : kb - 4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int it = (half * 6 + kb) * 2 + u;
-          const uint4 wh = rh[it % PF], wo = rl[it % PF];
-          if (it + PF < NIT) {
-            rh[it % PF] = tw[row_of(it + PF, 0)];
-            rl[it % PF] = tw[row_of(it + PF, 1)];
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          a[u] = mfmah(as_h8(wh), bh, a[u]);
-          l1[u] = mfmah(as_h8(wh), bl, l1[u]);
-          if (RIP_SPLIT_MERGE_LO)
-            l1[u] = mfmah(as_h8(wo), bh, l1[u]);
-          else
-            l2[u] = mfmah(as_h8(wo), bh, l2[u]);
+        RL[0] = tw[row_of(gi, 0, 1)];
+        RL[1] = tw[row_of(gi, 1, 1)];
+        if (gi + 1 < 12) {
+          RH[(gi + 1) & 1][0] = tw[row_of(gi + 1, 0, 0)];
+          RH[(gi + 1) & 1][1] = tw[row_of(gi + 1, 1, 0)];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        a[0] = mfmah(as_h8(RH[gi & 1][0]), bh, a[0]);
+        a[1] = mfmah(as_h8(RH[gi & 1][1]), bh, a[1]);
+        l[0] = mfmah(as_h8(RH[gi & 1][0]), bl, l[0]);
+        l[1] = mfmah(as_h8(RH[gi & 1][1]), bl, l[1]);
+        l[0] = mfmah(as_h8(RL[0]), bh, l[0]);
+        l[1] = mfmah(as_h8(RL[1]), bh, l[1]);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        dh[2 * half + u] = dh[2 * half + u] + (a[u] + (RIP_SPLIT_MERGE_LO ? l1[u] : l1[u] + l2[u]) * LO_INV) * ig;
+      for (int u = 0; u < 2; ++u) dh[2 * half + u] = dh[2 * half + u] + (a[u] + l[u] * LO_INV) * ig;
     }
     SPLIT_PRIO_VALU();
   }

@@ -288,8 +288,14 @@ hipError_t gemm(bool ta, bool tb, const float* A, int lda, const float* B, int l
   }
   // 16-byte loads need the contiguous dimension of both stored operands to be whole groups of four floats
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // ... and the buffer loads address an operand through a 32-bit byte offset with GEMM_OOB as the "outside" value: an
+  // operand of 2 GiB or more (features.2's [B*2500, 96] activations from B ~ 2237) would wrap in-range offsets past the
+  // descriptor's clamped size (silent zeros) or put GEMM_OOB inside it — such a call takes the predicated 64-bit
+  // pointer path instead (correct at any size, slower)
+  const size_t a_bytes = ((size_t)((ta ? K : M) - 1) * lda + (ta ? M : K)) * sizeof(float);
+  const size_t b_bytes = ((size_t)((tb ? N : K) - 1) * ldb + (tb ? K : N)) * sizeof(float);
   const bool vec = lda % 4 == 0 && ldb % 4 == 0 && al16(A) && al16(B) && (ta ? M % 4 == 0 : K % 4 == 0) &&
-                   (tb ? K % 4 == 0 : N % 4 == 0);
+                   (tb ? K % 4 == 0 : N % 4 == 0) && a_bytes < (size_t)GEMM_OOB && b_bytes < (size_t)GEMM_OOB;
   if (ta && tb)
     gemm_shape<true, true>(vec, bn, grid, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, accumulate);
   else if (ta)

@@ -16,8 +16,13 @@ def pytest_configure(config):
   # GPU; with the objects cached this is a hash check).  The PRODUCT still fails loudly without the library.
   lib = os.path.join(ROOT, "oatomobile_amd", "librip_hip.so")
   if not os.path.exists(lib):
-    import __graft_entry__
-    __graft_entry__.build()
+    try:
+      import __graft_entry__
+      __graft_entry__.build()
+    except Exception as e:  # no hipcc here / a compiler that rejects a flag: the oracle-only tests must still run
+      config._rip_build_error = "%s: %s" % (type(e).__name__, e)
+      sys.stderr.write("conftest: building librip_hip.so failed (%s); tests that load the library will fail, the "
+                       "oracle / golden tests still run\n" % config._rip_build_error)
 
 
 @pytest.fixture(scope="session")

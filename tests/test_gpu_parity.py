@@ -709,24 +709,53 @@ def _scaled_flow_models(seeds, wscale, dev):
   return hips, refs
 
 
+def _geomean(xs):
+  return float(np.exp(np.mean(np.log(np.maximum(np.asarray(xs, np.float64), 1e-30)))))
+
+
 @pytest.mark.parametrize("zscale,wscale", [(1e-3, 1.0), (1.0, 1.0), (1e2, 1.0), (1e3, 1.0), (1.0, 0.1), (1.0, 10.0), (5e3, 1.0)])
 def test_split_kernel_operand_ranges(dev, zscale, wscale):
   """the split-f16 kernel carries hidden states as two binary16 terms UNSCALED (|h| <= max(1, |z|)) —
   every other test drives it with O(1) z and weights.  One teacher-forced Adam step (algorithm MA: every model's adjoint
-  reaches the gradient, no arg-best ties) against the oracle with z scaled by 1e-3 .. 1e3 (lo' terms near the subnormal
+  reaches the gradient, no arg-best ties) against the oracle with z scaled by 1e-3 .. 1e3 (low terms near the subnormal
   range / hi terms in the thousands), flow weights x0.1 / x10 (saturated gates) and goals 100 m away.  Bar: 1e-4 relative
   to max(1, |posterior|) (gradients: to the candidate's largest entry) — or, where the conditioning of the inputs puts
   that out of reach of fp32 arithmetic itself, no worse than twice what the fp32-MFMA kernel (`phase`) reaches on the
   same launch.  z x 5e3 (max |z| ~ 2e4) is past the limit the split kernel accepts (2^14; binary16 ends at 65504): its
   prefix kernel raises the operand-range word, the split kernel returns and the fp32-MFMA kernel queued behind it runs
   the step — bit for bit the fp32 kernel's result, no silent inf.
+  Round 5: in the ill-conditioned cases (the fp32 kernel itself beyond 1e-4) the statistic — a MAXIMUM over 3 x 128
+  candidates of an error the search amplifies ~1e5-fold — moves by an order of magnitude from one input seed to the
+  next for ANY kernel: round 4's kernel, which passed on seed 11, is at 3.5x / 7.8x the fp32 kernel's posterior /
+  gradient error on seed 12 (profiles/r5/range_seeds_v1.log; the logarithm of the ratio scatters with sigma ~ 1).  Those
+  cases therefore run SIX seeds and gate the geometric mean of (split error / fp32-kernel error) at 2 (measured over
+  seeds 11..16 at weights x 10: 1.02 / 1.15 for round 4's kernel, 1.34 / 1.06 for round 5's), every single seed at 30x
+  (3.4 sigma): the defect this gate exists for — round 5's first forward step left the WEIGHTS' low terms unscaled,
+  2^-24-quantised — was 780x on the gradients at z x 100 and fails both.
   Found with this test and fixed: `pow2_scale` overflowed to inf for candidates whose gate gradients had all but
   vanished (NaN gradients at z x 1e3), and `goal_ll` returned -inf at |y| ~ 5e4 (all kernels; flow_math.h)."""
+  first = _operand_range_case(dev, zscale, wscale, 11)
+  e_post, e_grad = first
+  if max(e_post["phase"], e_grad["phase"]) <= 1e-4 or zscale >= 5e3:  # well conditioned (or the guard case): one seed, strict
+    assert e_post["split"] <= max(1e-4, 2.0 * e_post["phase"])
+    assert e_grad["split"] <= max(1e-4, 2.0 * e_grad["phase"])
+    return
+  runs = [first] + [_operand_range_case(dev, zscale, wscale, sd) for sd in (12, 13, 14, 15, 16)]
+  for name, idx in (("posteriors", 0), ("gradients", 1)):
+    ratios = [max(r[idx]["split"], 1e-4) / max(r[idx]["phase"], 1e-4) for r in runs]
+    print("  %s: split / fp32-kernel error over seeds 11..16: %s, geometric mean %.2f" %
+          (name, " ".join("%.2f" % v for v in ratios), _geomean(ratios)))
+    assert _geomean(ratios) <= 2.0 and max(ratios) <= 30.0, (name, ratios)
+
+
+def _operand_range_case(dev, zscale, wscale, seed):
+  """One teacher-forced MA step of the split and the fp32-MFMA kernel against the oracle; returns the two kernels' largest
+  relative posterior / gradient errors over three observations."""
   from oatomobile_amd import _lib, RIPAgent
   from oracle import reference_cpu as O
   K, N, S, algo = 3, 128, 24, "MA"  # S x N = 3072 >= 2304: what `auto` would give the split kernel as well
   hips, refs = _scaled_flow_models([300 + k for k in range(K)], wscale, dev)
-  rng = np.random.default_rng(11)
+  rng = np.random.default_rng(seed)
   z_np = (np.abs(rng.normal(size=(K, S, 64))) * zscale).astype(np.float32)  # a ReLU output: non-negative
   z_np[:, :, ::7] = 0.0
   goal_np = (np.cumsum(np.abs(rng.normal(size=(S, 10, 2))) * 2.0, axis=1) + 100.0).astype(np.float32)
@@ -762,10 +791,9 @@ def test_split_kernel_operand_ranges(dev, zscale, wscale):
     for name, post, grad in (("split", post_h, grad_h), ("phase", post_p, grad_p)):
       e_post[name] = max(e_post[name], float((np.abs(post[b] - post_o) / np.maximum(1.0, np.abs(post_o))).max()))
       e_grad[name] = max(e_grad[name], float((np.abs(grad[b] - grad_o) / gmax).max()))
-  print("z x %g, flow weights x %g: relative error of the posteriors split %.3g / fp32 kernel %.3g, of the gradients %.3g / %.3g" %
-        (zscale, wscale, e_post["split"], e_post["phase"], e_grad["split"], e_grad["phase"]))
-  assert e_post["split"] <= max(1e-4, 2.0 * e_post["phase"])
-  assert e_grad["split"] <= max(1e-4, 2.0 * e_grad["phase"])
+  print("z x %g, flow weights x %g, seed %d: relative error of the posteriors split %.3g / fp32 kernel %.3g, of the gradients %.3g / %.3g" %
+        (zscale, wscale, seed, e_post["split"], e_post["phase"], e_grad["split"], e_grad["phase"]))
+  return e_post, e_grad
 
 
 def test_g7_dim_forward(golden, dev):
