@@ -17,8 +17,8 @@
 // `a + l * 2^-11` combine and one multiply per split pair — a wave's time here is the SUM of its matrix-pipe cycles,
 // 4 cycles per vector instruction and 16 per transcendental (MFMAs and vector work of ONE wave do not overlap,
 // DESIGN_HISTORY §4.1), so instructions are what there is to remove.  (Packing the r / z rows pre-multiplied by -log2(e)
-// saves two more multiplies per unit pair and measured no faster: 2.654 vs 2.640 ms; not kept.)  The ADJOINT side keeps
-// round 3's two accumulators, see LO_SCALE below.
+// saves two more multiplies per unit pair and measured no faster: 2.654 vs 2.640 ms; not kept.)  The ADJOINT side: see
+// TW_SHIFT below.
 // The weights are split on the host (flow_split_pack.h); activations / gradients are split here, per candidate:
 //   * hidden states (|h| <= max(1, |z|)) and the head's hidden layer are split as they are;
 //   * adjoint quantities (unbounded either way) are first scaled by a per-candidate power of two that puts the
@@ -63,16 +63,17 @@ struct BSplit {
   h16x8 hs[2];  // hi * 2^-11 (forward states only): the B operand of the (Wlo' x hi) product, see the head of this file
 };
 
-// ADJOINT operands keep round 3's scaled low term, lo' = f16((x - hi) 2^11) on both sides (transposed weight rows, gate
-// gradients), with the two lo' products in a second accumulator: a gradient vector is scaled by ONE power of two per
-// candidate and its entries span many binades (saturated gates: r (1 - r) from 0.25 down to 1e-30) — entries 2^-14 below
-// the largest would keep only their hi bits without the 2^11, and at |z| ~ 100, where the search amplifies rounding
-// by ~1e5 (the fp32 kernel is at 4e-3 there), that showed as O(1) gradient errors (test_split_kernel_operand_ranges).
-constexpr float LO_SCALE = 2048.0f;
-constexpr float LO_INV = 1.0f / 2048.0f;
+// ADJOINT side: one accumulator as well, by scaling the WEIGHTS instead of their residuals.  The transposed rows and the
+// W_ih^T table are packed as w * 2^8 (flow_split_pack.h: exact; |w| < 255): hi = f16(256 w), lo = f16(256 w - hi) is then
+// a normal binary16 for every weight that matters, no 2^11 anywhere, and the 2^-8 is folded into the power of two the
+// contraction's result is scaled back by anyway (`pow2_scale`'s inverse: free).  Gradient operands: hi = f16(x s),
+// lo = f16(x s - hi) with the candidate's largest entry at 2^13: entries more than 2^16 below it keep only their hi bits
+// (11), i.e. 2^-27 of the largest — nothing that matters.
+constexpr float LO_INV = 1.0f / 2048.0f;      // forward: hs = hi * 2^-11
+constexpr int TW_SHIFT = 8;                   // transposed rows are packed as w * 2^8
 
-// 8 fp32 -> (hi, lo) packed halves.  SCALED (adjoint quantities): `s` = a power-of-two pre-scale and lo' = lo * 2^11.
-// Per pair: [v_pk_mul (s)], v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add, [v_pk_mul (2^11)], v_cvt_pk_f16_f32.
+// 8 fp32 -> (hi, lo) packed halves, lo = f16(x - hi).  SCALED (adjoint quantities): `s` = a power-of-two pre-scale.
+// Per pair: [v_pk_mul (s)], v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add, v_cvt_pk_f16_f32.
 template <bool SCALED>
 __device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8& lo) {
   u32x4 uh, ul;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8
     if (SCALED) x = x * f32x2{s, s};
     const h16x2 h = __builtin_convertvector(x, h16x2);
     const f32x2 back = __builtin_convertvector(h, f32x2);
-    const h16x2 l = __builtin_convertvector(SCALED ? (x - back) * f32x2{LO_SCALE, LO_SCALE} : x - back, h16x2);
+    const h16x2 l = __builtin_convertvector(x - back, h16x2);
     uh[p] = __builtin_bit_cast(unsigned, h);
     ul[p] = __builtin_bit_cast(unsigned, l);
   }
@@ -105,7 +106,7 @@ __device__ __forceinline__ float qmax(float m) {
   auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
   return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
 }
-// power of two that moves `amax` (>= 0) to [2^13, 2^14), and its inverse; amax == 0 -> 1.  The exponent is clamped at
+// power of two that moves `amax` (>= 0) to [2^13, 2^14), and its inverse (times 2^-TW_SHIFT); amax == 0 -> 1.  The exponent is clamped at
 // -100: a candidate whose gate gradients have all but vanished (saturated gates: r (1 - r) ~ 1e-35 at |z| ~ 1e3) would
 // otherwise ask for 2^130 = inf, and inf * 0 = NaN in every zero entry (found by test_split_kernel_operand_ranges;
 // below 2^-100 the scaled values are simply smaller than 2^13, which loses nothing that matters).
@@ -113,7 +114,7 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
   int e = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) : 14;  // amax = f * 2^e, f in [0.5, 1)
   e = e < -100 ? -100 : e;
   s = __builtin_ldexpf(1.0f, 14 - e);
-  inv = __builtin_ldexpf(1.0f, e - 14);
+  inv = __builtin_ldexpf(1.0f, e - 14 - TW_SHIFT);  // (the transposed weight rows carry 2^TW_SHIFT)
 }
 
 #ifndef RIP_PRIO
@@ -476,8 +477,8 @@ __device__ __forceinline__ float amax8(const float* v, float m) {
 // One step t of the adjoint (flow_phase.hip:adj_step with split-f16 contractions).
 //   dh_t = W1^T da1_t [12 f16 MFMAs, own scale] + W_hh^T (dpr, dpz, dgh_n)_{t+1} [72 f16 MFMAs, `gs` from step t+1]
 //   du_t = W_ih^T (dpr, dpz, dpn)_t [18 f16 MFMAs, the scale of this step's gate gradients]
-// + 2 (W2^T) + 4 (gi_n) fp32 MFMAs: 1824 matrix-pipe cycles (flow_phase.hip: 278 x 32 = 8896).  Adjoint operands keep the
-// 2^11-scaled low terms (above): (hi hi) into one accumulator, both lo' products into a second one.
+// + 2 (W2^T) + 4 (gi_n) fp32 MFMAs: 1824 matrix-pipe cycles (flow_phase.hip: 278 x 32 = 8896).  One accumulator per tile
+// (TW_SHIFT above).
 // tw: this lane's column of the transposed rows; wtab: this lane's entry (q * 2 + (c & 1)) of the W_ih^T table, one
 // group of 8 entries per (kb, term); wl: the forward rows (gi_n's k-step).  LASTSTEP (t = 1): nothing consumes the
 // gate gradients as W_hh^T operands any more.
@@ -571,25 +572,25 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     h16x8 ah, al;
     split8<true>(da1r, sa, ah, al);
     SPLIT_PRIO_BURST();
-    // rows 1 + ut * 2 (hi), 2 + ut * 2 (lo'); term by term, so that an accumulator is touched every fourth MFMA
-    f32x4 a[4], l[4];
+    // rows 1 + ut * 2 (hi), 2 + ut * 2 (lo); term by term, so that an accumulator is touched every fourth MFMA
+    f32x4 a[4];
 #pragma unroll
     for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(tw[(1 + ut * 2) * 64]), ah, zero4());
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(tw[(1 + ut * 2) * 64]), al, zero4());
+    for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(tw[(1 + ut * 2) * 64]), al, a[ut]);
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) l[ut] = mfmah(as_h8(tw[(2 + ut * 2) * 64]), ah, l[ut]);
+    for (int ut = 0; ut < 4; ++ut) a[ut] = mfmah(as_h8(tw[(2 + ut * 2) * 64]), ah, a[ut]);
     SPLIT_PRIO_VALU();
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut) dh[ut] = (a[ut] + l[ut] * LO_INV) * ia;
+    for (int ut = 0; ut < 4; ++ut) dh[ut] = a[ut] * ia;
   }
   // ---- part 2: W_hh^T (dpr, dpz, dgh_n)_{t+1}: 6 K blocks x 4 unit tiles, rows 9 + (kb * 4 + ut) * 2 + term ----
   if (!FIRST) {
     // dh'_{t+1} z_{t+1} joins here, before the big contraction, so that its 16 registers are free during it
 #pragma unroll
     for (int i = 0; i < 16; ++i) dh[i >> 2][i & 3] += dhz[i];
-    // group (half, kb): unit tiles ut = 2 half + u (u = 0, 1), hi row 9 + (kb * 4 + ut) * 2, lo' row behind it; six
-    // MFMAs (hi hi) u0 u1 -> a, (hi lo') u0 u1 and (lo' hi) u0 u1 -> l: accumulators alternate.  The hi rows of the next group are requested at the top of a group, its own lo rows as well.
+    // group (half, kb): unit tiles ut = 2 half + u (u = 0, 1: 8 accumulator registers), hi row 9 + (kb * 4 + ut) * 2, lo
+    // row behind it; six MFMAs (hi hi) u0 u1, (hi lo) u0 u1, (lo hi) u0 u1: the two accumulators alternate.  The hi rows of the next group are requested at the top of a group, its own lo rows as well.
     auto row_of = [](int gi, int u, int term) {
       const int half = gi / 6, kb = gi % 6;
       return (9 + (kb * 4 + 2 * half + u) * 2 + term) * 64;
@@ -601,7 +602,7 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     RH[0][1] = tw[row_of(0, 1, 0)];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      f32x4 a[2] = {zero4(), zero4()}, l[2] = {zero4(), zero4()};
+      f32x4 a[2] = {zero4(), zero4()};
 #pragma unroll
       for (int kb = 0; kb < 6; ++kb) {
         const int gi = half * 6 + kb;
@@ -616,13 +617,13 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
         __builtin_amdgcn_sched_barrier(0);
         a[0] = mfmah(as_h8(RH[gi & 1][0]), bh, a[0]);
         a[1] = mfmah(as_h8(RH[gi & 1][1]), bh, a[1]);
-        l[0] = mfmah(as_h8(RH[gi & 1][0]), bl, l[0]);
-        l[1] = mfmah(as_h8(RH[gi & 1][1]), bl, l[1]);
-        l[0] = mfmah(as_h8(RL[0]), bh, l[0]);
-        l[1] = mfmah(as_h8(RL[1]), bh, l[1]);
+        a[0] = mfmah(as_h8(RH[gi & 1][0]), bl, a[0]);
+        a[1] = mfmah(as_h8(RH[gi & 1][1]), bl, a[1]);
+        a[0] = mfmah(as_h8(RL[0]), bh, a[0]);
+        a[1] = mfmah(as_h8(RL[1]), bh, a[1]);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) dh[2 * half + u] = dh[2 * half + u] + (a[u] + l[u] * LO_INV) * ig;
+      for (int u = 0; u < 2; ++u) dh[2 * half + u] = dh[2 * half + u] + a[u] * ig;
     }
     SPLIT_PRIO_VALU();
   }
@@ -715,8 +716,8 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
     ub = mfmah(wo, bh, ub);
   }
   SPLIT_PRIO_VALU();
-  carry0 = c0 + (ua[0] + (ul[0] + ub[0]) * LO_INV) * ig;
-  carry1 = c1 + (ua[1] + (ul[1] + ub[1]) * LO_INV) * ig;
+  carry0 = c0 + (ua[0] + (ul[0] + ub[0])) * ig;  // (three accumulators: one would make the 18 MFMAs a dependent chain)
+  carry1 = c1 + (ua[1] + (ul[1] + ub[1])) * ig;
 }
 
 // adjoint pass of the current model (flow_phase.hip:pass_backward)

@@ -16,8 +16,9 @@
 
 namespace rip {
 
-constexpr float SPLIT_LO_SCALE = 2048.0f;          // 2^11
+constexpr float SPLIT_LO_SCALE = 2048.0f;          // 2^11: low terms of the FORWARD rows
 constexpr float SPLIT_LO_INV = 1.0f / 2048.0f;
+constexpr float SPLIT_TW_SCALE = 256.0f;           // 2^8: the TRANSPOSED rows and the W_ih^T table hold w * 2^8, low terms unscaled
 
 inline uint16_t split_f16_bits(float v) {
   const _Float16 h = (_Float16)v;  // round to nearest even
@@ -31,6 +32,14 @@ inline void split_f16(float w, uint16_t* hi, uint16_t* lo) {
   *hi = split_f16_bits((float)h);
   *lo = split_f16_bits(r);
 }
+// adjoint operands (round 5, flow_split_dev.h TW_SHIFT): 256 w = hi + lo — the residual of a weight of ordinary size is a
+// NORMAL binary16 without a scale of its own, so all three products of a tile share one accumulator
+inline void split_f16_tw(float w, uint16_t* hi, uint16_t* lo) {
+  const float ws = w * SPLIT_TW_SCALE;  // exact
+  const _Float16 h = (_Float16)ws;
+  *hi = split_f16_bits((float)h);
+  *lo = split_f16_bits(ws - (float)h);
+}
 
 // `mw` = the fp32 operand blob of the MFMA kernels (MW_SIZE floats, fold_and_pack): its fp32 rows (input / bias
 // k-steps, b1, W2, b2, W2^T) are reused as they are.  Reference tensors as in fold_and_pack.  Output: MH_SIZE dwords.
@@ -41,9 +50,9 @@ inline void pack_split_operands(const float* mw, const float* wih, const float* 
     uint32_t& d = out[row_base_dw + (size_t)lane * 4 + (i >> 1)];
     d = (i & 1) ? ((d & 0x0000ffffu) | ((uint32_t)v << 16)) : ((d & 0xffff0000u) | v);
   };
-  auto put2 = [&](size_t row_hi, int lane, int i, float w) {  // hi row at row_hi, lo' row right behind it
+  auto put2 = [&](size_t row_hi, int lane, int i, float w) {  // hi row at row_hi, lo' (forward) / lo (transposed) row right behind it
     uint16_t h, l;
-    split_f16(w, &h, &l);
+    if (row_hi >= (size_t)MHF_ROWS) split_f16_tw(w, &h, &l); else split_f16(w, &h, &l);
     put(row_hi * 256, lane, i, h);
     put((row_hi + 1) * 256, lane, i, l);
   };
@@ -78,7 +87,7 @@ inline void pack_split_operands(const float* mw, const float* wih, const float* 
       for (int par = 0; par < 2; ++par)
         for (int i = 0; i < 8; ++i) {
           uint16_t h, l;
-          split_f16(wih[gate_row(8 * kb + i, q) * 2 + par], &h, &l);
+          split_f16_tw(wih[gate_row(8 * kb + i, q) * 2 + par], &h, &l);
           const size_t e_hi = tab + (size_t)((kb * 2 + 0) * 8 + q * 2 + par) * 4;
           const size_t e_lo = tab + (size_t)((kb * 2 + 1) * 8 + q * 2 + par) * 4;
           uint32_t& dh = out[e_hi + (i >> 1)];
