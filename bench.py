@@ -471,8 +471,7 @@ def main():
       run = (sign * tp).cummax(dim=1).values  # running best over models 0..k
       take = (sign * tp[:, 1:]) > run[:, :-1]  # [S,K-1,B,N]: strictly better than every earlier model
       laid_out = float(take.view(S, K - 1, B, N // 16, 16).any(-1).sum().item())  # with the candidates as laid out
-      # what the timed (trace-free) launch really executes: the kernel regroups a workgroup's candidates by selected
-      # model between Adam steps, so the count comes from its own counter (rip_search_stats)
+      # what the timed (trace-free) launch really executes: the kernel's own counter (rip_search_stats)
       import ctypes
       cnt = ctypes.c_uint64(0)
       _lib.check(lib.rip_search_stats(h, None, 1))

@@ -309,12 +309,9 @@ int rip_train_num_layers(const rip_trainer* t);
  *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
  *     features.17 / 18 always run layer by layer.  auto = everything, the tile kernel only when the call carries
  *     >= 64 (model, observation) pairs (an explicit count uses it regardless).
- *   RIP_OPT_SEARCH_REGROUP (default 0): 1 = the split-f16 kernel regroups the candidates of a workgroup by the ensemble
- *     member they selected after every Adam step (WCM / BCM, trace-free launches whose workgroups stay inside one
- *     observation), so that a 16-candidate block mostly needs ONE inverse pass's adjoint (1.6 instead of 2.7 per block
- *     and step); a candidate's arithmetic does not depend on its lane, so 0 and 1 give bit-identical plans and best
- *     losses.  Off by default: the workgroup walks the model phases in lockstep, so the launch is no faster (measured
- *     2.82 vs 2.73 ms).
+ *   RIP_OPT_SEARCH_REGROUP: retired in round 5 (rounds 3 / 4: regrouped the candidates of ONE workgroup by selected
+ *     member between Adam steps; bit-identical results, fewer adjoints per block, no faster: the workgroup walks the
+ *     model phases in lockstep).  Accepted, no effect.
  *   RIP_OPT_ENCODER_MEGA (experimental): the fp32 encoder of a small batch as ONE persistent launch instead of 55
  *     dependent ones (a dependent launch costs 4.4-4.8 us whatever it computes): ensemble member k runs on XCD k % 8
  *     only — its activations stay in that XCD's L2 and the barrier between two layers is a counter in that L2 (~1 us

@@ -52,7 +52,6 @@ struct SearchArgs {
   float* trace_x;        // [steps][B][N][8] or nullptr
   float* trace_loss;     // [steps][B][N] or nullptr
   float* trace_grad;     // [steps][B][N][8] dLoss/dx of every Adam step, or nullptr
-  int regroup = 0;       // split kernel: regroup a workgroup's candidates by selected model between Adam steps (RIP_OPT_SEARCH_REGROUP)
   unsigned long long* stats = nullptr;  // device counter: += executed inverse-pass adjoints (phase-sequential kernels), or nullptr
   // Operand-range guard of the split-f16 kernel (hidden states are split into binary16 terms unscaled: |h| <= max(1, |z|)
   // must stay below the binary16 range).  `range_flag` is a device word the split launch zeroes and its prefix kernel

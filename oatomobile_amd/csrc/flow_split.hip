@@ -27,15 +27,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int WPB_MAX = 8;
-constexpr int SORT_FLOATS = 10;  // xv[2], m[2], v[2], x_best[2], loss_best, original candidate index
 constexpr int PARK_F4 = 3 * 64;  // per 16-candidate block: the Adam state of the 8-wave build between its uses
 constexpr int F_ROWS = MHF_ROWS;
 constexpr int T_ROWS = MHT_ROWS;
 #ifndef RIP_REGTAPE
 #define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
-#endif
-#ifndef RIP_SPLIT_SORT
-#define RIP_SPLIT_SORT 1  // regroup the candidates of a workgroup by selected model between Adam steps (development switch)
 #endif
 #ifndef RIP_SPLIT_OVERLAP
 #define RIP_SPLIT_OVERLAP 0  // 1 = register-tape builds request the next model's operands under the current adjoint (measured: 2.81 vs 2.77 ms)
@@ -52,10 +48,6 @@ struct PShared {
   float io[WPB][CB][8];          // per wave: x in, y out (in place)
   float gy[WPB][CB][8];          // per wave: dLoss/dy handed to the F_0 adjoint
   float stape[WPB][2][T][6][CB]; // per wave: per-candidate scalars of the F_0 pass [0] and of the current inverse [1]
-  // regrouping of the workgroup's candidates between Adam steps (SORT, 4- / 2-wave workgroups only: the 8-wave one has
-  // no LDS left): per (slot, q) the Adam state of a candidate, and the model every slot selected in the step
-  float sortbuf[WPB <= 4 ? WPB * CB : 1][4][SORT_FLOATS];
-  unsigned char sortkey[WPB <= 4 ? WPB * CB : 4];
 };
 
 // ---- operand staging: direct global -> LDS DMA, one 1 KB lane-major row per wave instruction ----
@@ -166,21 +158,16 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
 
   // Adam state: lane (c, q) owns latent coordinates 2q, 2q+1 of candidate c
   float xv0 = a.x0[row * 8 + 2 * q], xv1 = a.x0[row * 8 + 2 * q + 1];
-  // SORT (option RIP_OPT_SEARCH_REGROUP, default OFF; WCM / BCM, K > 1, a workgroup's blocks all in ONE observation, no
-  // traces): after every Adam step the workgroup's candidates are regrouped by the model they selected, so that the 16
-  // candidates of a block mostly agree and the block runs the adjoint of ONE inverse pass instead of nearly all of
-  // them (an inverse's adjoint runs for a block as soon as one of its candidates needs it: 2.67 per block and step as
-  // laid out, 1.58 regrouped — the selection is sticky, 93 % of the candidates keep theirs from one step to the next;
-  // tools/dev/adjoint_waste.py).  A candidate's arithmetic does not depend on the lane it sits in, so the results are
-  // bit-identical (tests); `orig` is its index within the observation, where its plan and best loss are written.
-  // MEASURED: it does not pay — 2.82 vs 2.73 ms per launch.  The waves of a workgroup walk the model phases together
-  // (one model's operands in LDS at a time), so a phase lasts as long as its slowest wave: with 64 candidates of one
-  // observation in a workgroup SOME block needs every adjoint, and the blocks that skip one only wait at the barrier.
-  // It would need workgroups that agree as a whole (regrouping across workgroups = a grid-wide exchange per Adam
-  // step) or waves decoupled from the phase barriers.  Kept as an option for that work; the counter it brought
-  // (`rip_search_stats`) is what bench.py counts executed adjoints with.
-  const bool sort_on = !TRACE && RIP_SPLIT_SORT && a.regroup && WPB <= 4 && K > 1 && a.algorithm != ALGO_MA && blocks_per_obs % WPB == 0;
-  int orig = n0 + c;
+  // Adjoints nobody needs (WCM / BCM back-propagate through ONE member per candidate, but a block runs an inverse pass's
+  // adjoint as soon as one of its 16 candidates needs it: 2.4-2.7 per block and step, `rip_search_stats`): two remedies
+  // were built and measured, neither pays at this launch size, neither ships.  Rounds 3 / 4: regrouping a WORKGROUP's 64
+  // candidates by selected member between steps — 1.58 adjoints per block, 2.82 vs 2.73 ms: the waves of a workgroup
+  // walk the model phases together and among 64 candidates of one observation some block needs every adjoint.  Round 5:
+  // one launch per Adam step with ALL candidates of the call binned by selected member in between (1.31 adjoints per
+  // block, 1.74 instead of 2.96 adjoint phases per workgroup) — 2.80-2.95 vs 2.56 ms: per block and step the gathers
+  // of prefix / goal rows of 16 different observations, the state round trip and the binning atomics cost 14.5 k cycles,
+  // the adjoints saved 16.6 k, and every launch ends in a tail (profiles/r5/binned_search_v1.txt).
+  const int orig = n0 + c;
   float am0 = 0.f, am1 = 0.f, av0 = 0.f, av1 = 0.f;
   float xb0 = xv0, xb1 = xv1, lbest = 1000.0f;
   double b1p = 1.0, b2p = 1.0;
@@ -363,31 +350,6 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       }
       if (a.trace_loss != nullptr && q == 0) a.trace_loss[srow] = loss;
     }
-    if (WPB <= 4 && sort_on && step + 1 < S) {
-      constexpr int NC = (WPB <= 4 ? WPB : 1) * CB;
-      const int slot = wave * CB + c;
-      if (q == 0) sh.sortkey[slot] = (unsigned char)ksel;
-      __syncthreads();
-      // stable counting rank of this candidate among the workgroup's NC: candidates with a smaller key, then the
-      // earlier slots with the same key
-      int rank = 0;
-#pragma unroll
-      for (int j4 = 0; j4 < NC / 4; ++j4) {
-        const unsigned w4 = reinterpret_cast<const unsigned*>(sh.sortkey)[j4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int kj = (int)((w4 >> (8 * e)) & 0xffu), j = 4 * j4 + e;
-          rank += (kj < ksel || (kj == ksel && j < slot)) ? 1 : 0;
-        }
-      }
-      float* dst = sh.sortbuf[rank][q];
-      dst[0] = xv0, dst[1] = xv1, dst[2] = am0, dst[3] = am1, dst[4] = av0, dst[5] = av1, dst[6] = xb0, dst[7] = xb1;
-      dst[8] = lbest, dst[9] = __int_as_float(orig);
-      __syncthreads();
-      const float* src = sh.sortbuf[slot][q];
-      xv0 = src[0], xv1 = src[1], am0 = src[2], am1 = src[3], av0 = src[4], av1 = src[5], xb0 = src[6], xb1 = src[7];
-      lbest = src[8], orig = __float_as_int(src[9]);
-    }
     if (K > 1 && S > 0) {
       // model 1's transposed operands for the next step, requested once every wave has left the T-buf
       __syncthreads();
@@ -402,7 +364,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
 #endif
   // plan = F_0(x_best) is in io (rip/agent.py:137)
   if (active) {
-    const size_t orow = (size_t)b * a.N + orig;  // (== row unless the candidates were regrouped)
+    const size_t orow = (size_t)b * a.N + orig;
     if (a.plans != nullptr) {
       a.plans[orow * 8 + 2 * q] = io[c][2 * q];
       a.plans[orow * 8 + 2 * q + 1] = io[c][2 * q + 1];

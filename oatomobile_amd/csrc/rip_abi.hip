@@ -41,7 +41,6 @@ struct rip_handle {
   int encoder_variant = 0;  // RIP_OPT_ENCODER_VARIANT: development / test kernel selections of the bf16 encoder (encoder.h ENC_VAR_*)
   bool kernel_log_on = false;  // RIP_OPT_KERNEL_LOG
   KernelLog klog;              // the encoder kernels of the last rip_encode* / rip_encode_tap* call (rip_kernel_log)
-  int search_regroup = 0;   // split-f16 search: regroup a workgroup's candidates by selected model between Adam steps (measured: no gain)
   bool loaded[RIP_MAX_MODELS] = {false};
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
   size_t buf_floats = 0;
@@ -352,8 +351,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
       return RIP_OK;
     case RIP_OPT_SEARCH_REGROUP:
       REQUIRE(value == 0 || value == 1, "search regroup must be 0 or 1 (got %d)", value);
-      h->search_regroup = value;
-      return RIP_OK;
+      return RIP_OK;  // retired in round 5 (no faster in two rounds of measurements): accepted, no effect
     case RIP_OPT_ENCODER_MEGA:
       REQUIRE(value >= -1 && value <= 1, "encoder_mega must be -1 (auto), 0 or 1 (got %d)", value);
       if (value == 1) {
@@ -674,7 +672,6 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
   a.trace_loss = nullptr;
   a.trace_grad = trace_grad_dev;
   a.stats = h->stats;
-  a.regroup = h->search_regroup;
   // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
   // wave-per-chain kernel has the lower latency for a single observation.  Among the MFMA kernels the phase-sequential
   // one (operands in LDS, two waves per SIMD, any K) is the default; mode 2 keeps the wave-per-model pipeline.
