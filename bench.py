@@ -72,7 +72,7 @@ MFMA_F16 = (16 * 16 * 32 * 2, 16)
 MFMA_F32 = (16 * 16 * 4 * 2, 32)
 PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 256 * 4
-KERNEL_NAMES = {1: "search_kernel (wave-per-chain, fp32 VALU)", 2: "search_mfma2_kernel (fp32 MFMA, wave per model)",
+KERNEL_NAMES = {1: "search_kernel (wave-per-chain, fp32 VALU)", 
                 3: "search_phase_kernel (fp32 MFMA, phase-sequential)", 4: "search_split_kernel (split-f16 MFMA, phase-sequential)"}
 
 

@@ -295,8 +295,7 @@ int rip_train_num_layers(const rip_trainer* t);
  *   RIP_OPT_SEARCH_KERNEL: 0 = auto (the split-f16 phase-sequential kernel when B*N >= 2304 and N % 16 == 0, else
  *     wave-per-chain),
  *     1 = wave-per-chain kernel (lowest latency, any K/N),
- *     2 = MFMA wave-per-model pipeline (16 candidates per wave, wave k = model k; N % 16 == 0, K <= 4; N % 32 == 0
- *         selects its dual-block form, the only one with trace outputs),
+ *     (2 = round 1's fp32-MFMA wave-per-model pipeline: removed in round 5, RIP_EINVAL),
  *     3 = fp32-MFMA phase-sequential kernel (one wave per 16-candidate block runs all K models, operands in LDS, two
  *         waves per SIMD; N % 16 == 0, any K <= 8, trace outputs),
  *     4 = split-f16 phase-sequential kernel: the same decomposition with the GRU / head contractions on
@@ -350,7 +349,7 @@ int rip_encoder_status(rip_handle* h);
 
 /* What rip_search would launch for B observations x N candidates under the handle's current options, and what that
  * launch executes on the matrix cores (bench.py's executed-flops count; rocprofv3 SQ_INSTS_MFMA is the check):
- * out[0] = kernel (1 wave-per-chain, 2 fp32-MFMA wave-per-model, 3 fp32-MFMA phase-sequential, 4 split-f16
+ * out[0] = kernel (1 wave-per-chain, 3 fp32-MFMA phase-sequential, 4 split-f16
  * phase-sequential); for kernels 3 / 4: out[1] = waves per workgroup, then (16x16x32 f16, 16x16x4 fp32) MFMA
  * instructions per 16-candidate block of out[2,3] one forward / inverse pass, out[4,5] the adjoint of an inverse pass,
  * out[6,7] the adjoint of F_0, out[8,9] the prefix step per (model, observation).  n_out >= 10. */

@@ -192,7 +192,7 @@ class RIPAgent(SetPointAgent):
                                max_candidates=self._num_candidates)
     self._versions = [None] * len(self._models)
     self._sync_weights()
-    # "auto" | "chain" (one wave per candidate x model chain) | "mfma" (16 candidates per wave on MFMA)
+    # "auto" | "chain" (one wave per candidate x model chain) | "phase" / "split" (16 candidates per wave on the matrix cores: fp32 MFMA / two-term f16)
     self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS[search_kernel])
     if fused_encoder is None and "RIP_ENCODER_FUSED" in os.environ:
       fused_encoder = int(os.environ["RIP_ENCODER_FUSED"])

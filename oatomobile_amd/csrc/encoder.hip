@@ -1056,7 +1056,7 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
   for (int c = 0; c < 4; ++c) flow[FW_B2 + c] = b2[c];
   std::memcpy(flow.data() + FW_W1, w1, 32 * 64 * sizeof(float));
 
-  // ---- operands of the MFMA search kernel (flow_mfma.hip): lane (m = lane & 15, q = lane >> 4) ----
+  // ---- operands of the MFMA search kernel (flow_phase.hip; the layout is round 1's): lane (m = lane & 15, q = lane >> 4) ----
   mw.assign(MW_SIZE, 0.f);
   auto F = [&](int idx, int lane) -> float& { return mw[(size_t)(idx / 4) * 256 + lane * 4 + (idx & 3)]; };
   auto Bk = [&](int f4, int lane, int comp) -> float& { return mw[MWF_FLOATS + ((size_t)f4 * 64 + lane) * 4 + comp]; };

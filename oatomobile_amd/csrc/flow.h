@@ -17,7 +17,7 @@ constexpr int FW_W2 = 13120;    // [q][64]: W2[2*(j>>5)+q][j & 31]
 constexpr int FW_B2 = 13248;    // [4]
 constexpr int FW_W1 = 13252;    // [32][64] row-major (staged to LDS)
 constexpr int FW_SIZE = 15300;
-// MFMA search kernel operands (flow_mfma.hip): 252 forward values/lane as 63 lane-major float4, then 69
+// fp32-MFMA search kernel operands (flow_phase.hip): 252 forward values/lane as 63 lane-major float4, then 69
 // lane-major float4 of transposed (adjoint) operands.
 constexpr int MWF_FLOATS = 63 * 64 * 4;
 constexpr int MWB_F4 = 69;
@@ -103,10 +103,6 @@ size_t search_lds_bytes(int K);
 // raises a kernel's dynamic-LDS limit to the CU's 160 KiB, once per (kernel, device); thread-safe, any device index
 hipError_t allow_lds(const void* fn);
 int device_cu_count();  // compute units of the current device (cached per device)
-// MFMA-batched variant (16 candidates per wave); needs N % 16 == 0, K <= 4, no traces
-bool search_mfma_supported(const SearchArgs& a);
-size_t search_mfma_tape_bytes(int B, int N, int K);
-hipError_t launch_search_mfma(const SearchArgs& a, const float* mw_all, void* tape, hipStream_t s);
 // phase-sequential variant (flow_phase.hip): one wave per 16-candidate block runs all K models, operands in LDS;
 // N % 16 == 0, any K <= MAX_MODELS, traces supported
 // split-f16 variant (flow_split.hip): the same decomposition with the contractions on v_mfma_f32_16x16x32_f16 and both

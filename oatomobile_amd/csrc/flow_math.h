@@ -1,4 +1,4 @@
-// Scalar device helpers shared by the flow kernels (flow.hip, flow_mfma.hip).
+// Scalar device helpers shared by the flow kernels (flow.hip, flow_phase.hip, flow_split.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

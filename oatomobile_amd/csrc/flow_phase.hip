@@ -1,6 +1,6 @@
 // Phase-sequential MFMA plan search for gfx950: the throughput kernel of RIPAgent.__call__ (rip/agent.py:78-137).
 //
-// Same arithmetic as search_mfma2_kernel (flow_mfma.hip: 16 candidates per wave on v_mfma_f32_16x16x4_f32, hidden
+// Same arithmetic as round 1's wave-per-model kernel (removed in round 5; DESIGN_HISTORY §4.1b: 16 candidates per wave on v_mfma_f32_16x16x4_f32, hidden
 // state in the "H layout", transposed products, the same operand blobs), another decomposition:
 //   * ONE WAVE owns a block of 16 candidates for the whole search and runs ALL K models on it, one after the other:
 //       F_0 -> for k = 1..K-1: inverse_k, adjoint_k -> ensemble aggregation -> adjoint-F_0 + Adam.
@@ -152,7 +152,7 @@ struct StepTape {
 enum { SAVE_NONE = 0, SAVE_TAPE = 1, SAVE_TAPE_NOHP = 2, SAVE_REGS = 3 };
 
 // One GRU + head step for 16 candidates with the 251 A operands read, tile by tile, from `wl` = this lane's column of
-// the 63 lane-major float4 rows of the F-buf (value i of the MW order of flow_mfma.hip sits in row i / 4, component
+// the 63 lane-major float4 rows of the F-buf (value i of the MW order, fold_and_pack, sits in row i / 4, component
 // i % 4).  Same MFMA order per accumulator as fwd_step there: bitwise the same results.
 // SAVE_TAPE: the step's tape goes to `tape` (global); SAVE_TAPE_NOHP: without hprev (step 1: hprev is the prefix);
 // SAVE_REGS: it stays in `tr` (the last inverse step is consumed by its adjoint right away).

@@ -5,7 +5,7 @@
 // (22 significant bits; the 2^11 keeps the residual in the normal range of binary16, so nothing depends on how the
 // matrix cores treat subnormal inputs).  An operand row is 64 lanes x 16 bytes = 8 halves per lane = one A operand of
 // v_mfma_f32_16x16x32_f16; the hi and lo' rows of a tile are separate rows.  Unit order inside a K block follows the
-// "H layout" of flow_phase.hip / flow_mfma.hip: lane (m = lane & 15, q = lane >> 4), half i <-> hidden unit
+// "H layout" of flow_phase.hip: lane (m = lane & 15, q = lane >> 4), half i <-> hidden unit
 // 16 * (2 kb + (i >> 2)) + 4 q + (i & 3), so the 16 fp32 values a lane holds of a 64-unit vector ARE its two B operands.
 #pragma once
 #include <cstdint>

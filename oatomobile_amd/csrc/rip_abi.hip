@@ -35,7 +35,7 @@ struct rip_handle {
   uint32_t* split_w = nullptr;  // [K][MH_SIZE] operands of the split-f16 search kernel
   void* tape = nullptr;     // scratch of the MFMA search kernel
   size_t tape_bytes = 0;
-  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 2 MFMA wave-per-model pipeline, 3 fp32-MFMA phase-sequential,
+  int search_mode = 0;      // 0 auto, 1 wave-per-chain (VALU), 3 fp32-MFMA phase-sequential,
                             // 4 split-f16 phase-sequential
   int encoder_fused = -1;   // leading inverted-residual blocks run fused (0 = none, 17 = all); -1 = auto by batch
   int encoder_variant = 0;  // RIP_OPT_ENCODER_VARIANT: development / test kernel selections of the bf16 encoder (encoder.h ENC_VAR_*)
@@ -257,9 +257,7 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     (void)hipMemset(h->stats, 0, 4 * sizeof(float));
   }
   // scratch of the MFMA search kernels (adjoint tape, prefix table): 0 when neither can ever run for this handle
-  h->tape_bytes = search_mfma_tape_bytes(max_batch, max_candidates, K);
-  if (search_phase_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
-    h->tape_bytes = search_phase_scratch_bytes(max_batch, max_candidates, K);
+  h->tape_bytes = search_phase_scratch_bytes(max_batch, max_candidates, K);
   if (search_split_scratch_bytes(max_batch, max_candidates, K) > h->tape_bytes)
     h->tape_bytes = search_split_scratch_bytes(max_batch, max_candidates, K);
   if (h->tape_bytes > 0) {
@@ -342,7 +340,9 @@ int rip_set_option(rip_handle* h, int option, int value) {
   REQUIRE(h != nullptr, "handle is NULL");
   switch (option) {
     case RIP_OPT_SEARCH_KERNEL:
-      REQUIRE(value >= 0 && value <= 4, "search kernel %d not in {0 auto, 1 wave-per-chain, 2 mfma, 3 phase, 4 split}", value);
+      REQUIRE(value != 2, "search kernel 2 (round 1's fp32-MFMA wave-per-model pipeline) was removed in round 5: no default "
+              "reached it since round 2; use 3 (fp32-MFMA phase-sequential) or 4 (split-f16)");
+      REQUIRE(value >= 0 && value <= 4, "search kernel %d not in {0 auto, 1 wave-per-chain, 3 phase, 4 split}", value);
       h->search_mode = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_FUSED:
@@ -618,8 +618,8 @@ int rip_cil_decode(const float* feat_dev, const float* vec_dev, const float* wei
 int rip_cil_blob_floats(void) { return cil_blob_floats(); }
 
 // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
-// wave-per-chain kernel has the lower latency for a single observation.  1 = wave-per-chain, 2 = fp32-MFMA wave-per-model
-// pipeline, 3 = fp32-MFMA phase-sequential, 4 = split-f16 phase-sequential (the default of large launches).
+// wave-per-chain kernel has the lower latency for a single observation.  1 = wave-per-chain, 3 = fp32-MFMA
+// phase-sequential, 4 = split-f16 phase-sequential (the default of large launches).
 static int pick_search_kernel(const rip_handle* h, int B, int N) {
   if (h->search_mode != 0) return h->search_mode;
   const bool big = (size_t)B * N >= 2304;
@@ -674,17 +674,14 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
   a.stats = h->stats;
   // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
   // wave-per-chain kernel has the lower latency for a single observation.  Among the MFMA kernels the phase-sequential
-  // one (operands in LDS, two waves per SIMD, any K) is the default; mode 2 keeps the wave-per-model pipeline.
+  // ones (operands in LDS, any K) are the default of large launches.
   // crossover measured at K = 4, N = 128: the chain kernel costs 64 us per observation, the phase kernel 1.1 ms per
   // launch up to one workgroup per CU (B = 16: 1.02 vs 1.11 ms, B = 32: 2.03 vs 1.11 ms)
   const int kernel = pick_search_kernel(h, B, N);
   if ((kernel == 3 && !search_phase_supported(a)) || (kernel == 4 && !search_split_supported(a)))
     return fail(RIP_EINVAL, "phase-sequential MFMA search needs N%%16==0 and K<=%d (K=%d N=%d)", RIP_MAX_MODELS, h->K, N);
-  if (kernel == 2 && !search_mfma_supported(a))
-    return fail(RIP_EINVAL, "MFMA search kernel needs K<=4 and N%%16==0 (N%%32==0 with trace outputs) (K=%d N=%d)", h->K, N);
   if (kernel != 1) {
-    const size_t need = kernel == 4 ? search_split_scratch_bytes(B, N, h->K)
-                                    : (kernel == 3 ? search_phase_scratch_bytes(B, N, h->K) : search_mfma_tape_bytes(B, N, h->K));
+    const size_t need = kernel == 4 ? search_split_scratch_bytes(B, N, h->K) : search_phase_scratch_bytes(B, N, h->K);
     if (need > h->tape_bytes)
       return fail(RIP_ESTATE, "MFMA search scratch for B=%d N=%d needs %zu B, rip_create sized %zu B (max_batch=%d x "
                   "max_candidates=%d)", B, N, need, h->tape_bytes, h->max_batch, h->max_candidates);
@@ -699,10 +696,9 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
         a.range_flag = nullptr;
         HIP_TRY(launch_search_phase(a, h->mfma_w, h->tape, (hipStream_t)stream));
       }
-    } else if (kernel == 3)
+    } else {
       HIP_TRY(launch_search_phase(a, h->mfma_w, h->tape, (hipStream_t)stream));
-    else
-      HIP_TRY(launch_search_mfma(a, h->mfma_w, h->tape, (hipStream_t)stream));
+    }
   } else {
     HIP_TRY(launch_search(a, (hipStream_t)stream));
   }

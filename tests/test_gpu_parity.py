@@ -607,12 +607,11 @@ def test_g6_rip_reference_recipe(golden, dev, algo):
     np.testing.assert_allclose(out, g["out30_" + tag], atol=TOL)
 
 
-@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase", "split"])
+@pytest.mark.parametrize("kernel", ["chain", "phase", "split"])
 @pytest.mark.parametrize("algo", ["WCM", "MA", "BCM"])
 def test_g6_search_traces(golden, dev, algo, kernel):
   """Per-step posteriors, latents, best loss and plan of BOTH search kernels vs the instrumented reference loop
-  (golden G6, from the reference's own objects).  The MFMA-batched kernel searches 32 candidates (its pipelined
-  dual-block form); candidate 0 starts at zeros = the reference start, so its row must follow the reference step for
+  (golden G6, from the reference's own objects).  The matrix-core kernels search 32 candidates; candidate 0 starts at zeros = the reference start, so its row must follow the reference step for
   step at 1e-4."""
   from oatomobile_amd import _lib, RIPAgent
   g = golden("g6_rip.npz")
@@ -642,7 +641,7 @@ def test_g6_search_traces(golden, dev, algo, kernel):
     assert torch.isfinite(tg).all()
 
 
-@pytest.mark.parametrize("kernel", ["chain", "mfma", "phase", "split"])
+@pytest.mark.parametrize("kernel", ["chain", "phase", "split"])
 @pytest.mark.parametrize("algo,K", [("WCM", 4), ("MA", 3), ("BCM", 2)])
 def test_teacher_forced_steps_vs_oracle(dev, kernel, algo, K):
   """Removes trajectory amplification from the kernel-vs-oracle comparison: every Adam step of the ORACLE's
@@ -833,8 +832,6 @@ def test_g8_scores(golden, dev):
 
 @pytest.mark.parametrize("kernel,algo,K,N", [("chain", "WCM", 4, 128), ("chain", "MA", 3, 16), ("chain", "BCM", 2, 5),
                                              ("chain", "WCM", 1, 7), ("chain", "WCM", 8, 8),
-                                             ("mfma", "WCM", 4, 128), ("mfma", "MA", 3, 16), ("mfma", "BCM", 2, 32),
-                                             ("mfma", "WCM", 1, 16),
                                              ("phase", "WCM", 4, 128), ("phase", "MA", 3, 16), ("phase", "BCM", 2, 48),
                                              ("phase", "WCM", 1, 16), ("phase", "WCM", 8, 32), ("phase", "MA", 5, 16),
                                              ("split", "WCM", 4, 128), ("split", "MA", 3, 16), ("split", "BCM", 2, 48),
@@ -853,10 +850,9 @@ def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
   plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
   _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"],
                       ob["goal"], x0=agent._x0_rows.cpu(), algorithm=algo)
-  # the kernel's own per-step latents next to the oracle's, so that an outlier can be dated (the wave-per-model MFMA
-  # kernel only traces in its dual-block form, N % 32 == 0)
+  # the kernel's own per-step latents next to the oracle's, so that an outlier can be dated
   x_h = None
-  if kernel != "mfma" or N % 32 == 0:
+  if True:
     from oatomobile_amd import _lib
     zz = torch.empty(K, 1, 64, device=dev)
     lib = _lib.load()
@@ -871,7 +867,7 @@ def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
                  plan.cpu().numpy()[0], res["plan"].numpy(), x_h=x_h, x_o=res["trace_x"].numpy())
 
 
-def test_mfma_kernel_matches_chain_kernel(dev):
+def test_mfma_kernels_match_chain_kernel(dev):
   """The two search kernels are the same algorithm: per-candidate best losses and plans agree (B=3, N=32)."""
   from oatomobile_amd import RIPAgent
   models = [hip_model(300 + k, dev) for k in range(4)]
@@ -880,17 +876,17 @@ def test_mfma_kernel_matches_chain_kernel(dev):
   vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
   goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
   out = {}
-  for kern in ("chain", "mfma", "phase", "split"):
+  for kern in ("chain", "phase", "split"):
     agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=32, max_batch=3, seed=9, search_kernel=kern)
     plan, loss = agent.plan_batch(lidar, vec, goal, return_loss=True)
     out[kern] = (plan.cpu().numpy(), loss.cpu().numpy())
-  for kern in ("mfma", "phase", "split"):
+  for kern in ("phase", "split"):
     close = np.abs(out["chain"][1] - out[kern][1]) <= 1e-3 + 1e-4 * np.abs(out["chain"][1])
     print("%s vs chain: %.4f of %d candidates within tolerance" % (kern, close.mean(), close.size))
     assert close.mean() >= 0.99, kern
     np.testing.assert_allclose(out["chain"][0], out[kern][0], atol=TOL, err_msg=kern)
   with pytest.raises(Exception):
-    RIPAgent(None, algorithm="WCM", models=models, num_candidates=5, search_kernel="mfma").plan_batch(
+    RIPAgent(None, algorithm="WCM", models=models, num_candidates=5, search_kernel="phase").plan_batch(
         lidar[:1].contiguous(), vec[:1].contiguous(), goal[:1].contiguous())
 
 
@@ -1175,11 +1171,11 @@ def test_candidate_parallel_halves_equal_whole(dev):
   lidar = torch.stack([torch.from_numpy(o["lidar"]) for o in obs]).to(dev)
   vec = torch.tensor([[*o["velocity"], o["is_at_traffic_light"], o["traffic_light_state"]] for o in obs], device=dev)
   goal = torch.stack([torch.from_numpy(o["goal"][:, :2].copy()) for o in obs]).to(dev)
-  whole = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=11, search_kernel="mfma")
+  whole = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, max_batch=B, seed=11, search_kernel="phase")
   plan_w, loss_w = whole.plan_batch(lidar, vec, goal, return_loss=True)
   recs, losses = [], []
   for r in range(2):
-    cp = D.CandidateParallelRIP(models, N, algorithm="WCM", seed=11, max_batch=B, device=dev, search_kernel="mfma",
+    cp = D.CandidateParallelRIP(models, N, algorithm="WCM", seed=11, max_batch=B, device=dev, search_kernel="phase",
                                 rank=r, world=2)
     loss, plans = cp.local_search(lidar, vec, goal)
     losses.append(loss)
@@ -1976,6 +1972,7 @@ def test_split_kernel_is_deterministic_and_counts_its_adjoints(dev, algo, K, N, 
   out = {}
   for run in (0, 1):
     _lib.check(lib.rip_set_option(h, _lib.OPT_SEARCH_REGROUP, run))  # retired: must be accepted and change nothing
+    assert lib.rip_set_option(h, _lib.OPT_SEARCH_KERNEL, 2) == _lib.RIP_EINVAL and b"removed in round 5" in lib.rip_last_error()
     plan = torch.empty(B, 4, 2, device=dev)
     plans = torch.empty(B, N, 4, 2, device=dev)
     lb = torch.empty(B, N, device=dev)

@@ -17,7 +17,7 @@ def main():
   ap.add_argument("--enc", default="fp32")
   ap.add_argument("--fused", type=int, default=-1, help="RIP_OPT_ENCODER_FUSED (-1 = auto)")
   ap.add_argument("--mega", type=int, default=-1, help="RIP_OPT_ENCODER_MEGA (-1 auto, 0 never, 1 up to 4 observations)")
-  ap.add_argument("--search-kernel", type=int, default=0, help="RIP_OPT_SEARCH_KERNEL (0 auto, 1 chain, 2 mfma, 3 phase, 4 split)")
+  ap.add_argument("--search-kernel", type=int, default=0, help="RIP_OPT_SEARCH_KERNEL (0 auto, 1 chain, 3 phase, 4 split)")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
   dev = torch.device("cuda", 0)
