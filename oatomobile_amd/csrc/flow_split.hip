@@ -33,12 +33,6 @@ constexpr int T_ROWS = MHT_ROWS;
 #ifndef RIP_REGTAPE
 #define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
 #endif
-#ifndef RIP_SPLIT_OVERLAP
-#define RIP_SPLIT_OVERLAP 0  // 1 = register-tape builds request the next model's operands under the current adjoint (measured: 2.81 vs 2.77 ms)
-#endif
-#ifndef RIP_SPLIT_PIPE
-#define RIP_SPLIT_PIPE 0  // 1 = 4- / 2-wave workgroups issue tile up+1's MFMAs ahead of tile up's gate math (measured: 2.82 vs 2.75 ms)
-#endif
 
 template <int WPB>
 struct PShared {
@@ -202,7 +196,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     {
       const Prefix16 pre = load_prefix(pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, q);
       TK_START();
-      const PassOut po = pass_forward<MODE_FWD, false, (WPB <= 4 && RIP_SPLIT_PIPE)>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
+      const PassOut po = pass_forward<MODE_FWD, false, false>(wl, pre, io, stF, tapeF, nullptr, c, q, (unsigned)lane);
       TK_STOP(1);
       __builtin_amdgcn_wave_barrier();
       if (final_pass) break;
@@ -216,15 +210,16 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
 #pragma unroll 1
     for (int k = 1; k < K; ++k) {
       constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
-      // OVERLAP (development switch, off; register-tape builds: the adjoint of an inverse pass never reads the F-buf):
-      // model k+1's forward operands are requested as soon as every wave has finished inverse_k and land under
-      // adjoint_k; its transposed ones are requested once adjoint_k is done and land under inverse_{k+1}.  Same two
-      // barriers per model and nobody waits on a DMA (2.5 k cycles per model: tools/search_ticks.py "barrier-dma"),
-      // yet the launch got SLOWER (2.81 vs 2.77 ms): the waves now wait at barriers placed where their pass lengths
-      // differ most (right behind the data-dependent adjoint) instead of where the DMA wait absorbed that skew.
-      constexpr bool OVERLAP = REGTAPE && RIP_SPLIT_OVERLAP;
+      // (Requesting model k + 1's forward operands under model k's adjoint — the adjoint of a register-tape inverse pass
+      // never reads the F-buf — was built twice.  Rounds 3 / 4: slower, 2.81 vs 2.77 ms; round 5 found why: the compiler
+      // cannot tell an LDS-DMA's destination from any other LDS location and puts s_waitcnt vmcnt(0) in front of the
+      // adjoint's first operand read, i.e. the whole transfer was waited for there.  With the DMA issued from inline
+      // assembly (invisible to that pass, explicit waits at the barriers) the adjoint runs under the transfer — and
+      // the launch takes exactly as long, 2.50 ms: the 4 k cycles per phase at the second barrier are not DMA latency
+      // any more than before, they are the waves waiting for the slowest wave's data-dependent adjoint, wherever the
+      // barrier stands (profiles/r5/overlap_v1.txt).  Not kept.)
       const uint32_t* mhk = mh_all + (size_t)(a.k0 + k) * MH_SIZE;
-      if (!OVERLAP || k == 1) {
+      {
         TK_START();
         __syncthreads();  // every wave is done with the F-buf (F_0 or inverse_{k-1}) and the T-buf (adjoint_{k-1})
         TK_STOP(2);
@@ -239,7 +234,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       TK_START();
       const Prefix16 pre = load_prefix(pre_all + ((size_t)k * a.B + b) * PRE_FLOATS, q);
       StepTape last[3];
-      const PassOut po = pass_forward<MODE_INV, REGTAPE, (WPB <= 4 && RIP_SPLIT_PIPE)>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
+      const PassOut po = pass_forward<MODE_INV, REGTAPE, false>(wl, pre, io, stI, tapeI, last, c, q, (unsigned)lane);
       TK_STOP(4);
       const float qk = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
       if (TRACE && a.trace_post != nullptr && q == 0 && active)
@@ -247,12 +242,6 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       q_sum += qk;
       // rip/agent.py:121-127 as coded: WCM = min_k(-q) = the largest posterior, BCM = the smallest (first on ties)
       const bool take = a.algorithm == ALGO_WCM ? (qk > q_sel) : (qk < q_sel);
-      if (OVERLAP) {
-        TK_START();
-        __syncthreads();  // every wave is done with F-buf(k); T-buf(k) (requested behind adjoint_{k-1}) has landed
-        TK_STOP(2);
-        if (RIP_ABL != 2) load_fbuf(sh, k + 1 < K ? mhk + MH_SIZE : mh0, wave, lane);  // next model's, or next step's F_0
-      }
       if (mean_mode || __any(take)) {
         __builtin_amdgcn_wave_barrier();
         float res[8];
@@ -275,12 +264,6 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
         q_sel = qk;
         ksel = k;
       }
-      if (OVERLAP && k + 1 < K) {
-        TK_START();
-        __syncthreads();  // every wave is done with T-buf(k); F-buf(k+1) has landed
-        TK_STOP(3);
-        if (RIP_ABL != 2) load_tbuf(sh, mhk + MH_SIZE, wave, lane, tid);
-      }
     }
     const float loss = -((mean_mode ? q_sum * inv_k : q_sel) + gl);
     w0 = (mean_mode ? inv_k : (ksel == 0 ? 1.0f : 0.0f)) * a.grad_scale;
@@ -291,8 +274,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
       TK_STOP(6);
       if (RIP_ABL != 2) {
         load_tbuf(sh, mh0, wave, lane, tid);
-        constexpr bool F0_IN_FLIGHT = RIP_REGTAPE && WPB <= 4 && RIP_SPLIT_OVERLAP;  // requested behind inverse_{K-1}
-        if (!F0_IN_FLIGHT) load_fbuf(sh, mh0, wave, lane);  // next step's F_0
+        load_fbuf(sh, mh0, wave, lane);  // next step's F_0 (and the input rows F_0's adjoint recomputes n from)
       }
     }
     // dLoss/dy = -(sum_k w_k dq_k/dy + d gl/dy_T): lane (c, q) fills coordinates 2q, 2q+1

@@ -123,9 +123,6 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
 
 #define SPLIT_PRIO_BURST() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define SPLIT_PRIO_VALU() do { if (RIP_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
-#ifndef RIP_PIPE_VALU
-#define RIP_PIPE_VALU 5  // vector instructions scheduled behind each matrix instruction in the one-wave-per-SIMD build
-#endif
 #ifndef RIP_ABL
 #define RIP_ABL 0  // development only: 1 = no tape loads, 3 = no tape stores (wrong results)
 #endif
