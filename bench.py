@@ -140,6 +140,48 @@ def _encoder_roofline(enc_ms, layerwise_bytes, B, K, C, enc_dtype, measured=None
   return line
 
 
+def _encoder_kernel_times(lib, h_obj, lidar, B, K, C, enc, reps=5):
+  """The encoder block by block from the event timeline (a regression shows up in the driver's run
+  without rocprof): `rip_encode_tap_k` with a NULL destination runs the launch sequence of the SAME (B, K) selection up to
+  conv layer i and stops; the difference of two consecutive stops is the time of the kernel(s) between them, whose
+  names come from the handle's kernel log.  The tail (classifier + merger) is the full encode minus the last stop."""
+  from oatomobile_amd import _lib, arch, transform_visual
+  h = h_obj.raw
+  vis = transform_visual(lidar, channels_last=True)
+  L = len(arch.conv_layers(C))
+  h_obj.set_option(_lib.OPT_KERNEL_LOG, 1)
+  st = torch.cuda.current_stream()
+
+  def timed_us(fn):
+    fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+      a.record(st)
+      fn()
+      b.record(st)
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
+
+  out, prev_t, prev_n = [], 0.0, 0
+  try:
+    for i in range(L):
+      rc = lib.rip_encode_tap_k(h, _lib.ptr(vis), B, 0, K, _lib.ENC_DTYPES[enc], i, None, 0, _lib.current_stream())
+      if rc == _lib.RIP_EINVAL:
+        continue  # interior to a fused block
+      _lib.check(rc)
+      log = [l.split(" ")[0] for l in h_obj.kernel_log()]
+      t = timed_us(lambda: _lib.check(lib.rip_encode_tap_k(h, _lib.ptr(vis), B, 0, K, _lib.ENC_DTYPES[enc], i, None, 0, _lib.current_stream())))
+      out.append({"through_layer": i, "kernels": log[prev_n:], "us": round(t - prev_t, 1)})
+      prev_t, prev_n = t, len(log)
+    vec = torch.zeros(B, 5, device=vis.device)
+    z = torch.empty(K, B, 64, device=vis.device)
+    full = timed_us(lambda: _lib.check(lib.rip_encode(h, _lib.ptr(vis), _lib.ptr(vec), B, 0, K, _lib.ENC_DTYPES[enc], _lib.ptr(z), None, _lib.current_stream())))
+    out.append({"through_layer": "tail", "kernels": [l.split(" ")[0] for l in h_obj.kernel_log()][prev_n:], "us": round(full - prev_t, 1)})
+  finally:
+    h_obj.set_option(_lib.OPT_KERNEL_LOG, 0)
+  return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle) — a subprocess with a hard timeout
 # ------------------------------------------------------------------------------------------------------------
@@ -558,6 +600,7 @@ def main():
           par_lines[mode] = {"calls_per_s": line["value"], "candidate_plans_per_s": line["candidate_plans_per_s"],
                              "ms_per_step": line["ms_per_step"], "collectives_per_step": line["collectives_per_step"],
                              "max_abs_plan_diff_vs_single_gpu": line["check"]["max_abs_plan_diff_vs_single_gpu"],
+                             "exchange": line.get("exchange"),
                              "scaling": line["scaling"], "candidates_total": line["config"]["candidates"],
                              "parallelism": line["config"]["parallelism"], "steps": sub_steps, "warmup": sub_warm}
       torch.cuda.empty_cache()
@@ -611,6 +654,13 @@ def main():
                 "calls/s vs 8 TB/s.  `traffic`: the adjoint tape.",
         "encoder": _encoder_roofline(enc_ms, enc_bytes, B, K, C, args.encoder_dtype, measured),
     }
+    if not args.no_extras:
+      try:
+        roof["encoder"]["kernels"] = _encoder_kernel_times(lib, agent._handle, batches[0][0], B, K, C, args.encoder_dtype)
+        roof["encoder"]["kernels_note"] = ("event-timed, median of 5: the launch sequence stopped after each block (rip_encode_tap_k, no "
+                                           "copy); `us` = difference of consecutive stops; transform_kernel is not in it")
+      except Exception as exc:  # noqa: BLE001
+        roof["encoder"]["kernels"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     roof.update(extras)
     out = {
         "metric": "RIPAgent.act() calls/sec (K=%d, %d plans, 200x200 BEV)" % (K, N),
@@ -912,6 +962,26 @@ def _bench_parallel_mode(args, mode, rank, world, dev, dist, timed, steps, warmu
     plan_1 = one(lidar, vec, goal)[0]
   check = {"max_abs_plan_diff_vs_single_gpu": float((plan_d - plan_1).abs().max().item()),
            "note": "plans of the %d-rank run vs ONE rank holding everything, same observations and latent starts" % world}
+
+  def local_ms(fn, reps=max(3, steps // 2)):  # rank 0 alone, no collective inside: what the exchange adds is ms_per_step minus this
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+  if mode == "candidates":
+    compute_ms = local_ms(lambda: cp.local_search(lidar, vec, goal))
+    exchange = {"rank_compute_ms_per_step": compute_ms, "exchange_ms_per_step": 1e3 * elapsed / steps - compute_ms,
+                "note": "rank 0's own share of the candidates (encoders + search, no collective, no selection) timed alone; the "
+                        "difference to ms_per_step is the all-gather of [B, 10] floats per rank, the arg-min over ranks and "
+                        "waiting for the slowest rank"}
+  else:
+    exchange = {"single_rank_ms_per_step": local_ms(lambda: one(lidar, vec, goal)),
+                "note": "ONE rank holding all K models (no collective) on the same observations: ms_per_step of the %d-rank run "
+                        "above this divided by %d is what the %d all-gathers per call cost" % (world, world, collectives)}
   calls = B * steps
   return {
       "check": check,
@@ -920,7 +990,7 @@ def _bench_parallel_mode(args, mode, rank, world, dev, dist, timed, steps, warmu
       "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
       "dtype": "%s encoder + flow/search: fp32 accumulate, GRU/head contractions as two-term binary16 operands on f16 MFMA" % args.encoder_dtype,
       "data": "synthetic",
-      "candidate_plans_per_s": calls / elapsed * n_total, "collectives_per_step": collectives,
+      "candidate_plans_per_s": calls / elapsed * n_total, "collectives_per_step": collectives, "exchange": exchange,
       "backend": args.backend_seen, "world_size_seen": args.world_seen,
       "config": {"workload": "RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV" % (K, args.algorithm, n_total, S, C),
                  "obs_per_step": B, "models": K, "candidates": n_total, "bev_channels": C, "mode": mode, "parallelism": par}}

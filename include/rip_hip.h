@@ -113,7 +113,8 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
  * torchvision's `features`: 0 = features.0, then [expand,] depthwise, project of features.1..17, 51 = features.18 — the
  * reference builds it at torch/networks/perception.py:36-51) and writes that layer's output as fp32:
  * `dst_dev` [k_count][B][H][W][C] (NHWC; bf16 activations are widened exactly), or [k_count][B][1280] for layer 51, whose 4x4 average
- * pool is part of its epilogue.  `dst_numel` must be exactly that size.  Overwrites the handle's activation workspace;
+ * pool is part of its epilogue.  `dst_numel` must be exactly that size — or `dst_dev` = NULL with `dst_numel` = 0: the launch
+ * sequence runs up to the layer and nothing is copied out (bench.py times the encoder block by block that way).  Overwrites the handle's activation workspace;
  * z is not produced.  RIP_EINVAL when the layer's output never reaches memory under the current
  * RIP_OPT_ENCODER_FUSED setting (an interior layer of a fused block). */
 int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin, int k_count, int enc_dtype, int layer,

@@ -1167,7 +1167,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     const Layer& l = plan.layers[li];
     const bool pooled = li + 1 == plan.layers.size() && plan.final_hw == 4;
     const size_t n = (size_t)kc * B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
-    (void)launch_tap_copy(bufs[l.dst], false, n, tap->dst, s);
+    if (tap->dst != nullptr) (void)launch_tap_copy(bufs[l.dst], false, n, tap->dst, s);
     tap->served = true;
     return true;
   };

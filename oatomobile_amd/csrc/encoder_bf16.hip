@@ -1155,7 +1155,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     const bool last = li + 1 == plan.layers.size();  // features.18: fp32, pooled when the map is 4x4
     const bool pooled = last && plan.final_hw == 4;
     const size_t n = (size_t)kc * B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
-    (void)launch_tap_copy(bufs[l.dst], !last, n, tap->dst, s);
+    if (tap->dst != nullptr) (void)launch_tap_copy(bufs[l.dst], !last, n, tap->dst, s);
     tap->served = true;
     return true;
   };

@@ -485,7 +485,8 @@ int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin,
                      float* dst_dev, size_t dst_numel, rip_stream_t stream) {
   int rc = check_models(h, k_begin, k_count);
   if (rc != RIP_OK) return rc;
-  REQUIRE(visual_dev != nullptr && dst_dev != nullptr, "NULL argument");
+  REQUIRE(visual_dev != nullptr, "NULL argument");
+  REQUIRE(dst_dev != nullptr || dst_numel == 0, "dst_dev is NULL with dst_numel=%zu (NULL + 0 = run up to the layer, copy nothing)", dst_numel);
   REQUIRE(B >= 1 && B <= h->max_batch, "B=%d outside [1,max_batch=%d]", B, h->max_batch);
   REQUIRE(enc_dtype == RIP_ENC_FP32 || enc_dtype == RIP_ENC_BF16, "unknown encoder dtype %d", enc_dtype);
   const int L = (int)h->plan.layers.size();
@@ -493,8 +494,8 @@ int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin,
   const Layer& l = h->plan.layers[layer];
   const bool pooled = layer + 1 == L && h->plan.final_hw == 4;
   const size_t need = (size_t)k_count * B * (pooled ? 1 : (size_t)l.h_out * l.h_out) * l.cout;
-  REQUIRE(dst_numel == need, "dst_numel=%zu, layer %d of %d model(s) x B=%d observations has %zu elements", dst_numel, layer,
-          k_count, B, need);
+  REQUIRE(dst_dev == nullptr || dst_numel == need, "dst_numel=%zu, layer %d of %d model(s) x B=%d observations has %zu elements",
+          dst_numel, layer, k_count, B, need);
   ENTER(h, stream);
   KernelLogScope log_(h);
   EncoderTap tap;
