@@ -85,6 +85,7 @@ def test_docs_quote_the_header_and_the_tests_as_they_are():
     assert quoted and quoted <= {n}, (doc, quoted, n)
   tests = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read() + open(os.path.join(ROOT, "tests", "test_host_cpu.py")).read()
   tests += open(os.path.join(ROOT, "tests", "test_distributed_cpu.py")).read()
+  tests += open(os.path.join(ROOT, "tests", "test_oracle_golden.py")).read()
   defined = set(re.findall(r"def (test_[a-z0-9_]+)\(", tests))
   for doc in ("README.md", "INTEGRATION.md", "DESIGN.md"):
     text = open(os.path.join(ROOT, doc)).read()
