@@ -540,7 +540,7 @@ def main():
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
 
   # ---------------- secondary lines (rank 0, N = 1 only; untimed by the driver's contract) ----------------
-  online = scoring = fp32_line = c4_line = train_line = replay_line = None
+  online = scoring = fp32_line = c4_line = train_line = replay_line = pipelined = None
   if rank == 0 and world == 1 and not args.no_extras:
     def extra(fn, *a):
       """A secondary line must never cost the headline: a failure becomes {"error": ...} in its place."""
@@ -569,7 +569,36 @@ def main():
                       "1e-4 parity contract.  `bf16_vs_fp32_plan_deviation_m`: what the bf16 encoder of `value` (the "
                       "precision BASELINE configs[2] names) moves the winning plans by on this batch"}
 
+    def two_handles():
+      """Two handles on two streams, each running encode -> search on its own resident batch: the encoder's launch
+      tails and the search fill each other's gaps.  A deployment option for batch replay, NOT `value` (whose kernels
+      run one after the other so that the event times and the rocprofv3 averages describe single kernels)."""
+      import ctypes
+      other = RIPAgent(None, algorithm=args.algorithm, models=models, num_candidates=N, num_steps=S, max_batch=B, seed=0,
+                       device=dev, encoder_dtype=args.encoder_dtype)
+      z2, plan2, loss2 = torch.empty_like(z), torch.empty_like(plan), torch.empty_like(loss)
+      s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+      def act(hh, batch, zz, pp, ll, st):
+        sp = ctypes.c_void_p(st.cuda_stream)
+        lidar_, vec_, goal_ = batch
+        _lib.check(lib.rip_encode_raw(hh, _lib.ptr(lidar_), 1, lidar_.shape[1], lidar_.shape[2], _lib.ptr(vec_), B, 0, K,
+                                      _lib.ENC_DTYPES[args.encoder_dtype], _lib.ptr(zz), sp))
+        _lib.check(lib.rip_search(hh, _lib.ptr(zz), _lib.ptr(goal_), _lib.ptr(x0), B, N, G, algo, S, 0.1, 1.0, _lib.ptr(pp), None,
+                                  _lib.ptr(ll), None, None, None, None, sp))
+
+      def pair(i, ev):
+        act(h, batches[0], z, plan, loss, s1)
+        act(other._handle.raw, batches[1], z2, plan2, loss2, s2)
+
+      n = max(4, args.steps // 4)
+      el = timed(pair, n, 2)
+      return {"calls_per_s": 2 * B * n / el, "ms_per_pair_of_steps": 1e3 * el / n,
+              "note": "two handles x two streams, observations resident in HBM, [B,4,2] plans left on the device; compare "
+                      "with hbm_resident.calls_per_s (one handle, one stream)"}
+
     online = extra(_bench_online, args, models, dev, host_batches[0])
+    pipelined = extra(two_handles)
     scoring = extra(_bench_scoring, args, lib, h, batches, z, enc_dtype, dev, timed, K, N, B, G, algo)
     if args.encoder_dtype == "bf16":
       fp32_line = extra(fp32_step)
@@ -688,6 +717,7 @@ def main():
                          "h2d_MB_per_step": h2d_bytes / 1e6, "d2h_KB_per_step": B * 30 * 3 * 8 / 1e3,
                          "r11_bit_identical_to_reference_arithmetic": bool(r11_ok)},
         "hbm_resident": hbm_line,
+        "two_handles_two_streams": pipelined,
         "backend": args.backend_seen,
         "world_size_seen": args.world_seen,
         "candidate_parallel": par_lines.get("candidates"),
