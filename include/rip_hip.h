@@ -307,7 +307,7 @@ int rip_train_num_layers(const rip_trainer* t);
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.
  *     bf16 encoder: count >= 1 fuses the stem with features.1 (one kernel), blocks 1..6 of the count are the
  *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
- *     features.17 / 18 always run layer by layer.  auto = everything, the tile kernel only when the call carries
+ *     and 16 (features.17, round 5); features.18 runs as a GEMM with the pooled epilogue.  auto = everything, the tile kernel only when the call carries
  *     >= 64 (model, observation) pairs (an explicit count uses it regardless).
  *   RIP_OPT_SEARCH_REGROUP: retired in round 5 (rounds 3 / 4: regrouped the candidates of ONE workgroup by selected
  *     member between Adam steps; bit-identical results, fewer adjoints per block, no faster: the workgroup walks the
@@ -326,7 +326,8 @@ int rip_train_num_layers(const rip_trainer* t);
  *     would after a placement miss / barrier timeout (RIP_ESTATE unless RIP_OPT_ENCODER_MEGA = 1 set the protocol up).
  *   RIP_OPT_ENCODER_VARIANT (development / tests; default 0 = what ships): bit mask of alternative bf16 encoder
  *     kernels kept for A/B runs — 1: features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit),
- *     2: stem + features.1 on round 3's front kernel, 4: the matrix-core depthwise kernel on features.5-7 as well.
+ *     2: stem + features.1 on round 3's front kernel, 4: the matrix-core depthwise kernel on features.5-7 as well,
+ *     8: features.17 as three layer-wise launches (round 4's persistent GEMMs + row-streaming depthwise) instead of a tile block.
  *     Same arithmetic definition; the teacher-forced block tests run every setting.
  *   RIP_OPT_KERNEL_LOG (tests; default 0): 1 = every rip_encode / rip_encode_raw* / rip_encode_tap* call records the
  *     encoder kernels it launches (name, template arguments, grid) — read with rip_kernel_log. */

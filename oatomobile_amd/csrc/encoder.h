@@ -23,6 +23,7 @@ enum {
   ENC_VAR_IRB_ROUND3 = 1,    // features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit)
   ENC_VAR_FRONT_ROUND3 = 2,  // stem + features.1 on round 3's front kernel
   ENC_VAR_IRB2_ALL = 4,      // the matrix-core depthwise kernel on features.5-7 as well
+  ENC_VAR_F17_LAYERWISE = 8, // features.17 as three layer-wise launches (round 4: persistent GEMMs + row-streaming depthwise) instead of a tile block
 };
 
 // Workgroup barrier for kernels whose waves talk to each other through LDS only.  `__syncthreads()` is a workgroup-scope
@@ -150,7 +151,7 @@ hipError_t launch_front2_bf16(const Layer& ls, const Layer& ld, const Layer& lp,
                               unsigned short* y, hipStream_t s);
 
 // small-image stages (7x7 / 4x4 maps, features.8 .. features.17): encoder_bf16_tile.hip
-bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
+bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, bool f17_layerwise = false);
 hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                                 const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
                                 const unsigned short* x, unsigned short* y, hipStream_t s);

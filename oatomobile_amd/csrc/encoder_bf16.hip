@@ -1175,7 +1175,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
     const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_IRB2_ALL) != 0);
     const bool rows = rows2 || irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
-    const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_F17_LAYERWISE) != 0);
     if (!rows && !tile) continue;
     tiled[bi] = tile ? 1 : (rows2 ? 2 : 0);
     if (fb.expand >= 0) in_block[fb.expand] = 1;

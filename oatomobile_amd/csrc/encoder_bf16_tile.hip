@@ -400,15 +400,15 @@ hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
 
 }  // namespace
 
-bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp) {
+bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, bool f17_layerwise) {
   if (le == nullptr) return false;
   const int cin = le->cin, hid = ld.cout, cout = lp.cout;
   if (hid != 6 * cin || hid % HC != 0) return false;
   if (ld.h_in == 7 && ld.stride == 1) return (cin == 64 && (cout == 64 || cout == 96)) || (cin == 96 && cout == 96);
   if (ld.h_in == 7 && ld.stride == 2) return cin == 96 && cout == 160;
-  // features.17 (160 -> 960 -> 320 at 4x4) stays layer-wise: with 320 output channels a wave's accumulators leave
-  // room for one 16-pixel tile only, every weight tile would feed a single MFMA (measured 424 us vs ~150 us)
-  if (ld.h_in == 4 && ld.stride == 1) return cin == 160 && cout == 160;
+  // features.17 (160 -> 960 -> 320 at 4x4): round 4 kept it layer-wise (with 320 output channels per wave a wave's
+  // accumulators leave room for one 16-pixel tile only: 424 us vs ~150 us); round 5 splits the channels over the waves
+  if (ld.h_in == 4 && ld.stride == 1) return cin == 160 && (cout == 160 || (!f17_layerwise && cout == 320));
   return false;
 }
 
@@ -442,6 +442,11 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
   if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_tile<7, 2, 96, 160, 4, true, true, 2>(a, kc, s);  // 14
   if (ld.h_in == 4 && ld.stride == 1 && cin == 160) {
     if (cout == 160) return launch_tile<4, 1, 160, 160, 8, false, false, 2>(a, kc, s);              // features.15, 16
+    // features.17 (round 5): the 320 output channels split FOUR ways over the matrix waves (WCH = 4: every wave owns 5
+    // channel tiles of all pixel tiles — 20 accumulators, 245 registers, no scratch) and 4 observations per workgroup;
+    // 139 -> 68 us against the three layer-wise launches (expand GEMM 57, depthwise 27, projection GEMM 57).  G = 2 / 3 and
+    // the builds without weight prefetch measured 1499-1567 us of encoder time against 1475 (profiles/r5/tile17_variants.txt)
+    if (cout == 320) return launch_tile<4, 1, 160, 320, 4, true, true, 4>(a, kc, s);
   }
   return hipErrorInvalidValue;
 }

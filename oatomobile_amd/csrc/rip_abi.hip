@@ -362,7 +362,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
       h->encoder_mega = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_VARIANT:
-      REQUIRE(value >= 0 && value <= 7, "encoder variant mask %d not in [0,7] (1 round-3 row-streaming blocks, 2 round-3 front, 4 matrix-core depthwise on features.5-7)", value);
+      REQUIRE(value >= 0 && value <= 15, "encoder variant mask %d not in [0,15] (1 round-3 row-streaming blocks, 2 round-3 front, 4 matrix-core depthwise on features.5-7, 8 features.17 layer-wise)", value);
       h->encoder_variant = value;
       return RIP_OK;
     case RIP_OPT_KERNEL_LOG:

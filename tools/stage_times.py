@@ -17,6 +17,7 @@ def main():
   ap.add_argument("--enc", default="fp32")
   ap.add_argument("--fused", type=int, default=-1, help="RIP_OPT_ENCODER_FUSED (-1 = auto)")
   ap.add_argument("--mega", type=int, default=-1, help="RIP_OPT_ENCODER_MEGA (-1 auto, 0 never, 1 up to 4 observations)")
+  ap.add_argument("--variant", type=int, default=0, help="RIP_OPT_ENCODER_VARIANT bit mask")
   ap.add_argument("--search-kernel", type=int, default=0, help="RIP_OPT_SEARCH_KERNEL (0 auto, 1 chain, 3 phase, 4 split)")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
@@ -28,6 +29,7 @@ def main():
   _lib.check(lib.rip_set_option(h, 1, args.fused))
   _lib.check(lib.rip_set_option(h, 0, args.search_kernel))
   _lib.check(lib.rip_set_option(h, 3, args.mega))
+  _lib.check(lib.rip_set_option(h, _lib.OPT_ENCODER_VARIANT, args.variant))
   lidar, vec, goal = (torch.from_numpy(a).to(dev) for a in synth_batch(np.random.default_rng(0), B, 2))
   x0 = agent._x0(B)
   z = torch.empty(K, B, 64, device=dev); plan = torch.empty(B, 4, 2, device=dev); loss = torch.empty(B, N, device=dev)
