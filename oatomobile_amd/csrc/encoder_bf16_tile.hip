@@ -437,6 +437,8 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
   if (ld.h_in == 7 && ld.stride == 1) {
     if (cin == 64 && cout == 64) return launch_tile<7, 1, 64, 64, 4, true, true, 2>(a, kc, s);    // features.8-10
     if (cin == 64 && cout == 96) return launch_tile<7, 1, 64, 96, 4, true, true, 2>(a, kc, s);    // features.11
+    // (features.12 / 13 and 15 / 16 with fewer observations per workgroup and the weight prefetch on — the recipe that paid
+    // for features.17 — measured 6-90 us SLOWER: profiles/r5/tile17_variants.txt)
     if (cin == 96 && cout == 96) return launch_tile<7, 1, 96, 96, 4, false, false, 2>(a, kc, s);    // features.12, 13
   }
   if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_tile<7, 2, 96, 160, 4, true, true, 2>(a, kc, s);  // 14
