@@ -88,7 +88,7 @@ hipError_t launch_tap_copy(const void* src, bool src_bf16, size_t n, float* dst,
 // and the flow blob (flow.h layout).  Returns false (and a message) on size mismatch.
 bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc_blob,
                    std::vector<float>& flow_blob, std::vector<float>& mfma_blob, std::vector<uint32_t>& split_blob,
-                   const char** err);
+                   const char** err, float* split_wmax = nullptr);
 
 bool transform_coded_supported(int C, int H, int W, int out_hw);
 hipError_t launch_transform_coded(const uint8_t* in, const float* lut /*[256]*/, int B, int C, int H, int W, int out_hw,

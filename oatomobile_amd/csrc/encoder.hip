@@ -973,7 +973,8 @@ EncoderPlan build_encoder_plan(int in_channels) {
 }
 
 bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, std::vector<float>& enc,
-                   std::vector<float>& flow, std::vector<float>& mw, std::vector<uint32_t>& mh, const char** err) {
+                   std::vector<float>& flow, std::vector<float>& mw, std::vector<uint32_t>& mh, const char** err,
+                   float* split_wmax) {
   enc.assign(plan.blob_floats, 0.f);
   flow.assign(FW_SIZE, 0.f);
   size_t pos = 0;
@@ -1104,7 +1105,8 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
         }
   }
   // ---- operands of the split-f16 search kernel (flow_split.hip) ----
-  pack_split_operands(mw.data(), wih, whh, w1, mh);
+  const float wmax = pack_split_operands(mw.data(), wih, whh, w1, mh);
+  if (split_wmax != nullptr) *split_wmax = wmax;
   return true;
 }
 

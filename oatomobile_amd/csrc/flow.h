@@ -61,6 +61,7 @@ struct SearchArgs {
   const unsigned* run_if_flag = nullptr;
 };
 constexpr float SPLIT_Z_LIMIT = 16384.0f;  // binary16 overflows at 65504; hidden states reach max(1, |z|)
+constexpr float SPLIT_W_LIMIT = 200.0f;    // ... and the transposed operand rows hold w * 2^8 (flow_split_pack.h)
 
 // Gradient-mode model-parallel search: one Adam step split at the exchange point.
 struct MpArgs {

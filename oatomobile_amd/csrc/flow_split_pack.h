@@ -8,6 +8,7 @@
 // "H layout" of flow_phase.hip: lane (m = lane & 15, q = lane >> 4), half i <-> hidden unit
 // 16 * (2 kb + (i >> 2)) + 4 q + (i & 3), so the 16 fp32 values a lane holds of a 64-unit vector ARE its two B operands.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -43,9 +44,16 @@ inline void split_f16_tw(float w, uint16_t* hi, uint16_t* lo) {
 
 // `mw` = the fp32 operand blob of the MFMA kernels (MW_SIZE floats, fold_and_pack): its fp32 rows (input / bias
 // k-steps, b1, W2, b2, W2^T) are reused as they are.  Reference tensors as in fold_and_pack.  Output: MH_SIZE dwords.
-inline void pack_split_operands(const float* mw, const float* wih, const float* whh, const float* w1,
-                                std::vector<uint32_t>& out) {
+// Returns the largest |w| of the split weights: the transposed rows hold w * 2^8 as binary16 (max 65504), so a model
+// with a flow weight of magnitude >= SPLIT_W_LIMIT cannot use this kernel (rip_abi.hip routes its searches to the
+// fp32-MFMA kernel; no trained or random-initialised GRU comes near it).
+inline float pack_split_operands(const float* mw, const float* wih, const float* whh, const float* w1,
+                                 std::vector<uint32_t>& out) {
   out.assign(MH_SIZE, 0u);
+  float wmax = 0.f;
+  for (int i = 0; i < 192 * 2; ++i) wmax = std::fmax(wmax, std::fabs(wih[i]));
+  for (int i = 0; i < 192 * 64; ++i) wmax = std::fmax(wmax, std::fabs(whh[i]));
+  for (int i = 0; i < 32 * 64; ++i) wmax = std::fmax(wmax, std::fabs(w1[i]));
   auto put = [&](size_t row_base_dw, int lane, int i, uint16_t v) {  // half i of the lane's 16-byte entry
     uint32_t& d = out[row_base_dw + (size_t)lane * 4 + (i >> 1)];
     d = (i & 1) ? ((d & 0x0000ffffu) | ((uint32_t)v << 16)) : ((d & 0xffff0000u) | v);
@@ -95,6 +103,7 @@ inline void pack_split_operands(const float* mw, const float* wih, const float* 
           dh = (i & 1) ? ((dh & 0xffffu) | ((uint32_t)h << 16)) : ((dh & 0xffff0000u) | h);
           dl = (i & 1) ? ((dl & 0xffffu) | ((uint32_t)l << 16)) : ((dl & 0xffff0000u) | l);
         }
+  return wmax == wmax ? wmax : SPLIT_W_LIMIT;  // (a NaN weight counts as out of range)
 }
 
 }  // namespace rip

@@ -42,6 +42,7 @@ struct rip_handle {
   bool kernel_log_on = false;  // RIP_OPT_KERNEL_LOG
   KernelLog klog;              // the encoder kernels of the last rip_encode* / rip_encode_tap* call (rip_kernel_log)
   bool loaded[RIP_MAX_MODELS] = {false};
+  float split_wmax[RIP_MAX_MODELS] = {0.f};  // largest flow weight magnitude per model (flow_split_pack.h: SPLIT_W_LIMIT)
   float* bufs[4] = {nullptr, nullptr, nullptr, nullptr};  // encoder activations
   size_t buf_floats = 0;
   // scratch for the fused entry points
@@ -393,7 +394,9 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
   std::vector<float> enc, flow, mw;
   std::vector<uint32_t> mh;
   const char* err = "";
-  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, mh, &err)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
+  float wmax = 0.f;
+  if (!fold_and_pack(h->plan, packed_host, numel, enc, flow, mw, mh, &err, &wmax)) return fail(RIP_EINVAL, "%s (got %zu floats)", err, numel);
+  h->split_wmax[k] = wmax;
   DeviceScope scope(h->device);
   if (scope.err != hipSuccess) return fail(RIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(scope.err));
   // setup call: synchronous copies; make sure no kernel of an earlier call still reads the old weights
@@ -621,10 +624,16 @@ int rip_cil_blob_floats(void) { return cil_blob_floats(); }
 // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
 // wave-per-chain kernel has the lower latency for a single observation.  1 = wave-per-chain, 3 = fp32-MFMA
 // phase-sequential, 4 = split-f16 phase-sequential (the default of large launches).
+static bool split_weights_ok(const rip_handle* h) {
+  for (int k = 0; k < h->K; ++k)
+    if (h->split_wmax[k] >= SPLIT_W_LIMIT) return false;
+  return true;
+}
 static int pick_search_kernel(const rip_handle* h, int B, int N) {
   if (h->search_mode != 0) return h->search_mode;
   const bool big = (size_t)B * N >= 2304;
-  return big && N % 16 == 0 && h->K <= RIP_MAX_MODELS ? 4 : 1;
+  if (!(big && N % 16 == 0 && h->K <= RIP_MAX_MODELS)) return 1;
+  return split_weights_ok(h) ? 4 : 3;  // a flow weight beyond the binary16 operand range: the fp32-MFMA kernel
 }
 
 static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev, const float* x0_dev, int B, int N, int G,
@@ -679,6 +688,9 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
   // crossover measured at K = 4, N = 128: the chain kernel costs 64 us per observation, the phase kernel 1.1 ms per
   // launch up to one workgroup per CU (B = 16: 1.02 vs 1.11 ms, B = 32: 2.03 vs 1.11 ms)
   const int kernel = pick_search_kernel(h, B, N);
+  if (kernel == 4 && !split_weights_ok(h))
+    return fail(RIP_EINVAL, "the split-f16 search kernel carries the flow weights as binary16 terms of w * 2^8: a model of this handle "
+                "has a flow weight of magnitude >= %g; use search kernel 0 (auto) or 3", (double)SPLIT_W_LIMIT);
   if ((kernel == 3 && !search_phase_supported(a)) || (kernel == 4 && !search_split_supported(a)))
     return fail(RIP_EINVAL, "phase-sequential MFMA search needs N%%16==0 and K<=%d (K=%d N=%d)", RIP_MAX_MODELS, h->K, N);
   if (kernel != 1) {

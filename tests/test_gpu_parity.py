@@ -714,6 +714,39 @@ def _scaled_flow_models(seeds, wscale, dev):
   return hips, refs
 
 
+def test_split_kernel_weight_range_guard(dev):
+  """Round 5 packs the adjoint's operand rows as w * 2^8 in binary16 (max 65504): a model with a flow weight of magnitude
+  >= 200 must not reach the split-f16 kernel.  `rip_load_model` records the largest flow weight; with one such model in
+  the handle `auto` takes the fp32-MFMA kernel (`rip_search_plan`), an explicit request for the split kernel is
+  RIP_EINVAL, and the search is the fp32 kernel's, finite."""
+  from oatomobile_amd import _lib, RIPAgent
+  K, N, B = 2, 128, 24
+  hips, _ = _scaled_flow_models([300, 301], 1.0, dev)
+  big, _ = _scaled_flow_models([302], 2000.0, dev)  # U(-1/8, 1/8) x 2000: weights up to 250
+  lib = _lib.load()
+  rng = np.random.default_rng(3)
+  z = torch.from_numpy(np.abs(rng.normal(size=(K, B, 64))).astype(np.float32)).to(dev)
+  goal = torch.from_numpy(np.cumsum(np.abs(rng.normal(size=(B, 10, 2))) * 2, axis=1).astype(np.float32)).to(dev)
+  outs = {}
+  for tag, models, kern in (("ok", hips, "auto"), ("guarded", [hips[0], big[0]], "auto"), ("phase", [hips[0], big[0]], "phase")):
+    agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=N, seed=9, search_kernel=kern, max_batch=B)
+    import ctypes
+    info = (ctypes.c_int32 * 10)()
+    _lib.check(lib.rip_search_plan(agent._handle.raw, B, N, info, 10))
+    plan = torch.empty(B, 4, 2, device=dev)
+    lb = torch.empty(B, N, device=dev)
+    _lib.check(lib.rip_search(agent._handle.raw, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(agent._x0(B)), B, N, 10, 0, 3, 0.1, 1.0,
+                              _lib.ptr(plan), None, _lib.ptr(lb), None, None, None, None, agent._handle.stream()))
+    outs[tag] = (int(info[0]), plan.cpu(), lb.cpu())
+  assert outs["ok"][0] == 4 and outs["guarded"][0] == 3 and outs["phase"][0] == 3
+  assert torch.equal(outs["guarded"][1], outs["phase"][1]) and torch.equal(outs["guarded"][2], outs["phase"][2])
+  assert torch.isfinite(outs["guarded"][1]).all()
+  forced = RIPAgent(None, algorithm="WCM", models=[hips[0], big[0]], num_candidates=N, seed=9, search_kernel="split", max_batch=B)
+  rc = lib.rip_search(forced._handle.raw, _lib.ptr(z), _lib.ptr(goal), _lib.ptr(forced._x0(B)), B, N, 10, 0, 3, 0.1, 1.0,
+                      _lib.ptr(plan), None, _lib.ptr(lb), None, None, None, None, forced._handle.stream())
+  assert rc == _lib.RIP_EINVAL and b"w * 2^8" in lib.rip_last_error()
+
+
 def _geomean(xs):
   return float(np.exp(np.mean(np.log(np.maximum(np.asarray(xs, np.float64), 1e-30)))))
 
