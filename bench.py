@@ -169,9 +169,11 @@ def _encoder_kernel_times(lib, h_obj, lidar, B, K, C, enc, reps=5):
       if rc == _lib.RIP_EINVAL:
         continue  # interior to a fused block
       _lib.check(rc)
-      log = [l.split(" ")[0] for l in h_obj.kernel_log()]
+      lines = h_obj.kernel_log()
+      log = [l.split(" ")[0] for l in lines]
       t = timed_us(lambda: _lib.check(lib.rip_encode_tap_k(h, _lib.ptr(vis), B, 0, K, _lib.ENC_DTYPES[enc], i, None, 0, _lib.current_stream())))
-      out.append({"through_layer": i, "kernels": log[prev_n:], "us": round(t - prev_t, 1)})
+      out.append({"through_layer": i, "kernels": log[prev_n:], "us": round(t - prev_t, 1),
+                  "launch": [" ".join(l.split(" ")[1:]) for l in lines[prev_n:]]})
       prev_t, prev_n = t, len(log)
     vec = torch.zeros(B, 5, device=vis.device)
     z = torch.empty(K, B, 64, device=vis.device)

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "encoder.h"
+#include "flow.h"  // device_cu_count
 
 namespace rip {
 
@@ -876,8 +877,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 // stores; the 4 q-lanes of a pixel write 32 contiguous bytes).
 // POOL: features.18 -- the 16 pixels of a pixel tile are one 4x4 image; the epilogue averages them and writes fp32
 // [image][Cout] (the pooled feature the classifier reads) instead of bf16 activations.
+// Two workgroups per CU at WN = 4 (<= 256 registers: 198 with operands requested two steps ahead), three at WN = 2.
+// Round 5: the three-steps-ahead build needed 260-268 registers, i.e. ONE workgroup per CU, while the launcher sized its
+// grid for two (520 workgroups on 256 slots: three rounds) — 84 us for features.18 at 512 observations x 4 models.  Capping
+// the registers with three sets in flight spills, and a spill reload is a vector-memory operation: `s_waitcnt vmcnt(0)`
+// in the loop, the prefetch distance gone (61 us).  Two sets, no spill, grid rounded down to the resident slots: 52 us.
+// (LDS row pitch 32 + 16 instead of 32 + 8 elements: the same within noise.)
+constexpr int GEMM_PERS_OCC4 = 2;
 template <int WN, bool POOL>
-__global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __restrict__ in,
+__global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_bf16_kernel(const bf16_t* __restrict__ in,
                                                               const bf16_t* __restrict__ whbase,
                                                               const float* __restrict__ wbase, size_t model_stride,
                                                               int k0, size_t w_off, size_t b_off,
@@ -886,7 +894,7 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
                                                               size_t act_model_stride_in, size_t act_model_stride_out,
                                                               int n_ptiles) {
   constexpr int BM = 128, BN = 32 * WN, BK = 32, LD = BK + 8;  // (K-steps of 64 measured slower: 45.8 / 64.8 / 100.4 vs 35.0 / 52.5 / 77.8 us)
-  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // [2][BN + BM][LD]: 73.7 KB at WN = 4 (dynamic: the launcher opts in)
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // [2][BN + BM][LD]: 40 KB at WN = 4
   auto As = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD; };
   auto Bs = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD + BN * LD; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1021,13 +1029,12 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
     }
   };
 
-  // Operands are requested THREE steps ahead (three register sets; the loop is unrolled by six = lcm of the register
-  // and the LDS rotation) and every load is issued whether or not a step s + 3 exists (clamped: see load_tiles), so the
-  // loop body has no branch between a load and its use and the waits are vmcnt(8) instead of vmcnt(0).
-  u32x4 a0[A_CH], b0[B_CH], a1[A_CH], b1[B_CH], a2[A_CH], b2[B_CH];
+  // Operands are requested TWO steps ahead (two register sets = the LDS rotation) and every load is issued whether or
+  // not a step s + 2 exists (clamped: see load_tiles), so the loop body has no branch between a load and its use and the
+  // waits are counted (vmcnt(4..7)) instead of vmcnt(0).
+  u32x4 a0[A_CH], b0[B_CH], a1[A_CH], b1[B_CH];
   load_tiles(a0, b0);
   load_tiles(a1, b1);
-  load_tiles(a2, b2);
   int s = 0;
 #define GEMM_STEP(buf_, ar_, br_)   \
   store_tiles(buf_, ar_, br_);      \
@@ -1039,10 +1046,6 @@ __global__ __launch_bounds__(256) void gemm_pers_bf16_kernel(const bf16_t* __res
   for (;;) {
     GEMM_STEP(0, a0, b0)
     GEMM_STEP(1, a1, b1)
-    GEMM_STEP(0, a2, b2)
-    GEMM_STEP(1, a0, b0)
-    GEMM_STEP(0, a1, b1)
-    GEMM_STEP(1, a2, b2)
   }
 #undef GEMM_STEP
 }
@@ -1051,8 +1054,9 @@ template <int WN, bool POOL>
 void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w, size_t ms, int k0, int kc,
                       const Layer& l, const bf16_t* res, void* dst, int M, hipStream_t s) {
   const int n_ptiles = (M + 127) / 128, n_slices = (l.cout + 32 * WN - 1) / (32 * WN);
-  const int per_cu = WN == 4 ? 2 : 3;  // resident workgroups per CU (registers)
-  int px = (per_cu * 256 + n_slices * kc - 1) / (n_slices * kc);
+  const int per_cu = WN == 4 ? GEMM_PERS_OCC4 : 3;  // resident workgroups per CU (registers: the kernel's launch bounds)
+  // every workgroup of the grid is resident at once (rounded DOWN: 520 workgroups on 512 slots are two rounds)
+  int px = per_cu * device_cu_count() / (n_slices * kc);
   if (px > n_ptiles) px = n_ptiles;
   if (px < 1) px = 1;
   const size_t sout = POOL ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;

@@ -18,6 +18,7 @@ def main():
   ap.add_argument("--fused", type=int, default=-1, help="RIP_OPT_ENCODER_FUSED (-1 = auto)")
   ap.add_argument("--mega", type=int, default=-1, help="RIP_OPT_ENCODER_MEGA (-1 auto, 0 never, 1 up to 4 observations)")
   ap.add_argument("--variant", type=int, default=0, help="RIP_OPT_ENCODER_VARIANT bit mask")
+  ap.add_argument("--blocks", action="store_true", help="also the encoder kernel by kernel (bench._encoder_kernel_times)")
   ap.add_argument("--search-kernel", type=int, default=0, help="RIP_OPT_SEARCH_KERNEL (0 auto, 1 chain, 3 phase, 4 split)")
   args = ap.parse_args()
   from oatomobile_amd import ImitativeModel, RIPAgent, _lib
@@ -50,6 +51,10 @@ def main():
   enc = np.median([e[0].elapsed_time(e[1]) for e in ev]) * 1e3
   sea = np.median([e[1].elapsed_time(e[2]) for e in ev]) * 1e3
   assert lib.rip_encoder_status(h) == 0
+  if args.blocks:
+    from bench import _encoder_kernel_times
+    for r in _encoder_kernel_times(lib, agent._handle, lidar, B, K, 2, args.enc, reps=15):
+      print("  blk %-5s %7.1f us  %s" % (r["through_layer"], r["us"], " ".join(r["kernels"]) + "  " + "; ".join(r.get("launch", []))))
   print("B=%d K=%d N=%d: encode %.1f us, search %.1f us, wall/iter %.1f us -> %.0f calls/s" % (B, K, N, enc, sea, wall * 1e6, B / wall))
 
 
