@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
                                                               const bf16_t* __restrict__ res, void* __restrict__ outv,
                                                               int M, int Cin, int Cout, int relu6,
                                                               size_t act_model_stride_in, size_t act_model_stride_out,
-                                                              int n_ptiles) {
+                                                              int n_ptiles, int n_slices, int walkers, int xcd_r) {
   constexpr int BM = 128, BN = 32 * WN, BK = 32, LD = BK + 8;  // (K-steps of 64 measured slower: 45.8 / 64.8 / 100.4 vs 35.0 / 52.5 / 77.8 us)
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // [2][BN + BM][LD]: 40 KB at WN = 4
   auto As = [&](int b) -> bf16_t* { return lds + b * (BN + BM) * LD; };
@@ -900,8 +900,32 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int wp = wave >> 1, wc = wave & 1;
-  const int k = blockIdx.z;
-  const int c0 = blockIdx.y * BN;
+  // Work of workgroup L of the 1-D grid: channel slice, model, and the pixel tiles (t_first + i * walkers) * t_mul + t_add.
+  // xcd_r > 0 (the launcher: the model count divides 8): workgroup L runs on XCD L % 8 (observed placement, used for
+  // speed only), and an XCD serves ONE model and every xcd_r-th pixel tile of it — each activation tile crosses the
+  // fabric into one L2 instead of into several (features.18 at 512 observations x 4 models: rocprofv3 FETCH_SIZE 157 MB
+  // per launch for 21 MB of activations + 3 MB of weights with the (tile, slice, model) grid; 54 -> 48 us).
+  int k, c0, t_first, t_mul, t_add, n_loc;
+  {
+    const int L = blockIdx.x;
+    if (xcd_r > 0) {
+      const int xcd = L & 7, j = L >> 3;
+      k = xcd / xcd_r;
+      t_add = xcd - k * xcd_r;
+      t_mul = xcd_r;
+      c0 = (j % n_slices) * BN;
+      t_first = j / n_slices;
+      n_loc = (n_ptiles - t_add + xcd_r - 1) / xcd_r;
+    } else {
+      const int x = L % walkers, y = (L / walkers) % n_slices;
+      k = L / (walkers * n_slices);
+      c0 = y * BN;
+      t_first = x;
+      t_mul = 1;
+      t_add = 0;
+      n_loc = n_ptiles;
+    }
+  }
   const bf16_t* A = whbase + (size_t)(k0 + k) * model_stride + w_off;
   const float* bias = wbase + (size_t)(k0 + k) * model_stride + b_off;
   const bf16_t* X = in + (size_t)k * act_model_stride_in;
@@ -909,7 +933,7 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
   bf16_t* O = reinterpret_cast<bf16_t*>(outv) + (size_t)k * act_model_stride_out;
   float* OF = reinterpret_cast<float*>(outv) + (size_t)k * act_model_stride_out;
   const int nk = (Cin + BK - 1) / BK;  // Cin % 32 == 0; a last half step loads clamped (re-read) K columns with zero weight
-  const int nt = ((int)blockIdx.x < n_ptiles) ? (n_ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int nt = t_first < n_loc ? (n_loc - 1 - t_first) / walkers + 1 : 0;
   const int total = nt * nk;
   if (total == 0) return;
 
@@ -917,14 +941,14 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
   constexpr int A_CH = BN * CPR / 256, B_CH = BM * CPR / 256;
   const u32x4 zero = {0u, 0u, 0u, 0u};
   // load stream position (tile, K-step), advanced once per load_tiles call
-  int l_tile = blockIdx.x, l_kt = 0;
+  int l_tile = t_first, l_kt = 0;
   // Loads are UNCONDITIONAL (rows beyond Cout / M are clamped to the last valid row: their products land in outputs
   // that are never stored; Cin is a multiple of 32 on this path): a predicated load is a branch, and behind every
   // control-flow merge the compiler's s_waitcnt falls back to vmcnt(0) — the load requested for two steps ahead was
   // waited for one step ahead, so a K-step cost one memory latency (~1900 cycles for 272 cycles of MFMAs per wave).
   auto load_tiles = [&](u32x4(&areg)[A_CH], u32x4(&breg)[B_CH]) __attribute__((always_inline)) {
-    const int lt = l_tile < n_ptiles ? l_tile : n_ptiles - 1;  // the stream runs past the last step: harmless re-loads
-    const int p0 = lt * BM;
+    const int lt = l_tile < n_loc ? l_tile : n_loc - 1;  // the stream runs past the last step: harmless re-loads
+    const int p0 = (lt * t_mul + t_add) * BM;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int e = tid + 256 * i, row = e / CPR, kk = l_kt * BK + (e % CPR) * 8;
@@ -941,7 +965,7 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
     }
     if (++l_kt == nk) {
       l_kt = 0;
-      l_tile += gridDim.x;
+      l_tile += walkers;
     }
   };
   auto store_tiles = [&](int buf, const u32x4(&areg)[A_CH], const u32x4(&breg)[B_CH]) __attribute__((always_inline)) {
@@ -969,7 +993,7 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
     bb[i] = co < Cout ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  int c_tile = blockIdx.x, c_kt = 0;  // compute stream position
+  int c_tile = t_first, c_kt = 0;  // compute stream position
   auto compute = [&](int buf) __attribute__((always_inline)) {
     u32x4 af[BK / 32][WN], bf[BK / 32][4];
 #pragma unroll
@@ -989,7 +1013,7 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(af[kh][i]), as_bf16x8(bf[kh][j]), acc[i][j], 0, 0, 0);
     if (++c_kt == nk) {  // tile finished: bias (+ residual) (+ ReLU6), store, restart the accumulators
-      const int p0 = c_tile * BM;
+      const int p0 = (c_tile * t_mul + t_add) * BM;
 #pragma unroll
       for (int i = 0; i < WN; ++i) {
         const int co = c0 + wc * 16 * WN + 16 * i + 4 * q;
@@ -1025,7 +1049,7 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
         }
       }
       c_kt = 0;
-      c_tile += gridDim.x;
+      c_tile += walkers;
     }
   };
 
@@ -1056,15 +1080,27 @@ void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w
   const int n_ptiles = (M + 127) / 128, n_slices = (l.cout + 32 * WN - 1) / (32 * WN);
   const int per_cu = WN == 4 ? GEMM_PERS_OCC4 : 3;  // resident workgroups per CU (registers: the kernel's launch bounds)
   // every workgroup of the grid is resident at once (rounded DOWN: 520 workgroups on 512 slots are two rounds)
-  int px = per_cu * device_cu_count() / (n_slices * kc);
-  if (px > n_ptiles) px = n_ptiles;
-  if (px < 1) px = 1;
+  const int slots = per_cu * device_cu_count();
+  // XCD-aware work list (kernel comment): the models split the eight XCDs evenly and every XCD has a walker per slice
+  const int xcd_r = (kc == 1 || kc == 2 || kc == 4 || kc == 8) && n_ptiles >= 8 && slots >= 8 * n_slices ? 8 / kc : 0;
+  int walkers, wgs;
+  if (xcd_r > 0) {
+    walkers = slots / (8 * n_slices);
+    const int most = (n_ptiles + 8 / kc - 1) / (8 / kc);  // pixel tiles of an XCD
+    if (walkers > most) walkers = most;
+    wgs = 8 * n_slices * walkers;
+  } else {
+    walkers = slots / (n_slices * kc);
+    if (walkers > n_ptiles) walkers = n_ptiles;
+    if (walkers < 1) walkers = 1;
+    wgs = walkers * n_slices * kc;
+  }
   const size_t sout = POOL ? (size_t)(M / 16) * l.cout : (size_t)M * l.cout;
   constexpr size_t lds = (size_t)2 * (32 * WN + 128) * (32 + 8) * sizeof(bf16_t);  // 40 KB at WN = 4
   static_assert(lds <= 64 * 1024, "more than 64 KB of dynamic LDS needs the per-device hipFuncSetAttribute opt-in");
-  note_kernel(dim3(px, n_slices, kc), dim3(256), "gemm_pers_bf16_kernel<%d,%s>", WN, POOL ? "true" : "false");
-  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN, POOL>), dim3(px, n_slices, kc), dim3(256), lds, s, in, enc_wh, enc_w, ms,
-                     k0, l.w_off, l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, sout, n_ptiles);
+  note_kernel(dim3(wgs), dim3(256), "gemm_pers_bf16_kernel<%d,%s>", WN, POOL ? "true" : "false");
+  hipLaunchKernelGGL((gemm_pers_bf16_kernel<WN, POOL>), dim3(wgs), dim3(256), lds, s, in, enc_wh, enc_w, ms, k0, l.w_off,
+                     l.b_off, res, dst, M, l.cin, l.cout, l.relu6, (size_t)M * l.cin, sout, n_ptiles, n_slices, walkers, xcd_r);
 }
 
 template <int WN>
