@@ -616,42 +616,51 @@ __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ act,
 }
 
 // classifier on the matrix cores for already pooled features (HW == 1: the bf16 encoder's features.18 epilogue pools):
-// one wave = 16 observations x 16 outputs on v_mfma_f32_16x16x4_f32, both operands read as 16-byte groups along K
+// one workgroup = 16 observations x 16 outputs on v_mfma_f32_16x16x4_f32, both operands read as 16-byte groups along K
 // (lane (n, q) holds k = 16 j + 4 q + e of row n: MFMA e of group j contracts the four k with that e — a partition of
 // K, so the order of the instruction's internal k does not matter).  fp32 in, fp32 accumulate; the summation order
-// differs from cls_kernel's lane-strided chain (last-bit differences).  62 -> 26 us at 512 observations x 4 models.
+// differs from cls_kernel's lane-strided chain (last-bit differences).  62 -> 26 us at 512 observations x 4 models
+// (a 16 x 64 merger on the same instruction, one wave per 16 observations, was 19 us against merger_kernel's 17).
 __global__ __launch_bounds__(256) void cls_mfma_kernel(const float* __restrict__ pooled, const float* __restrict__ wbase,
                                                         size_t model_stride, int k0, size_t cls_w, size_t cls_b, int B,
                                                         float* __restrict__ feat) {
   using f32x4 = __attribute__((ext_vector_type(4))) float;
+  __shared__ f32x4 part[3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int k = blockIdx.y;
-  const int bt = blockIdx.x * 4 + wave;   // 16-observation tile
+  const int bt = blockIdx.x;              // 16-observation tile
   const int ot = blockIdx.z;              // 16-output tile
-  if (bt * 16 >= B) return;
   const float* W = wbase + (size_t)(k0 + k) * model_stride;
   const int b = min(bt * 16 + n, B - 1);  // rows past B are computed on a valid row and not stored
-  const float4* xr = reinterpret_cast<const float4*>(pooled + ((size_t)k * B + b) * LAST_C) + q;
-  const float4* wr = reinterpret_cast<const float4*>(W + cls_w + (size_t)(ot * 16 + n) * LAST_C) + q;
+  // the four waves of the workgroup split K (round 5: one wave walked all of it, 80 dependent load -> MFMA rounds;
+  // 26 -> 21 us at 512 observations x 4 models); their partial tiles are summed in wave order through LDS
+  constexpr int JW = LAST_C / 16 / 4;
+  const float4* xr = reinterpret_cast<const float4*>(pooled + ((size_t)k * B + b) * LAST_C) + q + 4 * JW * wave;
+  const float4* wr = reinterpret_cast<const float4*>(W + cls_w + (size_t)(ot * 16 + n) * LAST_C) + q + 4 * JW * wave;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll 4
-  for (int j = 0; j < LAST_C / 16; ++j) {
+#pragma unroll 5
+  for (int j = 0; j < JW; ++j) {
     const float4 a = wr[4 * j], x = xr[4 * j];
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, acc1, 0, 0, 0);
   }
+  f32x4 sum = acc0 + acc1;
+  if (wave > 0) part[wave - 1][lane] = sum;
+  __syncthreads();
+  if (wave > 0) return;
+  sum = ((sum + part[0][lane]) + part[1][lane]) + part[2][lane];
   // lane (n = observation, q): outputs 4 q + r
   const int bo = bt * 16 + n;
   if (bo < B) {
     const float4 bias = *reinterpret_cast<const float4*>(W + cls_b + ot * 16 + 4 * q);
     float4 o;
-    o.x = acc0[0] + acc1[0] + bias.x;
-    o.y = acc0[1] + acc1[1] + bias.y;
-    o.z = acc0[2] + acc1[2] + bias.z;
-    o.w = acc0[3] + acc1[3] + bias.w;
+    o.x = sum[0] + bias.x;
+    o.y = sum[1] + bias.y;
+    o.z = sum[2] + bias.z;
+    o.w = sum[3] + bias.w;
     *reinterpret_cast<float4*>(feat + ((size_t)k * B + bo) * FEAT + ot * 16 + 4 * q) = o;
   }
 }
@@ -1225,12 +1234,12 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
   // classifier logits go to `feat` if the caller wants them, else to scratch
   float* feat_buf = feat != nullptr ? feat : scratch;
   if (hw == 1 && B >= 16)
-    note_kernel(dim3((B + 63) / 64, kc, FEAT / 16), dim3(256), "cls_mfma_kernel");
+    note_kernel(dim3((B + 15) / 16, kc, FEAT / 16), dim3(256), "cls_mfma_kernel");
   else
     note_kernel(dim3(B, kc, FEAT / CLS_GROUP), dim3(256), "cls_kernel");
   note_kernel(dim3(B, kc), dim3(64), "merger_kernel");
   if (hw == 1 && B >= 16)
-    hipLaunchKernelGGL(cls_mfma_kernel, dim3((B + 63) / 64, kc, FEAT / 16), dim3(256), 0, s, act_last, enc_w, ms, k0,
+    hipLaunchKernelGGL(cls_mfma_kernel, dim3((B + 15) / 16, kc, FEAT / 16), dim3(256), 0, s, act_last, enc_w, ms, k0,
                        plan.cls_w_off, plan.cls_b_off, B, feat_buf);
   else
     hipLaunchKernelGGL(cls_kernel, dim3(B, kc, FEAT / CLS_GROUP), dim3(256), 0, s, act_last,
