@@ -25,6 +25,8 @@
 //     persist in registers across the chunks.
 // Epilogue: bias (+ residual from the block input) -> bf16.  Arithmetic order is the layer-wise kernels': MFMA chain
 // over ascending K from zero, then bias; depthwise = bias, then taps in (ky, kx) order; RNE rounding at the same points.
+#include <cstdio>
+
 #include "encoder.h"
 
 namespace rip {
@@ -66,9 +68,22 @@ __device__ __forceinline__ f32x2 relu6_2(f32x2 v) {
 }
 
 // development only (tools/dev/tile_abl.sh rebuilds with -DRIP_TILE_ABL=<bits>; wrong results): 1 = no depthwise,
-// 2 = no matrix work, 4 = no tap loads, 8 = no LDS zeroing, 16 = no epilogue stores, 32 = pointwise weights of chunk 0 only
+// 2 = no matrix work, 4 = no tap loads, 8 = no LDS zeroing, 16 = no epilogue stores (the compiler then drops the matrix
+// work as well), 32 = pointwise weights of chunk 0 only, 64 = epilogue stores predicated off at run time
 #ifndef RIP_TILE_ABL
 #define RIP_TILE_ABL 0
+#endif
+
+#ifdef RIP_TILE_TICKS  // development (tools/dev/tile_ticks.sh): shader cycles per phase of matrix wave 0 / vector wave 4, summed over the workgroups
+__device__ unsigned long long g_tile_ticks[16];
+#define TILE_TICK(slot_)                                            \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    tk[slot_] += now_ - tlast;                                      \
+    tlast = now_;                                                   \
+  } while (0)
+#else
+#define TILE_TICK(slot_) do { } while (0)
 #endif
 
 constexpr int HC = 64;        // hidden channels per chunk
@@ -136,6 +151,10 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   bf16_t* yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+#ifdef RIP_TILE_TICKS
+  unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
   // zero both E buffers once: the padding columns are never written again
   if (!(RIP_TILE_ABL & 8))
     for (int e = tid; e < 2 * Geo::E_ROWS * LD / 8; e += 512) reinterpret_cast<u32x4*>(Ebuf)[e] = zero4;
@@ -148,6 +167,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       reinterpret_cast<float4*>(Tl + 9 * HIDs)[e] = *reinterpret_cast<const float4*>(Wk + a.bd_off + 4 * e);
   }
   lds_barrier();
+  TILE_TICK(0);  // prologue: LDS zeroing, taps
 
   if (w < 4) {
     // ================= matrix waves: expand + project =================
@@ -254,11 +274,15 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       if (APF && c + 1 < nch && !(RIP_TILE_ABL & 32)) load_ap(c + 1, 0);  // projected in the next step
     };
     const bool mx_on = !(RIP_TILE_ABL & 2);
+    TILE_TICK(1);  // operand setup (block input, first weights requested)
 #pragma unroll 1
     for (int s = 0; s < nch; ++s) {  // steps with an expansion
       if (mx_on) expand(s);
+      TILE_TICK(2);
       if (s >= 2 && mx_on) project(s - 2);
+      TILE_TICK(3);
       lds_barrier();
+      TILE_TICK(4);
     }
     // drain: the last two projections; the epilogue's operands (bias, residual = block input) are requested first
     float4 bpj[NCT];
@@ -273,14 +297,29 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         rres[t][ct] = (a.residual && p < m_out) ? *reinterpret_cast<const u32x2*>(xg + (size_t)p * CIN + 16 * (ct0w + ct) + 4 * q)
                                                 : u32x2{0u, 0u};
     }
+    TILE_TICK(5);  // epilogue operands requested
     if (nch >= 2 && mx_on) project(nch - 2);
+    TILE_TICK(6);
     lds_barrier();
+    TILE_TICK(7);
     if (mx_on) project(nch - 1);
+    TILE_TICK(6);
     lds_barrier();
+    TILE_TICK(7);
+    // Epilogue.  Every workgroup of a round reaches this point together and the store burst is 10-14 % of a workgroup's
+    // time (tools/dev/tile_ticks.sh: 5-12 k cycles; 0.5-1.4 k with the stores predicated off, RIP_TILE_ABL bit 64) — close
+    // to what the memory system takes for 256 x 40 KB at once (tools/micro/store_burst.hip: 4.0 TB/s sustained in this
+    // lane layout — 64 separate 8-byte pieces per instruction —, 6.0 TB/s with 64 contiguous bytes per pixel).  Measured
+    // and not kept: (a) exchanging two channel tiles between the lane pairs (q, q ^ 1) and transposing the lane grid with
+    // ds_bpermute (16-byte stores, four consecutive lanes = 64 contiguous bytes per pixel): within +-2 us on every block;
+    // (b) the block-input / residual loads unconditional (clamped address + select): 20 us slower over the ten blocks.
+    // What would hide the burst is other work on the CU while it drains — a second resident workgroup (LDS: one fits) or
+    // a persistent workgroup that starts the next observation group's expansion under it.
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
       const int p = 16 * (wpix + WP * t) + n;
       if (p >= m_out || (RIP_TILE_ABL & 16)) continue;
+      if ((RIP_TILE_ABL & 64) && a.k0 >= 0) continue;  // development: the epilogue's arithmetic stays, its stores never run
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         f32x2 v0 = {acc[t][ct][0] + bpj[ct].x, acc[t][ct][1] + bpj[ct].y};
@@ -293,6 +332,14 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         *reinterpret_cast<u32x2*>(yg + (size_t)p * COUT + 16 * (ct0w + ct) + 4 * q) = o;
       }
     }
+    TILE_TICK(8);  // epilogue
+#ifdef RIP_TILE_TICKS
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicAdd(&g_tile_ticks[i], tk[i]);
+      atomicAdd(&g_tile_ticks[9], 1ull);
+    }
+#endif
   } else {
     // ================= vector waves: depthwise 3x3 =================
     const int vt = tid - 256;
@@ -355,19 +402,30 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       }
     };
     load_taps(0, wt[0], bd[0]);
+    TILE_TICK(1);
 #pragma unroll 1
     for (int s = 0; s < nch + 2; s += 2) {
       // even step s: depthwise of chunk s-1 (odd buffers), taps of chunk s arrive in set 0
       if (s >= 1 && s <= nch && dw_on && !(RIP_TILE_ABL & 1))
         depthwise(Ebuf + (size_t)Geo::E_ROWS * LD, Dbuf + (size_t)Geo::D_ROWS * LD, wt[1], bd[1]);
       if (s + 1 < nch && !(RIP_TILE_ABL & 4)) load_taps(s + 1, wt[1], bd[1]);
+      TILE_TICK(2);
       lds_barrier();
+      TILE_TICK(3);
       if (s + 1 >= nch + 2) break;
       // odd step s+1: depthwise of chunk s (even buffers)
       if (s + 1 <= nch && dw_on && !(RIP_TILE_ABL & 1)) depthwise(Ebuf, Dbuf, wt[0], bd[0]);
       if (s + 2 < nch && !(RIP_TILE_ABL & 4)) load_taps(s + 2, wt[0], bd[0]);
+      TILE_TICK(2);
       lds_barrier();
+      TILE_TICK(3);
     }
+#ifdef RIP_TILE_TICKS
+    if (tid == 256) {
+      atomicAdd(&g_tile_ticks[10], tk[2]);
+      atomicAdd(&g_tile_ticks[11], tk[3]);
+    }
+#endif
   }
 }
 
@@ -395,6 +453,20 @@ hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
   note_kernel(dim3((a.B + G - 1) / G, 1, kc), dim3(512), "irb_tile_bf16_kernel<%d,%d,%d,%d,%d,%s,%s,%d> G=%d", HIN, STRIDE, CIN, COUT,
               GMAX, AEF ? "true" : "false", APF ? "true" : "false", WCH, G);
   hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
+#ifdef RIP_TILE_TICKS
+  {
+    unsigned long long t[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_tile_ticks), sizeof(t));
+    const double n = t[9] > 0 ? (double)t[9] : 1.0, st = a.HID / HC;
+    fprintf(stderr, "tile<%d,%d,%d,%d,G%d,%d> cycles per workgroup: prologue %.0f setup %.0f | per step (%d): expand %.0f project %.0f barrier %.0f | "
+            "drain: requests %.0f projections 2 x %.0f barriers 2 x %.0f epilogue %.0f | vector wave per step: work %.0f barrier %.0f\n",
+            HIN, STRIDE, CIN, COUT, G, WCH, t[0] / n, t[1] / n, (int)st, t[2] / n / st, t[3] / n / st, t[4] / n / st, t[5] / n, t[6] / n / 2,
+            t[7] / n / 2, t[8] / n, t[10] / n / (st + 2), t[11] / n / (st + 2));
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_ticks), z, sizeof(z));
+  }
+#endif
   return hipGetLastError();
 }
 
