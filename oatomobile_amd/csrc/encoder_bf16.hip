@@ -903,8 +903,8 @@ __global__ __launch_bounds__(256, WN == 4 ? GEMM_PERS_OCC4 : 3) void gemm_pers_b
   // Work of workgroup L of the 1-D grid: channel slice, model, and the pixel tiles (t_first + i * walkers) * t_mul + t_add.
   // xcd_r > 0 (the launcher: the model count divides 8): workgroup L runs on XCD L % 8 (observed placement, used for
   // speed only), and an XCD serves ONE model and every xcd_r-th pixel tile of it — each activation tile crosses the
-  // fabric into one L2 instead of into several (features.18 at 512 observations x 4 models: rocprofv3 FETCH_SIZE 157 MB
-  // per launch for 21 MB of activations + 3 MB of weights with the (tile, slice, model) grid; 54 -> 48 us).
+  // fabric into one L2 instead of into several (features.18 at 512 observations x 4 models, 21 MB of activations + 3 MB of
+  // weights: rocprofv3 FETCH_SIZE 157 -> 13.6 MB per launch, profiles/r5/pmc_summary_v2 / v3.csv; 54 -> 48 us).
   int k, c0, t_first, t_mul, t_add, n_loc;
   {
     const int L = blockIdx.x;
