@@ -511,6 +511,42 @@ def test_bf16_headline_launch_shape_vs_bf16_oracle(dev, variant, csv_path):
   assert max(f for _, f, _ in worst) < 0.02
 
 
+def test_bf16_model_count_does_not_change_a_model(dev):
+  """The persistent GEMM of features.18 walks an XCD-aware work list whose shape depends on the number of models in
+  the launch (1, 2, 4, 8 models: 8 / 4 / 2 / 1 XCDs per model; any other count: the plain (tile, slice, model) list), and
+  the fused blocks size their grids on B x k_count.  A model's z must not depend on who else is in the launch beyond
+  the bf16 noise of a different kernel selection: K = 8 models at B = 192, every prefix count 1 .. 8 and a launch that
+  starts in the middle (k_begin = 3), against the model encoded alone."""
+  from oatomobile_amd import _lib, RIPAgent
+  K, B, C = 8, 192, 2
+  models = [hip_model(300 + k, dev, max_batch=1) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=B, device=dev, encoder_dtype="bf16")
+  h, lib = agent._handle, _lib.load()
+  h.set_option(_lib.OPT_KERNEL_LOG, 1)
+  rng = np.random.default_rng(91)
+  vis = torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32))
+  vis = (vis * (torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32)) < 0.3)).to(dev)
+  vec = torch.from_numpy(rng.normal(0, 2, size=(B, 5)).astype(np.float32)).to(dev)
+
+  def encode(k0, kc):
+    z = torch.full((kc, B, 64), float("nan"), device=dev)
+    _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), B, k0, kc, _lib.ENC_DTYPES["bf16"], _lib.ptr(z), None, h.stream()))
+    return z.cpu().numpy(), {l.split(" ")[0] for l in h.kernel_log()}
+
+  alone = np.stack([encode(k, 1)[0][0] for k in range(K)])
+  assert np.isfinite(alone).all()
+  scale = np.abs(alone).max()
+  gemm_counts = []
+  for k0, kc in [(0, c) for c in range(2, K + 1)] + [(3, 3), (3, 5), (6, 2)]:
+    z, kernels = encode(k0, kc)
+    assert np.isfinite(z).all(), (k0, kc)
+    d = np.abs(z - alone[k0:k0 + kc]).max()
+    assert d <= 0.03 * scale, "models %d..%d in one launch differ from the models alone: %.3g of %.3g" % (k0, k0 + kc - 1, d, scale)
+    if "gemm_pers_bf16_kernel<4,true>" in kernels:
+      gemm_counts.append(kc)
+  assert {2, 3, 4, 8} <= set(gemm_counts), gemm_counts  # every branch of the work list ran
+
+
 def test_bf16_encoder_end_to_end_vs_bf16_oracle(dev):
   """BASELINE config 3 end to end.  z of the shipped bf16 path against the bf16 oracle, gated by what the oracle ITSELF
   does under the only freedom a correct bf16 implementation has — which way an element on a rounding boundary falls:
