@@ -28,6 +28,7 @@
 #include <cstdio>
 
 #include "encoder.h"
+#include "flow.h"  // device_cu_count
 
 namespace rip {
 
@@ -140,16 +141,30 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = blockIdx.z;
-  const int img0 = blockIdx.x * a.G;
-  const int n_img = min(a.G, a.B - img0);
-  const int m_in = n_img * HWI, m_out = n_img * HWO;
   const int HID = a.HID;
   const int nch = HID / HC;
   const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
   const bf16_t* Wh = a.whbase + (size_t)(a.k0 + k) * a.model_stride;
-  const bf16_t* xg = a.x + ((size_t)k * a.B + img0) * HWI * CIN;
-  bf16_t* yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // PERSISTENT over observation groups (round 5): one workgroup per CU is resident (LDS), so a large launch used to be
+  // two rounds of workgroups; now a workgroup walks the groups blockIdx.x, + gridDim.x, ... of its model: the LDS
+  // prologue (taps, zeroing: 4-8 k cycles of a 50-140 k cycle group, tools/dev/tile_ticks.sh) is paid once, and a
+  // group's output stores drain under the next group's operand loads.  (The (group, chunk) sequence flattened into ONE
+  // pipeline — the next group's expansions under the previous group's last projections — needs the next group's block
+  // input live during the epilogue: 110-190 bytes of scratch per lane with reloads inside the step loop; not shipped.)
+  const int n_groups = (a.B + a.G - 1) / a.G;
+  const int ng = (n_groups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;  // (the launcher: gridDim.x <= n_groups)
+  int img0 = 0, m_in = 0, m_out = 0;  // the current group (set by enter_group)
+  const bf16_t* xg = nullptr;
+  bf16_t* yg = nullptr;
+  auto enter_group = [&](int j) {
+    img0 = ((int)blockIdx.x + j * (int)gridDim.x) * a.G;
+    const int n_img = min(a.G, a.B - img0);
+    m_in = n_img * HWI;
+    m_out = n_img * HWO;
+    xg = a.x + ((size_t)k * a.B + img0) * HWI * CIN;
+    yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
+  };
 
 #ifdef RIP_TILE_TICKS
   unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -174,22 +189,9 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     const int n = lane & 15, q = lane >> 4;
     const int wpix = w / WCH, wch = w % WCH;  // this wave's pixel partition / channel partition
     const int ht0 = wch * NHT, ct0w = wch * NCT;
-    u32x4 xb[TIN][KSX];   // block input, B operands
-    int erow[TIN];        // padded E row of this lane's pixel per tile (the dump row beyond the workgroup's pixels)
-#pragma unroll
-    for (int t = 0; t < TIN; ++t) {
-      const int px = 16 * (wpix + WP * t) + n;
-#pragma unroll
-      for (int ks = 0; ks < KSX; ++ks)
-        xb[t][ks] = px < m_in ? *reinterpret_cast<const u32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q) : zero4;
-      const int g = px / HWI, r = px - g * HWI, iy = r / HIN, ix = r - iy * HIN;
-      erow[t] = px < m_in ? g * HIN * PW + iy * PW + ix + 1 : Geo::E_DUMP;
-    }
+    u32x4 xb[TIN][KSX];   // block input of the current group, B operands
+    int erow[TIN];        // padded E row of this lane's pixel per tile (the dump row beyond the group's pixels)
     f32x4 acc[TOUT][NCT];
-#pragma unroll
-    for (int t = 0; t < TOUT; ++t)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ae[NHT][KSX], ap[CTG][NKP];
     float4 be[NHT];
@@ -209,8 +211,6 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
 #pragma unroll
         for (int ks = 0; ks < NKP; ++ks) ap[ct][ks] = *reinterpret_cast<const u32x4*>(wp + (size_t)16 * ct * HID + 32 * ks);
     };
-    if (AEF) load_ae(0);
-    if (APF) load_ap(0, 0);
     // Both phases are software-pipelined by hand across pixel tiles: the MFMAs of tile t + 1 are issued before the
     // epilogue (expansion) / behind the operand reads (projection) of tile t.  Left to itself the compiler put every
     // chain into ONE accumulator tuple: MFMA pair, wait for the result, ten VALU instructions, next pair — the matrix
@@ -274,6 +274,29 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       if (APF && c + 1 < nch && !(RIP_TILE_ABL & 32)) load_ap(c + 1, 0);  // projected in the next step
     };
     const bool mx_on = !(RIP_TILE_ABL & 2);
+#pragma unroll 1
+    for (int j = 0; j < ng; ++j) {  // this workgroup's observation groups
+    enter_group(j);
+    // (lane coordinates re-derived behind an opaque copy per group and again for the epilogue: otherwise the per-lane
+    // offsets of the group's loads and stores are group-invariant, get hoisted above this loop and spill — 150-190 bytes
+    // of scratch per lane, reloaded inside the step loop)
+    int ng_ = n, qg_ = q;
+    asm volatile("" : "+v"(ng_), "+v"(qg_));
+#pragma unroll
+    for (int t = 0; t < TIN; ++t) {
+      const int px = 16 * (wpix + WP * t) + ng_;
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks)
+        xb[t][ks] = px < m_in ? *reinterpret_cast<const u32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * qg_) : zero4;
+      const int g = px / HWI, r = px - g * HWI, iy = r / HIN, ix = r - iy * HIN;
+      erow[t] = px < m_in ? g * HIN * PW + iy * PW + ix + 1 : Geo::E_DUMP;
+    }
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (AEF) load_ae(0);
+    if (APF) load_ap(0, 0);
     TILE_TICK(1);  // operand setup (block input, first weights requested)
 #pragma unroll 1
     for (int s = 0; s < nch; ++s) {  // steps with an expansion
@@ -287,14 +310,16 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     // drain: the last two projections; the epilogue's operands (bias, residual = block input) are requested first
     float4 bpj[NCT];
     u32x2 rres[TOUT][NCT];
+    int ne_ = n, qe_ = q;
+    asm volatile("" : "+v"(ne_), "+v"(qe_));
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) bpj[ct] = *reinterpret_cast<const float4*>(W + a.bp_off + 16 * (ct0w + ct) + 4 * q);
+    for (int ct = 0; ct < NCT; ++ct) bpj[ct] = *reinterpret_cast<const float4*>(W + a.bp_off + 16 * (ct0w + ct) + 4 * qe_);
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
-      const int p = 16 * (wpix + WP * t) + n;
+      const int p = 16 * (wpix + WP * t) + ne_;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
-        rres[t][ct] = (a.residual && p < m_out) ? *reinterpret_cast<const u32x2*>(xg + (size_t)p * CIN + 16 * (ct0w + ct) + 4 * q)
+        rres[t][ct] = (a.residual && p < m_out) ? *reinterpret_cast<const u32x2*>(xg + (size_t)p * CIN + 16 * (ct0w + ct) + 4 * qe_)
                                                 : u32x2{0u, 0u};
     }
     TILE_TICK(5);  // epilogue operands requested
@@ -317,7 +342,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     // a persistent workgroup that starts the next observation group's expansion under it.
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
-      const int p = 16 * (wpix + WP * t) + n;
+      const int p = 16 * (wpix + WP * t) + ne_;
       if (p >= m_out || (RIP_TILE_ABL & 16)) continue;
       if ((RIP_TILE_ABL & 64) && a.k0 >= 0) continue;  // development: the epilogue's arithmetic stays, its stores never run
 #pragma unroll
@@ -329,10 +354,11 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         u32x2 o;
         o.x = pack_bf16(v0);
         o.y = pack_bf16(v1);
-        *reinterpret_cast<u32x2*>(yg + (size_t)p * COUT + 16 * (ct0w + ct) + 4 * q) = o;
+        *reinterpret_cast<u32x2*>(yg + (size_t)p * COUT + 16 * (ct0w + ct) + 4 * qe_) = o;
       }
     }
     TILE_TICK(8);  // epilogue
+    }  // groups
 #ifdef RIP_TILE_TICKS
     if (tid == 0) {
 #pragma unroll
@@ -344,10 +370,10 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
     // ================= vector waves: depthwise 3x3 =================
     const int vt = tid - 256;
     const int c8 = vt & 7, dcol = (vt >> 3) % HOUT, dimg = (vt >> 3) / HOUT;
-    const bool dw_on = dimg < n_img;
+    const int dimg_c = dimg < G ? dimg : 0;  // (threads beyond G * HOUT * 8 never work; their addresses stay inside the buffers)
     // first of the three padded columns this thread reads (input column dcol*S - 1 -> padded index dcol*S)
-    const int e_off = ((dw_on ? dimg : 0) * HIN * PW + dcol * STRIDE) * LD + 8 * c8;
-    const int d_off = ((dw_on ? dimg : 0) * HWO + dcol) * LD + 8 * c8;
+    const int e_off = (dimg_c * HIN * PW + dcol * STRIDE) * LD + 8 * c8;
+    const int d_off = (dimg_c * HWO + dcol) * LD + 8 * c8;
     f32x2 wt[2][9][4], bd[2][4];
     auto load_taps = [&](int c, f32x2(&wt_)[9][4], f32x2(&bd_)[4]) {
       const float* wd = Tl + c * HC + 8 * c8;
@@ -401,6 +427,10 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
         }
       }
     };
+#pragma unroll 1
+    for (int j = 0; j < ng; ++j) {  // this workgroup's observation groups (the same barrier sequence as the matrix waves)
+    enter_group(j);
+    const bool dw_on = dimg * HWI < m_in;  // this thread's observation exists in the group (the last one may be ragged)
     load_taps(0, wt[0], bd[0]);
     TILE_TICK(1);
 #pragma unroll 1
@@ -420,6 +450,7 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
       lds_barrier();
       TILE_TICK(3);
     }
+    }  // groups
 #ifdef RIP_TILE_TICKS
     if (tid == 256) {
       atomicAdd(&g_tile_ticks[10], tk[2]);
@@ -450,9 +481,14 @@ hipError_t launch_tile(TileArgs a, int kc, hipStream_t s) {
   }
   if (a.HID != 6 * CIN) return hipErrorInvalidValue;
   static_assert(Geo::lds_bytes(6 * CIN) <= 160 * 1024, "LDS budget");
-  note_kernel(dim3((a.B + G - 1) / G, 1, kc), dim3(512), "irb_tile_bf16_kernel<%d,%d,%d,%d,%d,%s,%s,%d> G=%d", HIN, STRIDE, CIN, COUT,
+  // one workgroup per CU is resident (LDS); each walks the observation groups wgx, wgx + gx, ... of its model
+  const int n_groups = (a.B + G - 1) / G;
+  int gx = device_cu_count() / kc;
+  if (gx < 1) gx = 1;
+  if (gx > n_groups) gx = n_groups;
+  note_kernel(dim3(gx, 1, kc), dim3(512), "irb_tile_bf16_kernel<%d,%d,%d,%d,%d,%s,%s,%d> G=%d", HIN, STRIDE, CIN, COUT,
               GMAX, AEF ? "true" : "false", APF ? "true" : "false", WCH, G);
-  hipLaunchKernelGGL(kern, dim3((a.B + G - 1) / G, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
+  hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
 #ifdef RIP_TILE_TICKS
   {
     unsigned long long t[16];
