@@ -197,17 +197,24 @@ __global__ __launch_bounds__(512) void irb_tile_bf16_kernel(TileArgs a) {
 
     u32x4 ae[NHT][KSX], ap[CTG][NKP];
     float4 be[NHT];
+    // (the row pointers of a weight request are chunk-invariant per lane: left alone they are hoisted above the group
+    // loop — one 64-bit pointer per channel tile, 16 * HID elements apart, beyond any immediate offset — and spill;
+    // behind an opaque copy of the lane coordinates they cost a handful of integer instructions per request)
     auto load_ae = [&](int c) {  // expand weights / bias of chunk c
+      int n_ = n, q_ = q;
+      asm volatile("" : "+v"(n_), "+v"(q_));
 #pragma unroll
       for (int ht = 0; ht < NHT; ++ht) {
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks)
-          ae[ht][ks] = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)(c * HC + 16 * (ht0 + ht) + n) * CIN + 32 * ks + 8 * q);
-        be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q);
+          ae[ht][ks] = *reinterpret_cast<const u32x4*>(Wh + a.we_off + (size_t)(c * HC + 16 * (ht0 + ht) + n_) * CIN + 32 * ks + 8 * q_);
+        be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q_);
       }
     };
     auto load_ap = [&](int c, int ct0) {  // projection weights of chunk c, channel tiles ct0 .. ct0 + CTG - 1
-      const bf16_t* wp = Wh + a.wp_off + (size_t)(16 * (ct0w + ct0) + n) * HID + c * HC + 8 * q;
+      int n_ = n, q_ = q;
+      asm volatile("" : "+v"(n_), "+v"(q_));
+      const bf16_t* wp = Wh + a.wp_off + (size_t)(16 * (ct0w + ct0) + n_) * HID + c * HC + 8 * q_;
 #pragma unroll
       for (int ct = 0; ct < CTG; ++ct)
 #pragma unroll
