@@ -312,7 +312,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
       // (pixel tile, group) items one after the other.  An item's nine MFMAs accumulate into ONE register tuple and
       // issue back to back; the operand reads of item i + 1 are issued BEFORE item i's chain, and the chain starts with
       // the K block whose operand was read last (LDS returns in order: one s_waitcnt in front of the chain covers all
-      // five, nothing sits between two dependent MFMAs).
+      // five, nothing sits between two dependent MFMAs).  Round 5, measured and not kept: two items interleaved
+      // instruction by instruction with both operand sets read up front (the nine MFMAs of an item are a dependent chain,
+      // ~36 cycles each at a 16-cycle issue rate; per-row counters: the depthwise is 29-48 % of a row): features.2
+      // 155 -> 159 us, features.4 70 -> 71, features.3 (the second operand set spills) 176 -> 197 — as round 4 found at
+      // an earlier stage of the kernel, the chain latency is not what a row waits for.
       constexpr int NIT = NPTO * NG;
       u32x4 bt[BTD][5];  // BTD = 2: item i + 1's operands in flight during item i's chain (register-tight shapes: 1)
       auto issue_reads = [&](int item, u32x4(&dst)[5]) __attribute__((always_inline)) {
