@@ -427,7 +427,7 @@ def test_bf16_block_kernels_everywhere(dev):
 
 def _headline_kernel_names(csv_path):
   """Encoder kernels of the driver-shaped bench (512 observations x 4 models, bf16) as rocprofv3 saw them:
-  profiles/r5/bench_kernel_stats_v3.csv for what ships, profiles/r4/bench_kernel_stats_v3.csv (the file VERDICT r4
+  profiles/r5/bench_kernel_stats_v4.csv for what ships, profiles/r4/bench_kernel_stats_v3.csv (the file VERDICT r4
   recomputed the roofline from) for round 4's selection, which RIP_OPT_ENCODER_VARIANT bit 8 restores."""
   import csv
   import re
