@@ -243,6 +243,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
     for (int i = 0; i < NPTI; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, xoff[i], 0, 0);
   };
   const int lane_ring = (n * ELD + 4 * q) * 2;  // byte offset of this lane's 4 channels of pixel n inside a ring row
+  // Round 5, measured and not kept (tools/dev ticks, -DRIP_IRB2_TICKS: per row expand 0.7-1.7 k, depthwise 1.0-2.1 k,
+  // barrier 0.5-0.7 k, projection 0.3-0.8 k cycles; per observation a prologue of 8-11 k cycles = 8-15 % of the kernel):
+  // letting the last two rows of an observation request the first rows of the workgroup's NEXT observation (instead of
+  // rows off the image) removes the prologue's own requests and changes neither the prologue's time nor the kernels'
+  // (155 / 176 / 70 -> 157 / 177 / 73 us): what the prologue waits for is the memory latency of first-touch rows under
+  // load, which two rows of lead do not cover either.
   // The row loop holds NO branch between a vector-memory load and its use: the s_waitcnt insertion falls back to
   // vmcnt(0) behind every control-flow merge, which waits for the operand prefetches of the NEXT rows as well (measured:
   // the "expand" phase of the stride-2 blocks and the residual add each cost a full memory latency per row that way).
@@ -401,13 +407,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
       row(oy, xa, 0);
       if (oy + 1 < oy1) row(oy + 1, xb, 1);
     }
+    IRB2_TICK(5);
     lds_barrier();  // the last row's projection has read ds before the next observation's depthwise writes it
+    IRB2_TICK(4);  // (development: the wait at the end of an observation)
   }
 #ifdef RIP_IRB2_TICKS
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) atomicAdd(&g_irb2_ticks[i], tk[i]);
-    atomicAdd(&g_irb2_ticks[6], (unsigned long long)(oy1 - oy0));
+    atomicAdd(&g_irb2_ticks[6], (unsigned long long)(oy1 - oy0) * ((a.B - 1 - blockIdx.y) / gridDim.y + 1));
   }
 #endif
 }
@@ -446,8 +454,8 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_irb2_ticks), sizeof(t));
     const double rows = t[6] > 0 ? (double)t[6] : 1.0;  // wave-rows
-    fprintf(stderr, "irb2<S=%d HID=%d NW=%d NG=%d> cycles per wave-row: expand %.0f  depthwise %.0f  barrier %.0f  project %.0f  loop %.0f\n",
-            S, HID, NW, NG, t[0] / rows, t[1] / rows, t[2] / rows, t[3] / rows, t[5] / rows);
+    fprintf(stderr, "irb2<S=%d HID=%d NW=%d NG=%d> cycles per wave-row: expand %.0f  depthwise %.0f  barrier %.0f  project %.0f  | per observation: prologue %.0f  end barrier %.0f\n",
+            S, HID, NW, NG, t[0] / rows, t[1] / rows, t[2] / rows, t[3] / rows, t[5] / rows * H_OUT, t[4] / rows * H_OUT);
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_irb2_ticks), z, sizeof(z));
   }
