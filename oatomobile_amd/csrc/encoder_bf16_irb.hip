@@ -298,6 +298,8 @@ __global__ __launch_bounds__(NW * 64, 2) void irb_rows_bf16_kernel(IrbArgs a) {
 #pragma unroll 1
   for (int oy = oy0; oy < oy1; ++oy) {
     // 1. expand the S new rows (operands fetched during the previous row), then request the next ones
+    // (round 5: requested two / three output rows ahead with as many register sets — features.7, which has the registers:
+    // 48.0 / 46.7 / 47.2 us; the rows do not wait for their input)
 #pragma unroll
     for (int i = 0; i < STRIDE; ++i) expand_row(oy * STRIDE + 2 - STRIDE + i, xr[i]);
     // (unconditional: past the band the rows are image rows nobody uses, past the image load_x takes an empty
