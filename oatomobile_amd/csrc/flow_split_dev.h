@@ -82,6 +82,8 @@ __device__ __forceinline__ void split8(const float* v, float s, h16x8& hi, h16x8
     f32x2 x = {v[2 * p], v[2 * p + 1]};
     if (SCALED) x = x * f32x2{s, s};
     const h16x2 h = __builtin_convertvector(x, h16x2);
+    // (round 5: the residual as v_fma_mix_f32(h.half, -1, x) from inline assembly — four instead of five instructions
+    // per pair, 241 fewer in the kernel — measured 2.491 vs 2.494 ms: not kept)
     const f32x2 back = __builtin_convertvector(h, f32x2);
     const h16x2 l = __builtin_convertvector(x - back, h16x2);
     uh[p] = __builtin_bit_cast(unsigned, h);
