@@ -547,6 +547,38 @@ def test_bf16_model_count_does_not_change_a_model(dev):
   assert {2, 3, 4, 8} <= set(gemm_counts), gemm_counts  # every branch of the work list ran
 
 
+def test_bf16_ragged_last_group_of_a_persistent_workgroup(dev):
+  """The tile blocks and the row-streaming blocks keep their workgroups resident and let them walk several observation
+  groups.  With K = 4 models and B = 510 observations a tile workgroup's SECOND group is the ragged one (2 of 4
+  observations; its LDS rows still hold the previous, full group), and the row-streaming workgroups walk 3-4 observations
+  each.  Observations are independent: the first 510 rows of the B = 512 launch must come out the same."""
+  from oatomobile_amd import _lib, RIPAgent
+  K, B, C = 4, 512, 2
+  models = [hip_model(400 + k, dev, max_batch=1) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=B, device=dev, encoder_dtype="bf16")
+  h, lib = agent._handle, _lib.load()
+  h.set_option(_lib.OPT_KERNEL_LOG, 1)
+  rng = np.random.default_rng(123)
+  vis = torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32))
+  vis = (vis * (torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32)) < 0.3)).to(dev)
+  vec = torch.from_numpy(rng.normal(0, 2, size=(B, 5)).astype(np.float32)).to(dev)
+
+  def encode(b):
+    z = torch.full((K, b, 64), float("nan"), device=dev)
+    _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, K, _lib.ENC_DTYPES["bf16"], _lib.ptr(z), None, h.stream()))
+    return z.cpu().numpy(), h.kernel_log()
+
+  z_full, log_full = encode(B)
+  z_ragged, log_ragged = encode(B - 2)
+  assert np.isfinite(z_ragged).all()
+  tiles = [l for l in log_ragged if l.startswith("irb_tile_bf16_kernel")]
+  assert tiles and all("grid=(64,1,4)" in l for l in tiles), tiles  # two groups per workgroup, the last one ragged
+  d = np.abs(z_ragged - z_full[:, :B - 2]).max()
+  same_kernels = [l.split(" ")[0] for l in log_full] == [l.split(" ")[0] for l in log_ragged]
+  print("B = 510 vs the first 510 rows of B = 512: max|dz| = %.3g (same kernels: %s)" % (d, same_kernels))
+  assert d <= (0.0 if same_kernels else 0.03 * np.abs(z_full).max())
+
+
 def test_bf16_encoder_end_to_end_vs_bf16_oracle(dev):
   """BASELINE config 3 end to end.  z of the shipped bf16 path against the bf16 oracle, gated by what the oracle ITSELF
   does under the only freedom a correct bf16 implementation has — which way an element on a rounding boundary falls:
