@@ -293,7 +293,7 @@ int rip_train_peek(rip_trainer* t, int layer, int what, int B, float* dst_dev, s
 int rip_train_num_layers(const rip_trainer* t);
 
 /* Implementation knobs (results are identical within the parity tolerance; tests run every setting).
- *   RIP_OPT_SEARCH_KERNEL: 0 = auto (the split-f16 phase-sequential kernel when B*N >= 2304 and N % 16 == 0, else
+ *   RIP_OPT_SEARCH_KERNEL: 0 = auto (the split-f16 phase-sequential kernel when B*N >= 1280 and N % 16 == 0, else
  *     wave-per-chain),
  *     1 = wave-per-chain kernel (lowest latency, any K/N),
  *     (2 = round 1's fp32-MFMA wave-per-model pipeline: removed in round 5, RIP_EINVAL),

@@ -631,7 +631,10 @@ static bool split_weights_ok(const rip_handle* h) {
 }
 static int pick_search_kernel(const rip_handle* h, int B, int N) {
   if (h->search_mode != 0) return h->search_mode;
-  const bool big = (size_t)B * N >= 2304;
+  // crossover measured at K = 4, N = 128 (round 5): the wave-per-chain kernel costs 64.5 us per observation, a launch of
+  // the split kernel one workgroup-time (630 us) up to 1024 blocks: 10 observations (517 / 646 / 773 / 1028 us against
+  // 629 / 631 / 632 / 632 at B = 8 / 10 / 12 / 16)
+  const bool big = (size_t)B * N >= 1280;
   if (!(big && N % 16 == 0 && h->K <= RIP_MAX_MODELS)) return 1;
   return split_weights_ok(h) ? 4 : 3;  // a flow weight beyond the binary16 operand range: the fp32-MFMA kernel
 }

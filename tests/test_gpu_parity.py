@@ -859,7 +859,7 @@ def _operand_range_case(dev, zscale, wscale, seed):
   relative posterior / gradient errors over three observations."""
   from oatomobile_amd import _lib, RIPAgent
   from oracle import reference_cpu as O
-  K, N, S, algo = 3, 128, 24, "MA"  # S x N = 3072 >= 2304: what `auto` would give the split kernel as well
+  K, N, S, algo = 3, 128, 24, "MA"  # S x N = 3072 >= 1280: what `auto` would give the split kernel as well
   hips, refs = _scaled_flow_models([300 + k for k in range(K)], wscale, dev)
   rng = np.random.default_rng(seed)
   z_np = (np.abs(rng.normal(size=(K, S, 64))) * zscale).astype(np.float32)  # a ReLU output: non-negative
