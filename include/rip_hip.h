@@ -308,7 +308,7 @@ int rip_train_num_layers(const rip_trainer* t);
  *     bf16 encoder: count >= 1 fuses the stem with features.1 (one kernel), blocks 1..6 of the count are the
  *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
  *     and 16 (features.17, round 5); features.18 runs as a GEMM with the pooled epilogue.  auto = everything, the tile kernel only when the call carries
- *     >= 64 (model, observation) pairs (an explicit count uses it regardless).
+ *     >= 96 (model, observation) pairs (an explicit count uses it regardless).
  *   RIP_OPT_SEARCH_REGROUP: retired in round 5 (rounds 3 / 4: regrouped the candidates of ONE workgroup by selected
  *     member between Adam steps; bit-identical results, fewer adjoints per block, no faster: the workgroup walks the
  *     model phases in lockstep).  Accepted, no effect.

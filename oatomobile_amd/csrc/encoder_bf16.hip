@@ -1201,10 +1201,11 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
   };
   // inverted-residual blocks as one fused kernel each.  auto (measured, K = 4): the front kernel and the row-streaming
   // blocks (features.0-7) win at every batch size (B = 1: 304 vs 311 us, B = 4: 359 vs 401); the tile blocks
-  // (features.8-16, one workgroup per 1-8 observations walking 6-15 hidden chunks in sequence) from 64 (model,
-  // observation) pairs (B = 16: 481 vs ~500 us, B = 128: 779 vs 916; B = 1: 442 vs 304)
+  // (features.8-17, one workgroup per 1-8 observations walking 6-15 hidden chunks in sequence) from 96 (model,
+  // observation) pairs (round 5, tile vs layer-wise: B = 16: 396 vs 315 us, B = 24: 405 vs 403, B = 32: 417 vs 432, B = 64: 470 vs 602,
+  // B = 128: 562 vs 736; the layer-wise kernels grow by 7.3 us per observation, the tile blocks by 1.3)
   const bool auto_sel = fused_blocks < 0;
-  const bool tile_ok = !auto_sel || (long)B * kc >= 64;
+  const bool tile_ok = !auto_sel || (long)B * kc >= 96;
   if (auto_sel) fused_blocks = 17;
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
