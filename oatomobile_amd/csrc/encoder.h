@@ -159,4 +159,25 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
 hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                               size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);
 
+// Row bands per observation for the row-streaming blocks (encoder_bf16_irb.hip, encoder_bf16_irb2.hip): `slots` resident
+// workgroups walk pairs * bands (model, observation, band) items; an item costs its rows plus ~2 rows of halo / prologue.
+// The band count that minimises rounds * (rows + 2) — 768 pairs on 512 slots: one band is two rounds of 27, two bands are
+// three rounds of 15 (round 5: features.2 at 192 observations x 4 models 81 us with one band per observation).  A
+// handful of pairs: all rounds are one, the shortest bands win (the launch is a latency chain).
+inline int pick_row_bands(long pairs, int h_out, int min_rows, int slots) {
+  int best = 1;
+  long best_cost = -1;
+  const int max_b = h_out / min_rows > 1 ? h_out / min_rows : 1;
+  for (int b = 1; b <= max_b; ++b) {
+    const int rows = (h_out + b - 1) / b, nb = (h_out + rows - 1) / rows;
+    const long rounds = (pairs * nb + slots - 1) / slots;
+    const long cost = rounds * (rows + 2);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = nb;
+    }
+  }
+  return best;
+}
+
 }  // namespace rip

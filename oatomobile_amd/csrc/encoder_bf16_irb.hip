@@ -467,11 +467,9 @@ hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, co
   const int ew_tiles = 16 * ((a.H_in + 15) / 16) + 1;  // the expand writes whole 16-pixel tiles (zeros past the row)
   if (a.EW < ew_tiles) a.EW = ew_tiles;
   a.WP = (a.H_out + 15) & ~15;
-  // bands: enough workgroups for ~3 per CU, but bands re-expand their halo rows, so keep them >= 6 rows
-  int bands = (int)((768 + (long)B * kc - 1) / ((long)B * kc));
-  const int min_rows = (long)B * kc <= 16 ? 2 : 6;  // a handful of observations: a latency chain, short bands (as irb2)
-  if (bands > a.H_out / min_rows) bands = a.H_out / min_rows;
-  if (bands < 1) bands = 1;
+  // bands re-expand their halo rows, so keep them >= 6 rows (a handful of observations: a latency chain, short bands)
+  const int min_rows = (long)B * kc <= 16 ? 2 : 6;
+  int bands = pick_row_bands((long)B * kc, a.H_out, min_rows, 2 * device_cu_count());
   a.band_rows = (a.H_out + bands - 1) / bands;
   bands = (a.H_out + a.band_rows - 1) / a.band_rows;
   if (le == nullptr) return launch_irb<1, 4, false, 1, 4, 4, false, false, true, 32, 1>(a, kc, bands, s);

@@ -423,13 +423,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
 template <int S, int CIN, int HID, int COUT, int H_IN, int H_OUT, int NW, int NG, bool RES, int OCC, int BTD = 2>
 hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
   using SH = Irb2Shape<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG>;
-  // bands: enough workgroups for ~3 per CU, but bands re-expand their halo rows, so keep them >= 6 rows
-  int bands = (int)((768 + (long)B * kc - 1) / ((long)B * kc));
-  // (a handful of observations: the launch is a latency chain, not a throughput problem — bands of 2-3 rows, one
-  // workgroup each, although every band re-expands its halo row)
+  // bands re-expand their halo rows, so keep them >= 6 rows (a handful of observations: the launch is a latency chain,
+  // not a throughput problem — bands of 2-3 rows, one workgroup each, although every band re-expands its halo row)
   const int min_rows = (long)B * kc <= 16 ? 2 : 6;
-  if (bands > H_OUT / min_rows) bands = H_OUT / min_rows;
-  if (bands < 1) bands = 1;
+  int bands = pick_row_bands((long)B * kc, H_OUT, min_rows, OCC * device_cu_count());
   a.band_rows = (H_OUT + bands - 1) / bands;
   bands = (H_OUT + a.band_rows - 1) / a.band_rows;
   auto kern = irb2_bf16_kernel<S, CIN, HID, COUT, H_IN, H_OUT, NW, NG, RES, OCC, BTD>;
