@@ -87,6 +87,16 @@ OPT_ENCODER_VARIANT, OPT_KERNEL_LOG = 5, 6
 ENC_VAR_IRB_ROUND3, ENC_VAR_FRONT_ROUND3, ENC_VAR_IRB2_ALL, ENC_VAR_F17_LAYERWISE = 1, 2, 4, 8
 SEARCH_KERNELS = {"auto": 0, "chain": 1, "phase": 3, "split": 4}
 
+
+def search_kernel_id(name: str) -> int:
+  """`search_kernel=` of the agents -> the value of `OPT_SEARCH_KERNEL`; a `ValueError` names the valid kernels
+  (round 1's "mfma" kernel, option 2, was removed in round 5: the library answers RIP_EINVAL for it)."""
+  try:
+    return SEARCH_KERNELS[name]
+  except KeyError:
+    hint = " (\"mfma\", round 1's wave-per-model kernel, was removed: use \"split\" or \"phase\")" if name == "mfma" else ""
+    raise ValueError("unknown search_kernel %r%s; valid: %s" % (name, hint, ", ".join(sorted(SEARCH_KERNELS)))) from None
+
 _lib = None
 
 

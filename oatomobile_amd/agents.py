@@ -161,7 +161,7 @@ class RIPAgent(SetPointAgent):
     max_batch: observations per `plan_batch` call.
     encoder_dtype: "fp32" (parity mode, default) or "bf16" (BASELINE config 3: bf16 activations/weights in the
       MobileNetV2 encoder with fp32 accumulation; the flow and the search stay fp32).
-    search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 1280 (N % 16 == 0, K <= 4), else the
+    search_kernel: "auto" picks the MFMA-batched kernel once B*N >= 1280 (N % 16 == 0, any K <= 8), else the
       wave-per-chain kernel; both are the same algorithm.
     graph: `__call__` (one observation per call, the reference's usage) replays ONE captured hipGraph per call
       (H2D of the observation from pinned staging, transform, K encoders, search, D2H of the plan) instead of
@@ -193,7 +193,7 @@ class RIPAgent(SetPointAgent):
     self._versions = [None] * len(self._models)
     self._sync_weights()
     # "auto" | "chain" (one wave per candidate x model chain) | "phase" / "split" (16 candidates per wave on the matrix cores: fp32 MFMA / two-term f16)
-    self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS[search_kernel])
+    self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.search_kernel_id(search_kernel))
     if fused_encoder is None and "RIP_ENCODER_FUSED" in os.environ:
       fused_encoder = int(os.environ["RIP_ENCODER_FUSED"])
     if fused_encoder is not None:

@@ -1082,7 +1082,8 @@ void launch_gemm_pers(const bf16_t* in, const bf16_t* enc_wh, const float* enc_w
   // every workgroup of the grid is resident at once (rounded DOWN: 520 workgroups on 512 slots are two rounds)
   const int slots = per_cu * device_cu_count();
   // XCD-aware work list (kernel comment): the models split the eight XCDs evenly and every XCD has a walker per slice
-  const int xcd_r = (kc == 1 || kc == 2 || kc == 4 || kc == 8) && n_ptiles >= 8 && slots >= 8 * n_slices ? 8 / kc : 0;
+  // (the work list's L % 8 placement holds on a whole MI355X only: device_xcd_count() is 0 elsewhere and the plain list runs)
+  const int xcd_r = device_xcd_count() == 8 && (kc == 1 || kc == 2 || kc == 4 || kc == 8) && n_ptiles >= 8 && slots >= 8 * n_slices ? 8 / kc : 0;
   int walkers, wgs;
   if (xcd_r > 0) {
     walkers = slots / (8 * n_slices);

@@ -103,7 +103,9 @@ hipError_t launch_aggregate_scores(const float* S, int K, int B, int N, int algo
 size_t search_lds_bytes(int K);
 // raises a kernel's dynamic-LDS limit to the CU's 160 KiB, once per (kernel, device); thread-safe, any device index
 hipError_t allow_lds(const void* fn);
-int device_cu_count();  // compute units of the current device (cached per device)
+int device_cu_count();  // compute units of the current device (cached per device); the persistent launchers assume
+                        // `occupancy x device_cu_count()` workgroups are resident at once (true for a whole device in SPX mode)
+int device_xcd_count(); // 8 on a whole MI355X (256 CUs), 0 = unknown: XCD-aware work lists off
 // phase-sequential variant (flow_phase.hip): one wave per 16-candidate block runs all K models, operands in LDS;
 // N % 16 == 0, any K <= MAX_MODELS, traces supported
 // split-f16 variant (flow_split.hip): the same decomposition with the contractions on v_mfma_f32_16x16x32_f16 and both

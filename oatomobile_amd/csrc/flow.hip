@@ -1461,6 +1461,11 @@ int device_cu_count() {
   return n;
 }
 
+// XCDs the workgroups of a launch are dealt over round-robin (workgroup L -> XCD L % n), or 0 when that is not known:
+// an MI355X in SPX mode is 8 XCDs x 32 CUs = 256 CUs; any other CU count (CPX / partitioned modes, another part) turns
+// the XCD-aware work lists OFF (results never depend on placement, only L2 reuse does).
+int device_xcd_count() { return device_cu_count() == 256 ? 8 : 0; }
+
 static int rows_grid(int rows) {
   int g = (rows + 3) / 4;
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);

@@ -51,9 +51,16 @@ inline float pack_split_operands(const float* mw, const float* wih, const float*
                                  std::vector<uint32_t>& out) {
   out.assign(MH_SIZE, 0u);
   float wmax = 0.f;
-  for (int i = 0; i < 192 * 2; ++i) wmax = std::fmax(wmax, std::fabs(wih[i]));
-  for (int i = 0; i < 192 * 64; ++i) wmax = std::fmax(wmax, std::fabs(whh[i]));
-  for (int i = 0; i < 32 * 64; ++i) wmax = std::fmax(wmax, std::fabs(w1[i]));
+  bool bad = false;  // a NaN / infinite weight (std::fmax drops NaN operands, so it is tracked on its own)
+  auto scan = [&](const float* w, int n) {
+    for (int i = 0; i < n; ++i) {
+      if (!(std::fabs(w[i]) <= 3.402823466e38f)) bad = true;
+      wmax = std::fmax(wmax, std::fabs(w[i]));
+    }
+  };
+  scan(wih, 192 * 2);
+  scan(whh, 192 * 64);
+  scan(w1, 32 * 64);
   auto put = [&](size_t row_base_dw, int lane, int i, uint16_t v) {  // half i of the lane's 16-byte entry
     uint32_t& d = out[row_base_dw + (size_t)lane * 4 + (i >> 1)];
     d = (i & 1) ? ((d & 0x0000ffffu) | ((uint32_t)v << 16)) : ((d & 0xffff0000u) | v);
@@ -103,7 +110,7 @@ inline float pack_split_operands(const float* mw, const float* wih, const float*
           dh = (i & 1) ? ((dh & 0xffffu) | ((uint32_t)h << 16)) : ((dh & 0xffff0000u) | h);
           dl = (i & 1) ? ((dl & 0xffffu) | ((uint32_t)l << 16)) : ((dl & 0xffff0000u) | l);
         }
-  return wmax == wmax ? wmax : SPLIT_W_LIMIT;  // (a NaN weight counts as out of range)
+  return bad ? SPLIT_W_LIMIT : wmax;  // (a NaN / infinite weight counts as out of range)
 }
 
 }  // namespace rip

@@ -214,7 +214,7 @@ class CandidateParallelRIP:
                                max_candidates=n_local)
     for k, m in enumerate(self._models):
       self._handle.load_model(k, m.packed_weights())
-    self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS[search_kernel])
+    self._handle.set_option(_lib.OPT_SEARCH_KERNEL, _lib.search_kernel_id(search_kernel))
     # the SAME N latent starts as RIPAgent(seed=...) draws on one GPU; this rank keeps its rows
     x0 = np.random.default_rng(seed).standard_normal((self._n_total, arch.T, 2)).astype(np.float32)
     x0[0] = 0.0

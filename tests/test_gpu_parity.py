@@ -835,8 +835,8 @@ def test_split_kernel_operand_ranges(dev, zscale, wscale):
   next for ANY kernel: round 4's kernel, which passed on seed 11, is at 3.5x / 7.8x the fp32 kernel's posterior /
   gradient error on seed 12 (profiles/r5/range_seeds_v1.log; the logarithm of the ratio scatters with sigma ~ 1).  Those
   cases therefore run SIX seeds and gate the geometric mean of (split error / fp32-kernel error) at 2 (measured over
-  seeds 11..16 at weights x 10: 1.02 / 1.15 for round 4's kernel, 1.34 / 1.06 for round 5's), every single seed at 30x
-  (3.4 sigma): the defect this gate exists for — round 5's first forward step left the WEIGHTS' low terms unscaled,
+  seeds 11..16 at weights x 10: 1.02 / 1.15 for round 4's kernel, 1.34 / 1.06 for round 5's), every single seed at 10x
+  (round 6; the recorded per-seed ratios are next to the assertion): the defect this gate exists for — round 5's first forward step left the WEIGHTS' low terms unscaled,
   2^-24-quantised — was 780x on the gradients at z x 100 and fails both.
   Found with this test and fixed: `pow2_scale` overflowed to inf for candidates whose gate gradients had all but
   vanished (NaN gradients at z x 1e3), and `goal_ll` returned -inf at |y| ~ 5e4 (all kernels; flow_math.h)."""
@@ -851,7 +851,11 @@ def test_split_kernel_operand_ranges(dev, zscale, wscale):
     ratios = [max(r[idx]["split"], 1e-4) / max(r[idx]["phase"], 1e-4) for r in runs]
     print("  %s: split / fp32-kernel error over seeds 11..16: %s, geometric mean %.2f" %
           (name, " ".join("%.2f" % v for v in ratios), _geomean(ratios)))
-    assert _geomean(ratios) <= 2.0 and max(ratios) <= 30.0, (name, ratios)
+    # Round 6: the per-seed cap follows the recorded data instead of "3.4 sigma".  Per-seed ratios at weights
+    # x 10, seeds 11..16 (profiles/r5/range_seeds_v1.log) — round 4's kernel: posteriors 0.86 3.46 2.56 0.43 0.46 0.75,
+    # gradients 0.94 7.76 2.60 0.56 0.40 0.53; the shipped kernel: posteriors 2.43 2.07 1.38 0.99 0.54 0.94, gradients
+    # 1.37 4.29 1.75 1.03 0.40 1.05.  The largest ratio any correct build has shown is 7.8: the cap is 10 (it was 30).
+    assert _geomean(ratios) <= 2.0 and max(ratios) <= 10.0, (name, ratios)
 
 
 def _operand_range_case(dev, zscale, wscale, seed):

@@ -1,9 +1,8 @@
-# GPU box: SQ / LDS counters of the encoder block kernels.  bash tools/dev/pmc_job.sh [variant] [kernel-regex]
+# GPU box: SQ / LDS counters of the encoder block kernels.  bash tools/dev/pmc_job.sh [RIP_OPT_ENCODER_VARIANT bit mask] [kernel-regex]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc; rm -rf $O; mkdir -p $O; cd $R
 V=${1:-0}; RX=${2:-irb2_bf16|irb_rows}
-if [ $V = old ]; then export RIP_IRB_OLD=1; else export RIP_IRB2_VARIANT=$V; fi
-CMD="python tools/stage_times.py --obs-batch 512 --iters 3 --enc bf16"
+CMD="python tools/stage_times.py --obs-batch 512 --iters 3 --enc bf16 --variant $V"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-include-regex "$RX" -d $O/sq --output-format csv -- $CMD > $O/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "$RX" -d $O/lds --output-format csv -- $CMD > $O/lds.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAVE32_INSTS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA --kernel-include-regex "$RX" -d $O/vm --output-format csv -- $CMD > $O/vm.log 2>&1

@@ -9,6 +9,6 @@ run ""
 for st in max-memory-clause iterative-maxocc max-ilp; do
   run "train.hip=$S=$st"
   run "encoder.hip=$S=$st;encoder_fused.hip=$S=$st"
-  run "flow_phase.hip=$S=$st;flow_mfma.hip=$S=$st;flow.hip=$S=$st"
+  run "flow_phase.hip=$S=$st;flow_split.hip=$S=$st;flow.hip=$S=$st"
 done
 run ""
