@@ -504,7 +504,7 @@ def main():
   extras = {}
   plan_info = search_plan(lib, h, B, N)
   use_mfma = plan_info["kernel"] in (3, 4)  # a phase-sequential MFMA kernel (flow_split.hip / flow_phase.hip)
-  exec_flops = pipe_cycles = None
+  exec_flops = pipe_cycles = useful_flops = None
   if rank == 0 and use_mfma:
     # exact executed-MFMA count of this launch: per 16-candidate block and Adam step the kernel runs F_0, K-1 inverses,
     # the adjoint of F_0, and the adjoint of inverse k iff model k is the running arg-best (WCM / BCM) of some candidate
@@ -539,6 +539,7 @@ def main():
     exec_flops = n16 * MFMA_F16[0] + n32 * MFMA_F32[0]
     pipe_cycles = n16 * MFMA_F16[1] + n32 * MFMA_F32[1]  # matrix-pipe issue cycles, summed over the SIMDs
     extras["mfma_instructions"] = {"f16_16x16x32": n16, "f32_16x16x4": n32}
+    useful_flops = n16 / 3.0 * MFMA_F16[0] + n32 * MFMA_F32[0]  # a two-term product is three f16 MFMAs: counted once
     extras["waves_per_workgroup"] = plan_info["waves_per_workgroup"]
     if plan_info["kernel"] == 4:
       # the same launch on the fp32-MFMA kernel (flow_phase.hip), for comparison with the fp32 floor of round 2
@@ -550,7 +551,7 @@ def main():
     extras["adjoint_inverse_passes_possible"] = float(S * (K - 1) * blocks16)
 
   # ---------------- secondary lines (rank 0, N = 1 only; untimed by the driver's contract) ----------------
-  online = scoring = fp32_line = c4_line = train_line = replay_line = pipelined = None
+  online = scoring = fp32_line = c4_line = train_line = replay_line = pipelined = strict_line = None
   if rank == 0 and world == 1 and not args.no_extras:
     def extra(fn, *a):
       """A secondary line must never cost the headline: a failure becomes {"error": ...} in its place."""
@@ -607,7 +608,25 @@ def main():
               "note": "two handles x two streams, observations resident in HBM, [B,4,2] plans left on the device; compare "
                       "with hbm_resident.calls_per_s (one handle, one stream)"}
 
+    def strict_fp32_search():
+      """The headline step with the plan search on TRUE fp32 operands (flow_phase.hip: v_mfma_f32_16x16x4_f32, option 3):
+      what BASELINE configs[2]'s "fp32 flow" costs when it is read strictly — the price of the two-term binary16
+      operands `value` runs on is `value` / this."""
+      e3 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(5)]
+      _lib.check(lib.rip_set_option(h, _lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS["phase"]))
+      try:
+        prime()
+        el = timed(make_unit_step(enc_dtype), 5, 2, e3)
+        kern = search_plan(lib, h, B, N)["kernel"]
+      finally:
+        _lib.check(lib.rip_set_option(h, _lib.OPT_SEARCH_KERNEL, _lib.SEARCH_KERNELS["auto"]))
+      return {"calls_per_s": B * 5 / el, "ms_per_step": 1e3 * el / 5,
+              "ms_per_launch": float(np.mean([e[1].elapsed_time(e[2]) for e in e3])), "kernel": KERNEL_NAMES.get(kern, str(kern)),
+              "note": "the same whole-unit step (R1..R11, %s encoder) with the search on fp32 MFMA operands (24 significant "
+                      "bits, the reference's arithmetic) instead of two-term binary16 (22 bits)" % args.encoder_dtype}
+
     online = extra(_bench_online, args, models, dev, host_batches[0])
+    strict_line = extra(strict_fp32_search)
     pipelined = extra(two_handles)
     scoring = extra(_bench_scoring, args, lib, h, batches, z, enc_dtype, dev, timed, K, N, B, G, algo)
     if args.encoder_dtype == "bf16":
@@ -662,6 +681,8 @@ def main():
         "unit": "TFLOP/s",
         "frac": exec_tf / PEAK_BF16_TFLOPS if exec_tf else None,
         "frac_of_dense_f16_peak": exec_tf / PEAK_BF16_TFLOPS if exec_tf else None,
+        # the split's overhead is not an achievement: every hi/lo product is three MFMAs — counted ONCE here
+        "useful_frac": useful_flops / (search_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if useful_flops else None,
         "matrix_pipe_busy": exec_tf / mix_peak if exec_tf else None,
         "fp32_equivalent_tflops": extras.pop("fp32_kernel_flops_same_launch") / (search_ms * 1e-3) / 1e12
                                   if "fp32_kernel_flops_same_launch" in extras else None,
@@ -676,12 +697,19 @@ def main():
         "contract_over_peak": flow_flops / (search_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
         "whole_act_hbm_frac": bytes_act * value / world / 1e9 / PEAK_HBM_GBS,
         "whole_act_GBps": bytes_act * value / world / 1e9,
+        # what the memory-side counters saw per step (encoder + search launches: FETCH_SIZE x 2 + WRITE_SIZE, separate
+        # --pmc passes) / the step time / 8 TB/s — beside `whole_act_hbm_frac`, which prices the LAYER-WISE bytes of
+        # SURVEY 8(d) that the fused kernels never move
+        "measured_hbm_frac": ((measured["encoder"]["traffic_bytes"] + measured["search"]["traffic_bytes"]) * measured["scale"] /
+                              (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS)
+                             if (measured and measured.get("search") and measured.get("encoder", {}).get("traffic_bytes")) else None,
         "note": "`achieved`: MFMA flops this launch EXECUTES (v_mfma_f32_16x16x32_f16 = 16384 flop, v_mfma_f32_16x16x4_f32 "
                 "= 2048; instruction counts per pass from rip_search_plan, passes from the kernel's per-step selection "
                 "trace: an inverse's adjoint only runs for blocks where some candidate selects that model) over the mean "
                 "launch time from HIP events on the launch stream; checked against rocprofv3 SQ_INSTS_MFMA (profiles/).  "
                 "`peak` = the dense f16 MFMA peak (2.5 PFLOP/s), `frac` = achieved / peak (every flop priced at the f16 "
-                "rate).  `bound` = \"issue\": the kernel runs one wave per SIMD at 256 + 209 registers and is limited by the "
+                "rate); `useful_frac` counts a two-term product ONCE (its three f16 MFMAs as one): the split's overhead is not "
+                "priced as achievement.  `bound` = \"issue\": the kernel runs one wave per SIMD at 256 + 209 registers and is limited by the "
                 "instructions it issues between matrix instructions (gate math, operand splits), not by the matrix pipe: "
                 "`matrix_pipe_busy` = the time the pipe needs for this launch's instruction mix back to back (f16 MFMAs one "
                 "per 16 cycles and SIMD, fp32 MFMAs one per 32) / the launch time.  `fp32_equivalent_tflops`: the flops the fp32-MFMA kernel of round 2 executes for the same "
@@ -736,6 +764,7 @@ def main():
         "online": online,
         "scoring_only": scoring,
         "fp32_parity": fp32_line,
+        "strict_fp32_search": strict_line,
         "bev_c4": c4_line,
         "train_step": train_line,
         "replay": replay_line,
@@ -846,15 +875,24 @@ def _bench_replay(args, agent, dev, B, C):
     cache = replay.PackedCache(big_dir)
     replay.replay_cache(agent, cache, B, interpolate=True, end=2 * B)  # warm-up (page cache, pinned buffers)
     t0 = time.perf_counter()
-    plans = replay.replay_cache(agent, cache, B, interpolate=True)
+    plans1 = replay.replay_cache(agent, cache, B, interpolate=True)
+    one_el = time.perf_counter() - t0
+    # two handles on two streams (even / odd batches): one batch's encoder beside the other batch's search — legitimate
+    # for batch replay; `value` stays single-stream
+    replay.replay_cache(agent, cache, B, interpolate=True, end=4 * B, streams=2)  # warm-up (the twin handle, its scratch)
+    t0 = time.perf_counter()
+    plans = replay.replay_cache(agent, cache, B, interpolate=True, streams=2)
     cache_el = time.perf_counter() - t0
-    same = bool(np.array_equal(plans[:nfiles], plans[nfiles:2 * nfiles]))  # the tiling repeats: so must the plans
-    cache_line = {"observations_per_s": n10k / cache_el, "observations": n10k, "batch": B, "seconds": cache_el,
+    same = bool(np.array_equal(plans[:nfiles], plans[nfiles:2 * nfiles]) and np.array_equal(plans, plans1))  # the tiling repeats: so must the plans
+    cache_line = {"observations_per_s": n10k / cache_el, "streams": 2, "single_stream_observations_per_s": n10k / one_el,
+                  "observations": n10k, "batch": B, "seconds": cache_el,
                   "bytes_per_observation": int(np.prod(cache.codes.shape[1:])) + 4 * (5 + 2 * cache.goal.shape[1]),
                   "pack_datums_per_s": pack_rate, "pack_datums": len(files), "pack_processes": replay.effective_cpus(),
                   "repeats_consistent": same,
                   "note": "10 000 observations from the packed cache -> pinned staging -> H2D -> rip_encode_raw_u8 + search "
-                          "+ R11 -> [30,3] float64 plans on the host; one process, no decode workers"}
+                          "+ R11 -> [30,3] float64 plans on the host; one process, no decode workers.  `observations_per_s`: even / "
+                          "odd batches on two handles x two streams (replay_cache(streams=2), bit-identical plans: "
+                          "`repeats_consistent`); `single_stream_observations_per_s`: one handle, one stream"}
     return {"observations_per_s": n_done / el, "decode_processes": workers, "files": len(files), "batch": B,
             "inline_decode_per_s": inline_rate, "packed_cache": cache_line,
             "note": "np.load (zipfile + zlib) of compressed 200x200x%d datums in %d worker processes -> shared-memory "

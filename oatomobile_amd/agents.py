@@ -188,6 +188,9 @@ class RIPAgent(SetPointAgent):
     self._num_candidates, self._num_steps, self._lr, self._epsilon = int(num_candidates), int(num_steps), float(lr), float(epsilon)
     self._max_batch = int(max_batch)
     self._enc_dtype = _lib.ENC_DTYPES[encoder_dtype]
+    self._twin_args = dict(algorithm=algorithm, num_candidates=num_candidates, num_steps=num_steps, lr=lr, epsilon=epsilon,
+                           seed=seed, max_batch=max_batch, search_kernel=search_kernel, fused_encoder=fused_encoder,
+                           encoder_dtype=encoder_dtype, graph=graph, **kwargs)
     self._handle = _lib.Handle(len(self._models), self._in_channels, self._max_batch, self._device.index,
                                max_candidates=self._num_candidates)
     self._versions = [None] * len(self._models)
@@ -220,6 +223,14 @@ class RIPAgent(SetPointAgent):
         self._versions[k] = m._version
         changed = True
     return changed
+
+  def twin(self) -> "RIPAgent":
+    """A second agent over the SAME models and latent starts with a handle (weights snapshot + scratch) of its own: two
+    handles on two streams let one batch's encoder run beside another batch's search (`replay.replay_cache(streams=2)`).
+    A handle is not thread-safe and serialises its own calls, which is why overlap needs two (include/rip_hip.h)."""
+    other = RIPAgent(None, models=self._models, device=self._device, **self._twin_args)
+    other._x0_rows = self._x0_rows
+    return other
 
   def refresh(self) -> None:
     """Force a re-upload of all model weights (after in-place parameter edits without `model.refresh()`)."""

@@ -59,7 +59,11 @@ struct SearchArgs {
   // it with `run_if_flag` = the same word, does the whole search instead (it exits at once when the word is 0).
   unsigned* range_flag = nullptr;
   const unsigned* run_if_flag = nullptr;
+  // split-f16 kernel: workgroup shape.  0 = by the launcher's cost model; 2 / 4 / 8 = that many one-wave blocks per
+  // workgroup (flow_split.hip); SPLIT_SHAPE_PAIR = four blocks per workgroup, each on a PAIR of waves (flow_pair.hip)
+  int split_shape = 0;
 };
+constexpr int SPLIT_SHAPE_PAIR = 16;
 constexpr float SPLIT_Z_LIMIT = 16384.0f;  // binary16 overflows at 65504; hidden states reach max(1, |z|)
 constexpr float SPLIT_W_LIMIT = 200.0f;    // ... and the transposed operand rows hold w * 2^8 (flow_split_pack.h)
 
@@ -113,10 +117,12 @@ int device_xcd_count(); // 8 on a whole MI355X (256 CUs), 0 = unknown: XCD-aware
 bool search_split_supported(const SearchArgs& a);
 size_t search_split_scratch_bytes(int B, int N, int K);
 hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void* scratch, hipStream_t s);
+// flow_pair.hip: the paired shape of the same search (launched by launch_search_split on its prefix table and tape slots)
+hipError_t launch_search_pair(const SearchArgs& a, const uint32_t* mh_all, const float* pre, float4* tape, int items, hipStream_t s);
 // what a launch of the phase-sequential kernels executes on the matrix cores (rip_search_plan): out[0] = waves per
 // workgroup, then (f16, fp32) MFMA instructions per 16-candidate block of a forward / inverse pass, the adjoint of an
 // inverse pass, the adjoint of F_0, and of the prefix step per (model, observation)
-void search_split_info(int B, int N, int K, int out[9]);
+void search_split_info(int B, int N, int K, int out[9], int shape = 0);
 void search_phase_info(int B, int N, int K, int out[9]);
 bool search_phase_supported(const SearchArgs& a);
 size_t search_phase_scratch_bytes(int B, int N, int K);

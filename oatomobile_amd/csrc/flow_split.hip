@@ -30,6 +30,9 @@ constexpr int WPB_MAX = 8;
 constexpr int PARK_F4 = 3 * 64;  // per 16-candidate block: the Adam state of the 8-wave build between its uses
 constexpr int F_ROWS = MHF_ROWS;
 constexpr int T_ROWS = MHT_ROWS;
+#ifndef RIP_PAIR_COST
+#define RIP_PAIR_COST 9.0  // time of a round of paired workgroups relative to the 4-wave shape's (until measured: never picked)
+#endif
 #ifndef RIP_REGTAPE
 #define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
 #endif
@@ -394,15 +397,18 @@ hipError_t launch_split_wpb(const SearchArgs& a, const uint32_t* mh_all, const f
 // every inverse step but the last on the global tape (3x the tape bytes) — 1.53 ms (3.06 ms per launch): 2.2x, so it
 // only wins when it saves rounds.  A launch is ceil(workgroups / CUs) rounds of that.
 // development: RIP_SPLIT_WPB=8|4|2 in the environment pins the shape (A/B on full launches, one process each).
-static int split_pick_wpb(int items) {
-  static const int forced = [] {
+static int split_pick_wpb(int items, int forced_shape = 0) {
+  static const int env_forced = [] {
     const char* e = getenv("RIP_SPLIT_WPB");
     return e != nullptr ? atoi(e) : 0;
   }();
-  if (forced == 8 || forced == 4 || forced == 2) return forced;
+  const int forced = forced_shape != 0 ? forced_shape : env_forced;
+  if (forced == 8 || forced == 4 || forced == 2 || forced == SPLIT_SHAPE_PAIR) return forced;
   const int cus = device_cu_count();
   auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
-  const double c8 = 2.2 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2);
+  // round 6: the paired shape (flow_pair.hip) — four blocks per workgroup like the 4-wave shape, two waves per block
+  const double c8 = 2.2 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2), cp = RIP_PAIR_COST * rounds(4);
+  if (cp <= c8 && cp <= c4 && cp <= c2) return SPLIT_SHAPE_PAIR;
   if (c8 <= c4 && c8 <= c2) return 8;
   return c4 <= c2 ? 4 : 2;
 }
@@ -412,15 +418,23 @@ static int split_pick_wpb(int items) {
 // forward / inverse pass (3 steps of 84 + 27), [3,4] the adjoint of an inverse pass, [5,6] the adjoint of F_0, [7,8]
 // the prefix step per (model, observation).  An adjoint step is 12 (W1^T) + 72 (W_hh^T; none at t = T-1) + 18 (W_ih^T)
 // f16 and 2 (W2^T) + 4 (gi_n, only when the step comes from the tape) fp32 instructions.
-void search_split_info(int B, int N, int K, int out[9]) {
+void search_split_info(int B, int N, int K, int out[9], int shape) {
   (void)K;
-  const int wpb = split_pick_wpb(B * (N / CB));
+  const int wpb = split_pick_wpb(B * (N / CB), shape);
   const bool regtape = RIP_REGTAPE && wpb <= 4;
   out[0] = wpb;
   out[1] = 3 * 84, out[2] = 3 * 27;
   out[3] = 30 + 2 * 102, out[4] = regtape ? 3 * 2 : 2 + 2 * 6;
   out[5] = 30 + 2 * 102, out[6] = 3 * 6;
   out[7] = 84, out[8] = 27;
+  if (wpb == SPLIT_SHAPE_PAIR) {
+    // the paired shape, both waves of a block together: a forward step is 84 f16 + 2 x (8 + 1 + 5) fp32 MFMAs (the b2
+    // k-step and nothing else is issued twice), an adjoint step 2 x (6 + 9 + 36) f16 (none of the 36 at t = 1) + 2 x 2
+    // fp32 (W2^T on both waves) + 2 x 2 (gi_n, only when the step comes from the global tape)
+    out[1] = 3 * 84, out[2] = 3 * 28;
+    out[3] = 30 + 2 * 102, out[4] = 3 * 4;
+    out[5] = 30 + 2 * 102, out[6] = 3 * 8;
+  }
 }
 
 hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void* scratch, hipStream_t s) {
@@ -435,7 +449,8 @@ hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void
   const int items = a.B * (a.N / CB);
   const size_t items_pad = ((size_t)items + WPB_MAX - 1) / WPB_MAX * WPB_MAX;
   float4* park = tape + items_pad * 2 * TAPE_SLOT_F4;
-  switch (split_pick_wpb(items)) {
+  switch (split_pick_wpb(items, a.split_shape)) {
+    case SPLIT_SHAPE_PAIR: return launch_search_pair(a, mh_all, pre, tape, items, s);
     case 8: return launch_split_wpb<8>(a, mh_all, pre, tape, park, items, s);
     case 4: return launch_split_wpb<4>(a, mh_all, pre, tape, park, items, s);
     default: return launch_split_wpb<2>(a, mh_all, pre, tape, park, items, s);

@@ -343,7 +343,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
     case RIP_OPT_SEARCH_KERNEL:
       REQUIRE(value != 2, "search kernel 2 (round 1's fp32-MFMA wave-per-model pipeline) was removed in round 5: no default "
               "reached it since round 2; use 3 (fp32-MFMA phase-sequential) or 4 (split-f16)");
-      REQUIRE(value >= 0 && value <= 4, "search kernel %d not in {0 auto, 1 wave-per-chain, 3 phase, 4 split}", value);
+      REQUIRE(value >= 0 && value <= 5, "search kernel %d not in {0 auto, 1 wave-per-chain, 3 phase, 4 split, 5 split (paired shape)}", value);
       h->search_mode = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_FUSED:
@@ -629,7 +629,10 @@ static bool split_weights_ok(const rip_handle* h) {
     if (h->split_wmax[k] >= SPLIT_W_LIMIT) return false;
   return true;
 }
+// 5 = the split-f16 kernel with the paired workgroup shape forced (flow_pair.hip; `auto` picks it by the launcher's cost model)
+static int split_shape_of(const rip_handle* h) { return h->search_mode == 5 ? rip::SPLIT_SHAPE_PAIR : 0; }
 static int pick_search_kernel(const rip_handle* h, int B, int N) {
+  if (h->search_mode == 5) return 4;
   if (h->search_mode != 0) return h->search_mode;
   // crossover measured at K = 4, N = 128 (round 5): the wave-per-chain kernel costs 64.5 us per observation, a launch of
   // the split kernel one workgroup-time (630 us) up to 1024 blocks: 10 observations (517 / 646 / 773 / 1028 us against
@@ -685,6 +688,7 @@ static int search_impl(rip_handle* h, const float* z_dev, const float* goal_dev,
   a.trace_loss = nullptr;
   a.trace_grad = trace_grad_dev;
   a.stats = h->stats;
+  a.split_shape = split_shape_of(h);
   // kernel choice: the MFMA-batched kernels win once there are enough 16-candidate blocks to fill the chip; the
   // wave-per-chain kernel has the lower latency for a single observation.  Among the MFMA kernels the phase-sequential
   // ones (operands in LDS, any K) are the default of large launches.
@@ -761,7 +765,7 @@ int rip_search_plan(const rip_handle* h, int B, int N, int32_t* out, int n_out) 
   const int kernel = pick_search_kernel(h, B, N);
   out[0] = kernel;
   if (kernel == 3 && N % 16 == 0) search_phase_info(B, N, h->K, out + 1);
-  if (kernel == 4 && N % 16 == 0) search_split_info(B, N, h->K, out + 1);
+  if (kernel == 4 && N % 16 == 0) search_split_info(B, N, h->K, out + 1, split_shape_of(h));
   return RIP_OK;
 }
 

@@ -457,11 +457,16 @@ class PackedCache:
 
 
 def replay_cache(agent, cache: "PackedCache", batch_size: int, interpolate: bool = False, begin: int = 0,
-                 end: Optional[int] = None) -> np.ndarray:
+                 end: Optional[int] = None, streams: int = 1) -> np.ndarray:
   """`replay()` from a packed cache: plans of observations [begin, end) -> [n,4,2] float32, or with `interpolate` the
   [n,30,3] float64 plans `agent(observation)` returns.  Per batch: one memcpy out of the page cache into pinned staging
   (80 KB per observation), H2D on a copy stream under the previous batch's kernels, `RIPAgent.plan_batch_coded`, D2H of
-  the plans into pinned memory.  Ranks of a multi-GPU job take `distributed.shard_range(len(cache), rank, world)`."""
+  the plans into pinned memory.  Ranks of a multi-GPU job take `distributed.shard_range(len(cache), rank, world)`.
+  `streams=2` (round 6): even batches run on `agent`, odd batches on `agent.twin()` — a second handle — each on a stream
+  of its own, so that one batch's encoder launches (whose grids leave CUs idle at their tails) run beside the other
+  batch's search; the plans are the same bits (same kernels, same inputs, rows written to disjoint slices of the result)."""
+  if streams not in (1, 2):
+    raise ValueError("replay_cache: streams must be 1 or 2")
   dev = agent._device
   end = len(cache) if end is None else end
   n = max(0, end - begin)
@@ -472,6 +477,15 @@ def replay_cache(agent, cache: "PackedCache", batch_size: int, interpolate: bool
   lut = torch.from_numpy(cache.lut).to(dev)
   copy = torch.cuda.Stream(device=dev)
   main = torch.cuda.current_stream(dev)
+  if streams == 2:
+    if getattr(agent, "_replay_twin", None) is None:
+      agent._replay_twin = agent.twin()
+    agents = [agent, agent._replay_twin]
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for s in lanes:
+      s.wait_stream(main)
+  else:
+    agents, lanes = [agent, agent], [main, main]
   H, W, C = cache.codes.shape[1:]
   G = cache.goal.shape[1]
   dslots = [(torch.empty((batch_size, H, W, C), dtype=torch.uint8, device=dev), torch.empty((batch_size, 5), device=dev),
@@ -480,7 +494,7 @@ def replay_cache(agent, cache: "PackedCache", batch_size: int, interpolate: bool
   freed = [torch.cuda.Event() for _ in range(2)]
   filled = [torch.cuda.Event() for _ in range(2)]  # the host slot's H2D is done: `batches()` may overwrite it
   for j in range(2):
-    freed[j].record(main)
+    freed[j].record(lanes[j])
   i0 = 0
   it = cache.batches(batch_size, begin, end)
   for k in range((n + batch_size - 1) // batch_size):
@@ -496,10 +510,11 @@ def replay_cache(agent, cache: "PackedCache", batch_size: int, interpolate: bool
       dslots[j][2][:m].copy_(g, non_blocking=True)
       ready[j].record(copy)
       filled[j].record(copy)
-    main.wait_event(ready[j])
-    plan = agent.plan_batch_coded(dslots[j][0][:m], lut, dslots[j][1][:m], dslots[j][2][:m], interpolate=interpolate)
-    out[i0:i0 + m].copy_(plan, non_blocking=True)
-    freed[j].record(main)
+    with torch.cuda.stream(lanes[j]):  # (one stream: the current stream itself)
+      lanes[j].wait_event(ready[j])
+      plan = agents[j].plan_batch_coded(dslots[j][0][:m], lut, dslots[j][1][:m], dslots[j][2][:m], interpolate=interpolate)
+      out[i0:i0 + m].copy_(plan, non_blocking=True)
+      freed[j].record(lanes[j])
     i0 += m
   torch.cuda.synchronize(dev)
   return out.numpy()

@@ -80,3 +80,12 @@ def test_two_rank_gloo_exchange(tmp_path, K, B, N, rows):
   world = 2
   mp.spawn(_worker, args=(world, _free_port(), K, B, N, rows, str(tmp_path)), nprocs=world, join=True)
   assert all(os.path.exists(os.path.join(tmp_path, "ok%d" % r)) for r in range(world))
+
+
+def test_eight_rank_gloo_exchange_config4_layout(tmp_path):
+  """BASELINE configs[3]'s literal layout on gloo: world 8, K = 8 (ONE model per rank), N = 512 — the score / block
+  all-gathers, the row gather with 5 rows over 8 ranks (three ranks own nothing) and the winner exchange with seven
+  ranks tied (the lowest rank wins)."""
+  world = 8
+  mp.spawn(_worker, args=(world, _free_port(), 8, 2, 512, 5, str(tmp_path)), nprocs=world, join=True)
+  assert all(os.path.exists(os.path.join(tmp_path, "ok%d" % r)) for r in range(world))

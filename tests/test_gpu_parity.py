@@ -42,13 +42,25 @@ def ctx_tensors(obs_list, dev):
   )
 
 
-def candidate_gate(tag, lh, lo, plan_h=None, plan_o=None, frac=0.99, x_h=None, x_o=None):
+# Outliers of the statistical end-to-end gates as recorded on the MI355X (profiles/r6/outliers_v1.log: `pytest -s`, the
+# "candidates outside" lines): tag -> most candidates that may fall outside 1e-3 + 1e-4 |loss|.  EVERY gate of the suite
+# recorded 0 outliers in round 6 (17 kernel x algorithm x size cases, K=8 N=512 over all 512 candidates, 16 observations of
+# the bench configuration, the model-parallel compositions; largest |d loss| 9.5e-6), so the table is empty and the
+# ceiling of every tag is 0: one candidate outside the tolerance fails the test.
+OUTLIER_CEILINGS = {
+}
+
+
+def candidate_gate(tag, lh, lo, plan_h=None, plan_o=None, frac=0.99, x_h=None, x_o=None, ceiling="table"):
   """The N-candidate gate of the end-to-end search tests.  Every candidate's best loss against the oracle's within
   1e-3 + 1e-4 |loss| for >= `frac` of the candidates (N < 100: all of them), the winning plan at 1e-4 when the winner
   is unambiguous (its best loss more than 1e-3 below the runner-up's).  Whatever falls outside is printed: the
   candidate, both losses, the oracle's gap to its runner-up and — when per-step latents `x_h` / `x_o` [steps,N,4,2]
   are given — the first Adam step at which the two trajectories differ by more than 1e-4 (an Adam sign flip of a
-  near-zero gradient coordinate moves x by 2 lr there)."""
+  near-zero gradient coordinate moves x by 2 lr there).
+  Round 6: the NUMBER of outliers is pinned as well — `OUTLIER_CEILINGS[tag]` is the count recorded on the
+  MI355X for that parametrisation (the kernels are deterministic; the ceiling leaves room for one more flip, not for
+  a drift from 0.2 % to 0.9 %).  A tag without an entry must have NO outlier."""
   lh, lo = np.asarray(lh, np.float64).reshape(-1), np.asarray(lo, np.float64).reshape(-1)
   d = np.abs(lh - lo)
   out = np.flatnonzero(~(d <= 1e-3 + 1e-4 * np.abs(lo)))
@@ -65,6 +77,10 @@ def candidate_gate(tag, lh, lo, plan_h=None, plan_o=None, frac=0.99, x_h=None, x
     print("   candidate %d: loss %.6f vs oracle %.6f (|d| %.3g), rank %d of the oracle's ordering%s" %
           (n, lh[n], lo[n], d[n], int(np.sum(lo < lo[n])), first))
   assert 1.0 - out.size / lo.size >= frac, "%s: %d of %d candidates outside the tolerance" % (tag, out.size, lo.size)
+  if ceiling == "table":
+    ceiling = OUTLIER_CEILINGS.get(tag, 0)
+  if ceiling is not None:
+    assert out.size <= ceiling, "%s: %d candidates outside the tolerance, recorded ceiling %d" % (tag, out.size, ceiling)
   if plan_h is not None and (gap > 1e-3 or lo.size == 1):
     err = float(np.abs(np.asarray(plan_h) - np.asarray(plan_o)).max())
     print("%s: winner plan max |d| = %.3g m" % (tag, err))
@@ -425,32 +441,23 @@ def test_bf16_block_kernels_everywhere(dev):
       assert any(l.startswith(must) for l in log), (variant, must, log)
 
 
-def _headline_kernel_names(csv_path):
-  """Encoder kernels of the driver-shaped bench (512 observations x 4 models, bf16) as rocprofv3 saw them:
-  profiles/r5/bench_kernel_stats_v4.csv for what ships, profiles/r4/bench_kernel_stats_v3.csv (the file VERDICT r4
-  recomputed the roofline from) for round 4's selection, which RIP_OPT_ENCODER_VARIANT bit 8 restores."""
-  import csv
-  import re
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  names = set()
-  with open(os.path.join(root, *csv_path)) as f:
-    for row in csv.DictReader(f):
-      m = re.search(r"rip::\(anonymous namespace\)::(\w+(?:<[^>]*>)?)", row["Name"])
-      if m:
-        names.add(m.group(1).replace(" ", ""))
-  drop = ("search_", "split_prefix", "phase_prefix", "select_best", "interpolate_plans", "transform_kernel")
-  return {n for n in names if not n.startswith(drop)}
+def _headline_kernel_names(variant):
+  """Encoder kernels of the driver-shaped bench (512 observations x 4 models, bf16) per `RIP_OPT_ENCODER_VARIANT` value:
+  the committed manifest tests/golden/headline_kernels.json (recorded from the rocprofv3 kernel traces under profiles/;
+  a parity test must not depend on which profiling artefact is newest — VERDICT r5 weak #1)."""
+  import json
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline_kernels.json")) as f:
+    return set(json.load(f)[str(variant)])
 
 
-@pytest.mark.parametrize("variant,csv_path", [(0, ("profiles", "r5", "bench_kernel_stats_v2.csv")),
-                                              (8, ("profiles", "r4", "bench_kernel_stats_v3.csv"))])
-def test_bf16_headline_launch_shape_vs_bf16_oracle(dev, variant, csv_path):
+@pytest.mark.parametrize("variant", [0, 8])
+def test_bf16_headline_launch_shape_vs_bf16_oracle(dev, variant):
   """the bf16 kernel selection keys on B * k_count, and the teacher-forced block tests above tap ONE
   model at B <= 160 — they never launch `gemm_pers_bf16_kernel<4,false|true>` / `dw_rows_bf16_kernel<1,4>` (features.17 /
   18 of a large launch), nor the grids the fused blocks take at 2048 (model, observation) pairs.  Here the tap runs the
   headline's own launch (`rip_encode_tap_k`: K = 4 models x B = 512 observations, automatic selection), (a) the
   kernel log of a whole encode of that shape must be exactly the encoder kernel set rocprofv3 recorded for the bench
-  (`csv_path`), and (b) every output that reaches memory is gated teacher-forced against the bf16 oracle on rows
+  (the manifest tests/golden/headline_kernels.json), and (b) every output that reaches memory is gated teacher-forced against the bf16 oracle on rows
   {0, 255, 511} of every model (12 images on the oracle side).  variant 0 = what ships (round 5: features.17 is a tile
   block too); variant 8 = features.17 layer-wise, i.e. round 4's selection with `gemm_pers_bf16_kernel<4,false>` x 2 and
   `dw_rows_bf16_kernel<1,4>`, kernels no other launch of the suite reaches."""
@@ -472,7 +479,7 @@ def test_bf16_headline_launch_shape_vs_bf16_oracle(dev, variant, csv_path):
   # (a) the kernels of the whole launch
   _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), B, 0, K, _lib.ENC_DTYPES["bf16"], _lib.ptr(z), None, h.stream()))
   got = {l.split(" ")[0] for l in h.kernel_log()}
-  assert got == _headline_kernel_names(csv_path), (sorted(got ^ _headline_kernel_names(csv_path)))
+  assert got == _headline_kernel_names(variant), (sorted(got ^ _headline_kernel_names(variant)))
   # (b) every block output of that launch, three rows per model
   layers = arch.conv_layers(C)
   L = len(layers)
@@ -835,7 +842,7 @@ def test_split_kernel_operand_ranges(dev, zscale, wscale):
   next for ANY kernel: round 4's kernel, which passed on seed 11, is at 3.5x / 7.8x the fp32 kernel's posterior /
   gradient error on seed 12 (profiles/r5/range_seeds_v1.log; the logarithm of the ratio scatters with sigma ~ 1).  Those
   cases therefore run SIX seeds and gate the geometric mean of (split error / fp32-kernel error) at 2 (measured over
-  seeds 11..16 at weights x 10: 1.02 / 1.15 for round 4's kernel, 1.34 / 1.06 for round 5's), every single seed at 10x
+  seeds 11..16 at weights x 10: 1.02 / 1.15 for round 4's kernel, 1.34 / 1.06 for round 5's), every single seed at 16x
   (round 6; the recorded per-seed ratios are next to the assertion): the defect this gate exists for — round 5's first forward step left the WEIGHTS' low terms unscaled,
   2^-24-quantised — was 780x on the gradients at z x 100 and fails both.
   Found with this test and fixed: `pow2_scale` overflowed to inf for candidates whose gate gradients had all but
@@ -851,11 +858,14 @@ def test_split_kernel_operand_ranges(dev, zscale, wscale):
     ratios = [max(r[idx]["split"], 1e-4) / max(r[idx]["phase"], 1e-4) for r in runs]
     print("  %s: split / fp32-kernel error over seeds 11..16: %s, geometric mean %.2f" %
           (name, " ".join("%.2f" % v for v in ratios), _geomean(ratios)))
-    # Round 6: the per-seed cap follows the recorded data instead of "3.4 sigma".  Per-seed ratios at weights
-    # x 10, seeds 11..16 (profiles/r5/range_seeds_v1.log) — round 4's kernel: posteriors 0.86 3.46 2.56 0.43 0.46 0.75,
-    # gradients 0.94 7.76 2.60 0.56 0.40 0.53; the shipped kernel: posteriors 2.43 2.07 1.38 0.99 0.54 0.94, gradients
-    # 1.37 4.29 1.75 1.03 0.40 1.05.  The largest ratio any correct build has shown is 7.8: the cap is 10 (it was 30).
-    assert _geomean(ratios) <= 2.0 and max(ratios) <= 10.0, (name, ratios)
+    # Round 6: the per-seed cap follows the recorded data instead of "3.4 sigma".  Per-seed ratios, seeds 11..16.
+    # Weights x 10 (profiles/r5/range_seeds_v1.log) — round 4's kernel: posteriors 0.86 3.46 2.56 0.43 0.46 0.75, gradients
+    # 0.94 7.76 2.60 0.56 0.40 0.53.  The shipped kernel (profiles/r6/outliers_v1.log) — weights x 10: posteriors 1.96 3.86
+    # 3.52 0.51 0.68 0.63, gradients 2.02 4.61 0.75 1.00 0.35 0.57; z x 100: posteriors 0.19 0.54 0.92 0.94 1.00 4.00,
+    # gradients 0.26 1.01 2.57 12.66 0.93 0.79; z x 1000: posteriors 0.72 1.00 0.83 0.30 1.07 0.43, gradients 1.96 2.27 0.94
+    # 1.41 3.28 1.25.  The largest ratio a correct build has shown is 12.7 (the advisor's 10 would fail what ships): the
+    # cap is 16 (it was 30); the defect the gate exists for was 780x.
+    assert _geomean(ratios) <= 2.0 and max(ratios) <= 16.0, (name, ratios)
 
 
 def _operand_range_case(dev, zscale, wscale, seed):
@@ -1074,9 +1084,8 @@ def test_full_size_properties(dev):
   assert float(loss.max()) < 1000.0  # every candidate improved on the sentinel (rip/agent.py:100)
   refs = [oracle_model(500 + k) for k in range(K)]
   _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"], ob["goal"],
-                      x0=agent._x0_rows.cpu()[:64], algorithm="WCM")  # the first 64 candidates suffice for the oracle
-  lo, lh = res["loss_best"].numpy(), loss.cpu().numpy()[0, :64]
-  assert (np.abs(lh - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.99
+                      x0=agent._x0_rows.cpu(), algorithm="WCM")  # all 512 candidates (round 6; the oracle side is seconds)
+  candidate_gate("full size K=8 N=512", loss.cpu().numpy()[0], res["loss_best"].numpy(), plan.cpu().numpy()[0], res["plan"].numpy())
   perm = torch.randperm(N, generator=torch.Generator().manual_seed(0))
   agent._x0_rows = agent._x0_rows[perm.to(dev)].contiguous()
   agent._x0_cache = {}
@@ -1343,7 +1352,8 @@ def test_model_parallel_gradient_mode(dev, algo):
   agent = RIPAgent(None, algorithm=algo, models=models, num_candidates=N, max_batch=B, seed=4, search_kernel="chain")
   plan_s, loss_s = agent.plan_batch(lidar, vec, goal, return_loss=True)
   l1, ls = lb1.cpu().numpy(), loss_s.cpu().numpy()
-  assert (np.abs(l1 - ls) <= 1e-3 + 1e-4 * np.abs(ls)).mean() >= 0.9  # same algorithm, another kernel's rounding
+  # same algorithm, another kernel's rounding; 32 candidates: the count is pinned by OUTLIER_CEILINGS (round 6), not by `frac`
+  candidate_gate("model-parallel %s vs chain kernel" % algo, l1, ls, frac=0.9)
   srt = np.sort(ls, axis=1)
   for b in range(B):
     if srt[b, 1] - srt[b, 0] > 1e-3:
@@ -1353,7 +1363,7 @@ def test_model_parallel_gradient_mode(dev, algo):
   _, res = O.rip_call(refs, ob["lidar"], ob["velocity"], ob["is_at_traffic_light"], ob["traffic_light_state"], ob["goal"],
                       x0=one._x0_rows.cpu(), algorithm=algo)
   lo = res["loss_best"].numpy()
-  assert (np.abs(lb1.cpu().numpy()[0] - lo) <= 1e-3 + 1e-4 * np.abs(lo)).mean() >= 0.9
+  candidate_gate("model-parallel %s vs oracle, observation 0" % algo, lb1.cpu().numpy()[0], lo, frac=0.9)
 
 
 def test_abi_contract_no_growth_and_validation(dev):
@@ -1733,19 +1743,23 @@ def test_replay_512_cached_observations(dev, tmp_path):
   np.testing.assert_array_equal(plans3, plans)
 
 
-def _run_bench_two_ranks(extra):
+def _run_bench_ranks(n, extra, steps=3, timeout=600):
   import json, subprocess, sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = dict(os.environ, RIP_BENCH_SHARE_GPU="1", RIP_BENCH_BACKEND="gloo")
   for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
     env.pop(k, None)
-  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", "1",
                         "--no-cpu-baseline", "--no-extras"] + extra, cwd=root, env=env, capture_output=True, text=True,
-                       timeout=600)
+                       timeout=timeout)
   assert out.returncode == 0, out.stderr[-2000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
   assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
   return json.loads(lines[0])
+
+
+def _run_bench_two_ranks(extra):
+  return _run_bench_ranks(2, extra)
 
 
 @pytest.mark.gpu
@@ -1795,6 +1809,25 @@ def test_bench_parallel_modes_two_ranks(mode):
   rec = _run_bench_two_ranks(["--mode", mode, "--obs-batch", "8"])
   assert rec["n_gpus"] == 2 and rec["value"] > 0
   assert rec["config"]["mode"] == mode
+  assert rec["check"]["max_abs_plan_diff_vs_single_gpu"] <= 1e-4, rec["check"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["models", "candidates"])
+def test_bench_parallel_modes_eight_ranks(mode):
+  """BASELINE configs[3]'s LITERAL layout as a dry run on one GPU — world 8 (eight gloo processes sharing
+  the device), K = 8 models, N = 512 candidates.  `models`: ONE model per rank, every rank but rank 0 holding a copy of
+  model 0's flow (`flow0`) for y = F_0(x; z_0), one all-gather of z_0 and one of the [1,B,512,9] block per Adam step,
+  the K-aggregation of rip/agent.py:109-127 on every rank after the gather.  `candidates`: all 8 models on every rank,
+  64 of the 512 latent starts each, one all-gather of (best loss, plan).  Two Adam steps; the plans must equal those of
+  ONE rank holding all 8 models and all 512 candidates (bench.py's own check).  Makes the first real SCALE record an
+  execution of tested code, not a first run."""
+  per_rank = {"models": "512", "candidates": "64"}[mode]
+  rec = _run_bench_ranks(8, ["--mode", mode, "--models", "8", "--candidates", per_rank, "--search-steps", "2", "--obs-batch", "2"],
+                         steps=2, timeout=1200)
+  assert rec["n_gpus"] == 8 and rec["world_size_seen"] == 8 and rec["value"] > 0
+  assert rec["config"]["mode"] == mode and rec["config"]["models"] == 8 and rec["config"]["candidates"] == 512
+  assert rec["collectives_per_step"] == (3 if mode == "models" else 1)
   assert rec["check"]["max_abs_plan_diff_vs_single_gpu"] <= 1e-4, rec["check"]
 
 
@@ -2028,6 +2061,9 @@ def test_packed_cache_replay_bit_identical(dev, tmp_path):
   np.testing.assert_allclose(replay.replay_cache(agent, cache, 5), ref4, atol=1e-4)
   np.testing.assert_array_equal(replay.replay_cache(agent, cache, 16, interpolate=True), ref30)
   np.testing.assert_array_equal(replay.replay_cache(agent, cache, 16, begin=16, end=37), ref4[16:37])  # a rank's share
+  # round 6: two handles on two streams (even / odd batches) — the same bits, whole and ragged batch counts
+  np.testing.assert_array_equal(replay.replay_cache(agent, cache, 16, streams=2), ref4)
+  np.testing.assert_array_equal(replay.replay_cache(agent, cache, 5, interpolate=True, streams=2), replay.replay_cache(agent, cache, 5, interpolate=True))
   # the encoder output itself, coded vs float32 BEV (fp32 encoder)
   lib, h = _lib.load(), agent._handle.raw
   codes = torch.from_numpy(np.array(cache.codes[:8])).to(dev)
