@@ -72,6 +72,10 @@ MFMA_F16 = (16 * 16 * 32 * 2, 16)
 MFMA_F32 = (16 * 16 * 4 * 2, 32)
 PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 256 * 4
+# observations (= act() calls) per step and GPU.  Round 6: 512 -> 2048.  Every kernel of the step has a fixed part per launch
+# (persistent workgroups' prologues, launch tails, the ~25 launch boundaries): 127.7 k calls/s at 512 observations per step,
+# 132.3 k at 1024, 134.5 k at 2048 (profiles/r6/batch_sweep_v1.txt); the line carries the 512-observation step beside it.
+DEFAULT_OBS_BATCH = 2048
 KERNEL_NAMES = {1: "search_kernel (wave-per-chain, fp32 VALU)", 
                 3: "search_phase_kernel (fp32 MFMA, phase-sequential)", 4: "search_split_kernel (split-f16 MFMA, phase-sequential)"}
 
@@ -300,7 +304,7 @@ def main():
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps; value = the median one")
   ap.add_argument("--warmup", type=int, default=5)
-  ap.add_argument("--obs-batch", type=int, default=512, help="observations (= act() calls) per step per GPU")
+  ap.add_argument("--obs-batch", type=int, default=DEFAULT_OBS_BATCH, help="observations (= act() calls) per step per GPU")
   ap.add_argument("--encoder-dtype", default="bf16", choices=["bf16", "fp32"],
                   help="MobileNetV2 encoder arithmetic; BASELINE configs[2] names bf16 encoder + fp32 flow")
   ap.add_argument("--models", type=int, default=4)
@@ -501,6 +505,28 @@ def main():
               "note": "R2..R10 on observations already in HBM, [B,4,2] fp32 plans copied back: no H2D, no R11 (round 2's "
                       "headline definition)"}
 
+  # the same resident step at 512 observations (rounds 2-5 ran `value` at 512 observations per step)
+  hbm512 = None
+  if B > 512:
+    b5 = 512
+    small = [tuple(t[:b5] for t in bt) for bt in batches]
+    x0_5, z5 = agent._x0(b5), torch.empty(K, b5, 64, device=dev)
+    plan5, loss5 = torch.empty(b5, 4, 2, device=dev), torch.empty(b5, N, device=dev)
+
+    def step512(i, ev):
+      lidar5, vec5, goal5 = small[i & 1]
+      s5 = _lib.current_stream(dev)
+      _lib.check(lib.rip_encode_raw(h, _lib.ptr(lidar5), 1, 200, 200, _lib.ptr(vec5), b5, 0, K, enc_dtype, _lib.ptr(z5), s5))
+      _lib.check(lib.rip_search(h, _lib.ptr(z5), _lib.ptr(goal5), _lib.ptr(x0_5), b5, N, G, algo, S, 0.1, 1.0, _lib.ptr(plan5), None,
+                                _lib.ptr(loss5), None, None, None, None, s5))
+      plan_host[:b5].copy_(plan5, non_blocking=True)
+
+    n5 = max(8, args.steps)
+    el5 = timed(step512, n5, 3)
+    hbm512 = {"calls_per_s": b5 * n5 * world / el5, "ms_per_step": 1e3 * el5 / n5, "obs_per_step": b5,
+              "note": "`hbm_resident` at 512 observations per step (the step size of rounds 2-5): every kernel's fixed part per "
+                      "launch weighs four times as much"}
+
   extras = {}
   plan_info = search_plan(lib, h, B, N)
   use_mfma = plan_info["kernel"] in (3, 4)  # a phase-sequential MFMA kernel (flow_split.hip / flow_phase.hip)
@@ -634,7 +660,7 @@ def main():
     if C == 2:
       c4_line = extra(_bench_c4, args, dev, timed, seeds)
     train_line = extra(_bench_train, args, dev, timed)
-    replay_line = extra(_bench_replay, args, agent, dev, B, C)
+    replay_line = extra(_bench_replay, args, agent, dev, min(B, 1024), C)  # (10 000 observations: ten batches of 1024, the last one ragged)
   # ---------------- N > 1 without --mode: the compositions that need a collective, same invocation ----------------
   par_lines, rccl = {}, None
   if world > 1 and not explicit_mode:
@@ -755,6 +781,7 @@ def main():
                          "h2d_MB_per_step": h2d_bytes / 1e6, "d2h_KB_per_step": B * 30 * 3 * 8 / 1e3,
                          "r11_bit_identical_to_reference_arithmetic": bool(r11_ok)},
         "hbm_resident": hbm_line,
+        "hbm_resident_512": hbm512,
         "two_handles_two_streams": pipelined,
         "backend": args.backend_seen,
         "world_size_seen": args.world_seen,

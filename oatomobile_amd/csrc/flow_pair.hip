@@ -59,6 +59,16 @@ __device__ __forceinline__ void load_tbuf(PairShared& sh, const uint32_t* __rest
 #define RIP_PAIR_SAME_SIMD 0  // 1: the two waves of a pair are waves w, w + 4 (one SIMD under round-robin placement)
 #endif
 
+#ifdef RIP_PROFILE_TICKS  // development (tools/search_ticks.py): where a wave's cycles go; one workgroup prints at the end
+#define TK_DECL() long long tk_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk0_ = 0
+#define TK_START() tk0_ = clock64()
+#define TK_STOP(i_) tk_[i_] += clock64() - tk0_
+#else
+#define TK_DECL()
+#define TK_START()
+#define TK_STOP(i_)
+#endif
+
 template <bool TRACE>
 __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, const uint32_t* __restrict__ mh_all,
                                                                   const float* __restrict__ pre_all, float4* __restrict__ tape_all) {
@@ -94,12 +104,12 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
   float4* tapeF = tape_all + (size_t)item * 2 * TAPE_SLOT_F4;  // (flow_split.hip's scratch layout: two slots per block, one used)
 
   PairXchg x;
-  x.my_rows = sh.xrows[wave][0] + lane;
-  x.peer_rows = sh.xrows[peer][0] + lane;
-  x.my_extra = sh.xextra[wave] + lane;
-  x.peer_extra = sh.xextra[peer] + lane;
-  x.my_ctl = sh.ctl[wave];
-  x.peer_ctl = sh.ctl[peer];
+  x.my_rows = (volatile RIP_LDS u32x4*)(sh.xrows[wave][0] + lane);
+  x.peer_rows = (const volatile RIP_LDS u32x4*)(sh.xrows[peer][0] + lane);
+  x.my_extra = (volatile RIP_LDS f32x2*)(sh.xextra[wave] + lane);
+  x.peer_extra = (const volatile RIP_LDS f32x2*)(sh.xextra[peer] + lane);
+  x.my_ctl = (volatile RIP_LDS unsigned*)sh.ctl[wave];
+  x.peer_ctl = (const volatile RIP_LDS unsigned*)sh.ctl[peer];
   x.seq = 0;
   if (lane < 2) sh.ctl[wave][lane] = 0u;
 
@@ -115,19 +125,24 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
   load_tbuf(sh, K > 1 ? mh0 + MH_SIZE : mh0, wave, lane, tid);
 
   const int S = a.num_steps;
+  TK_DECL();
 #pragma unroll 1
   for (int step = 0; step <= S; ++step) {
     const bool final_pass = step == S;
     // ================= F_0: x -> y (F-buf = model 0) =================
     xs[c][2 * q] = final_pass ? xb0 : xv0;
     xs[c][2 * q + 1] = final_pass ? xb1 : xv1;
+    TK_START();
     __syncthreads();  // F-buf (and, at step 0, T-buf and the exchange words) landed; xs visible
+    TK_STOP(0);
     float q_sel, gl = 0.f, gg0 = 0.f, gg1 = 0.f, w0;
     int ksel = 0;
     float gsa = 0.f, gsb = 0.f;  // sum_k w_k dq_k/dy, coordinates 2q and 2q+1 of this lane's candidate
     {
       const Prefix16 pre = load_prefix(pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, q);
+      TK_START();
       const PassOut po = pass_forward_pair<MODE_FWD>(wl, hw, pre, xs, ys, stF, tapeF, nullptr, c, q, (unsigned)lane, x);
+      TK_STOP(1);
       if (final_pass) break;
       if (goal != nullptr) gl = goal_ll(goal, a.G, a.epsilon, ys[c][6], ys[c][7], &gg0, &gg1);
       q_sel = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // model 0's posterior through the self-inverse shortcut
@@ -139,14 +154,20 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
 #pragma unroll 1
     for (int k = 1; k < K; ++k) {
       const uint32_t* mhk = mh_all + (size_t)(a.k0 + k) * MH_SIZE;
+      TK_START();
       __syncthreads();  // every wave is done with the F-buf (F_0 or inverse_{k-1}) and the T-buf (adjoint_{k-1})
+      TK_STOP(2);
+      TK_START();
       load_fbuf(sh, mhk, wave, lane);
       if (k > 1) load_tbuf(sh, mhk, wave, lane, tid);  // (model 1's T-buf was requested under F_0)
       __syncthreads();  // operands of model k landed
+      TK_STOP(3);
       const float* prek = pre_all + ((size_t)k * a.B + b) * PRE_FLOATS;
       const Prefix16 pre = load_prefix(prek, q);
       HalfTape last[3];
+      TK_START();
       const PassOut po = pass_forward_pair<MODE_INV>(wl, hw, pre, xs, ys, stI, nullptr, last, c, q, (unsigned)lane, x);
+      TK_STOP(4);
       const float qk = (-0.5f * po.sq - 4.0f * LOG_2PI) - po.lad;  // rip/agent.py:111-112
       if (TRACE && a.trace_post != nullptr && q == 0 && active && hw == 0)
         a.trace_post[(((size_t)step * K + k) * a.B + b) * a.N + n0 + c] = qk + gl;
@@ -155,7 +176,9 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
       const bool take = a.algorithm == ALGO_WCM ? (qk > q_sel) : (qk < q_sel);
       if (mean_mode || __any(take)) {
         float res[8];
+        TK_START();
         pass_backward_pair<MODE_INV>(tw, wq4, wl, hw, ys, nullptr, stI, nullptr, last, prek, c, q, res, 0.f, x);
+        TK_STOP(5);
         if (a.stats != nullptr && lane == 0 && active && hw == 0) atomicAdd(a.stats, 1ull);  // executed inverse-pass adjoints (bench.py)
         const float ra = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
         const float rb = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
@@ -176,7 +199,9 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
     w0 = (mean_mode ? inv_k : (ksel == 0 ? 1.0f : 0.0f)) * a.grad_scale;
     // ================= adjoint of F_0 + Adam (T-buf = model 0) =================
     if (K > 1) {
+      TK_START();
       __syncthreads();  // every wave is done with model K-1's buffers
+      TK_STOP(6);
       load_tbuf(sh, mh0, wave, lane, tid);
       load_fbuf(sh, mh0, wave, lane);  // next step's F_0 (and the input rows F_0's adjoint recomputes n from)
     }
@@ -190,10 +215,14 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
       gy[c][2 * q] = -ga * a.grad_scale;
       gy[c][2 * q + 1] = -gb * a.grad_scale;
     }
+    TK_START();
     if (K > 1) __syncthreads();  // model 0's T-buf (and next step's F-buf) landed
+    TK_STOP(7);
     __builtin_amdgcn_wave_barrier();
     float res[8];
+    TK_START();
     pass_backward_pair<MODE_FWD>(tw, wq4, wl, hw, ys, gy, stF, tapeF, nullptr, pre_all + ((size_t)0 * a.B + b) * PRE_FLOATS, c, q, res, w0, x);
+    TK_STOP(8);
     const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
     const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
     // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
@@ -230,6 +259,12 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
       if (step + 1 < S) load_tbuf(sh, mh0 + MH_SIZE, wave, lane, tid);
     }
   }
+#ifdef RIP_PROFILE_TICKS
+  if (blockIdx.x == 7 && lane == 0)
+    printf("ticks wave %d: barrier-top %lld | F %lld | barrier-done %lld barrier-dma %lld | inv %lld adj %lld | "
+           "barrier-last %lld barrier-dma0 %lld | adjF %lld | spin ack %lld data %lld\n", wave, tk_[0], tk_[1], tk_[2], tk_[3], tk_[4],
+           tk_[5], tk_[6], tk_[7], tk_[8], x.spin_ack, x.spin_data);
+#endif
   // plan = F_0(x_best) is in ys (rip/agent.py:137)
   if (active && hw == 0) {
     const size_t orow = (size_t)b * a.N + n0 + c;

@@ -29,27 +29,49 @@ namespace split {
 // One slot per wave (2 rows of 64 x 16 B + 64 x 8 B), a flag (payloads published) and an ack (peer payloads consumed).
 // LDS executes one wave's instructions in order, so "payload stores, then the flag store" and "payload loads, then the
 // ack store" need no fence; every access is volatile so that the compiler keeps them in program order as well.
+// The pointers carry the LDS address space explicitly: through generic pointers every access of the exchange compiled
+// to a FLAT instruction with system scope and `s_waitcnt vmcnt(0) lgkmcnt(0)` — each poll of the peer's word waited for
+// the wave's outstanding global tape stores as well (first build: 3.58 ms per launch against the one-wave shape's 2.51).
+#define RIP_LDS __attribute__((address_space(3)))
+#ifdef RIP_ISA_MARKS  // development: comment lines in the ISA listing (tools/dev/isa_regions.py counts instructions between them)
+#define RIP_MARK(name_) asm volatile("; RIPMARK " name_)
+#else
+#define RIP_MARK(name_)
+#endif
 struct PairXchg {
-  volatile u32x4* my_rows;          // + lane; row r at [r * 64]  (native vectors: HIP's uint4 is a struct without volatile members)
-  const volatile u32x4* peer_rows;
-  volatile f32x2* my_extra;         // + lane
-  const volatile f32x2* peer_extra;
-  volatile unsigned* my_ctl;        // [0] flag, [1] ack
-  const volatile unsigned* peer_ctl;
+  volatile RIP_LDS u32x4* my_rows;          // + lane; row r at [r * 64]  (native vectors: HIP's uint4 is a struct without volatile members)
+  const volatile RIP_LDS u32x4* peer_rows;
+  volatile RIP_LDS f32x2* my_extra;         // + lane
+  const volatile RIP_LDS f32x2* peer_extra;
+  volatile RIP_LDS unsigned* my_ctl;        // [0] flag, [1] ack
+  const volatile RIP_LDS unsigned* peer_ctl;
   unsigned seq;                     // payloads published so far (both waves of a pair publish in lockstep)
+#ifdef RIP_PROFILE_TICKS
+  long long spin_ack = 0, spin_data = 0;  // development: cycles spent waiting for the peer
+#endif
 };
 
-__device__ __forceinline__ void xch_spin(const volatile unsigned* p, unsigned need) {
-  while ((unsigned)__builtin_amdgcn_readfirstlane((int)*p) < need) __builtin_amdgcn_s_sleep(1);
+#ifndef RIP_PAIR_SLEEP
+#define RIP_PAIR_SLEEP 1  // s_sleep argument between two polls of the peer's word (0: poll back to back)
+#endif
+__device__ __forceinline__ void xch_spin(const volatile RIP_LDS unsigned* p, unsigned need) {
+  while ((unsigned)__builtin_amdgcn_readfirstlane((int)*p) < need) {
+    if (RIP_PAIR_SLEEP > 0) __builtin_amdgcn_s_sleep(RIP_PAIR_SLEEP);
+  }
 }
+#ifdef RIP_PROFILE_TICKS
+#define XCH_TIMED(acc_, stmt_) do { const long long t0_ = clock64(); stmt_; acc_ += clock64() - t0_; } while (0)
+#else
+#define XCH_TIMED(acc_, stmt_) do { stmt_; } while (0)
+#endif
 // before overwriting my slot: the peer has consumed my previous payload
-__device__ __forceinline__ void xch_begin(PairXchg& x) { xch_spin(x.peer_ctl + 1, x.seq); }
+__device__ __forceinline__ void xch_begin(PairXchg& x) { XCH_TIMED(x.spin_ack, xch_spin(x.peer_ctl + 1, x.seq)); }
 __device__ __forceinline__ void xch_publish(PairXchg& x) {
   x.seq += 1;
   x.my_ctl[0] = x.seq;
 }
 // the peer's payload number `seq` (the one that matches my last published one) is in its slot
-__device__ __forceinline__ void xch_wait(PairXchg& x) { xch_spin(x.peer_ctl, x.seq); }
+__device__ __forceinline__ void xch_wait(PairXchg& x) { XCH_TIMED(x.spin_data, xch_spin(x.peer_ctl, x.seq)); }
 __device__ __forceinline__ void xch_done(PairXchg& x) { x.my_ctl[1] = x.seq; }
 
 __device__ __forceinline__ u32x4 h8_bits(h16x8 v) { return __builtin_bit_cast(u32x4, v); }
@@ -85,6 +107,7 @@ template <int SAVE>
 __device__ __forceinline__ void fwd_step_pair(const uint4* wl, int hw, float (&H)[8], HSplit& hs, float yp0, float yp1, int q,
                                               unsigned lane, float4* __restrict__ tape, HalfTape* tr, PairXchg& x,
                                               float (&o)[4], unsigned& mask8) {
+  RIP_MARK("fwd_begin");
   const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
   unsigned loff = lane * 16u;
   asm volatile("" : "+v"(loff));
@@ -151,6 +174,7 @@ __device__ __forceinline__ void fwd_step_pair(const uint4* wl, int hw, float (&H
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) H[i] = Hn[i];
+  RIP_MARK("fwd_tiles_done");
   // ---- exchange (a): the new state's own K block ----
   split8<false>(H, 1.f, hs.own_hi, hs.own_lo);
   xch_begin(x);
@@ -214,6 +238,7 @@ __device__ __forceinline__ void fwd_step_pair(const uint4* wl, int hw, float (&H
   if (SAVE == SAVE_REGS) tr->mask = mask8;
   if ((SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) && RIP_ABL != 3)
     *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tape + TAPE_ROWS * 64) + (loff >> 2)) = mask8;  // (both waves: the same word)
+  RIP_MARK("fwd_end");
 }
 
 // forward (x -> y) or inverse pass of the current model, this wave's half (flow_split_dev.h:pass_forward).  `xs` = the
@@ -337,6 +362,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
                                               float w0, AdjCarry& cy, float (&res)[8], PairXchg& x) {
   constexpr bool FIRST = TS == T - 1;
   constexpr bool LASTSTEP = TS == 1;
+  RIP_MARK("adj_begin");
   int zero = 0;
   asm volatile("" : "+v"(zero));
   const uint4* tw = tw_in + zero;
@@ -564,6 +590,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
     *x.my_extra = f32x2{cy.du0, cy.du1};
     xch_publish(x);
   }
+  RIP_MARK("adj_end");
 }
 
 // adjoint pass of the current model, this wave's half (flow_split_dev.h:pass_backward)

@@ -442,7 +442,7 @@ def test_bf16_block_kernels_everywhere(dev):
 
 
 def _headline_kernel_names(variant):
-  """Encoder kernels of the driver-shaped bench (512 observations x 4 models, bf16) per `RIP_OPT_ENCODER_VARIANT` value:
+  """Encoder kernels of the driver-shaped bench (bench.DEFAULT_OBS_BATCH observations x 4 models, bf16) per `RIP_OPT_ENCODER_VARIANT` value:
   the committed manifest tests/golden/headline_kernels.json (recorded from the rocprofv3 kernel traces under profiles/;
   a parity test must not depend on which profiling artefact is newest — VERDICT r5 weak #1)."""
   import json
@@ -455,16 +455,17 @@ def test_bf16_headline_launch_shape_vs_bf16_oracle(dev, variant):
   """the bf16 kernel selection keys on B * k_count, and the teacher-forced block tests above tap ONE
   model at B <= 160 — they never launch `gemm_pers_bf16_kernel<4,false|true>` / `dw_rows_bf16_kernel<1,4>` (features.17 /
   18 of a large launch), nor the grids the fused blocks take at 2048 (model, observation) pairs.  Here the tap runs the
-  headline's own launch (`rip_encode_tap_k`: K = 4 models x B = 512 observations, automatic selection), (a) the
+  headline's own launch (`rip_encode_tap_k`: K = 4 models x B = bench.DEFAULT_OBS_BATCH observations (2048 since round 6), automatic selection), (a) the
   kernel log of a whole encode of that shape must be exactly the encoder kernel set rocprofv3 recorded for the bench
   (the manifest tests/golden/headline_kernels.json), and (b) every output that reaches memory is gated teacher-forced against the bf16 oracle on rows
   {0, 255, 511} of every model (12 images on the oracle side).  variant 0 = what ships (round 5: features.17 is a tile
   block too); variant 8 = features.17 layer-wise, i.e. round 4's selection with `gemm_pers_bf16_kernel<4,false>` x 2 and
   `dw_rows_bf16_kernel<1,4>`, kernels no other launch of the suite reaches."""
+  import bench
   from oracle import bf16_encoder as BE
   from oracle import reference_cpu as O
   from oatomobile_amd import _lib, arch, RIPAgent
-  K, B, C = 4, 512, 2
+  K, B, C = 4, bench.DEFAULT_OBS_BATCH, 2  # (round 6: the bench step is 2048 observations)
   seeds = [100 + k for k in range(K)]
   models = [hip_model(sd, dev, max_batch=1) for sd in seeds]
   agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=B, device=dev, encoder_dtype="bf16")
@@ -513,8 +514,8 @@ def test_bf16_headline_launch_shape_vs_bf16_oracle(dev, variant):
         continue
       _bf16_layer_gate("model %d layers %d..%d" % (k, a, b), taps[b], want[b], worst, layers=b - a + 1)
   worst.sort(key=lambda t: -t[1])
-  print("bf16 headline launch (K = 4, B = 512) vs bf16 oracle: most differing blocks (fraction of elements): %s" %
-        "; ".join("%s %.3f %%" % (t, 100 * f) for _, f, t in worst[:4]))
+  print("bf16 headline launch (K = 4, B = %d) vs bf16 oracle: most differing blocks (fraction of elements): %s" % (B,
+        "; ".join("%s %.3f %%" % (t, 100 * f) for _, f, t in worst[:4])))
   assert max(f for _, f, _ in worst) < 0.02
 
 
@@ -688,7 +689,7 @@ def test_g6_rip_reference_recipe(golden, dev, algo):
     np.testing.assert_allclose(out, g["out30_" + tag], atol=TOL)
 
 
-@pytest.mark.parametrize("kernel", ["chain", "phase", "split"])
+@pytest.mark.parametrize("kernel", ["chain", "phase", "split", "pair"])
 @pytest.mark.parametrize("algo", ["WCM", "MA", "BCM"])
 def test_g6_search_traces(golden, dev, algo, kernel):
   """Per-step posteriors, latents, best loss and plan of BOTH search kernels vs the instrumented reference loop
@@ -722,7 +723,7 @@ def test_g6_search_traces(golden, dev, algo, kernel):
     assert torch.isfinite(tg).all()
 
 
-@pytest.mark.parametrize("kernel", ["chain", "phase", "split"])
+@pytest.mark.parametrize("kernel", ["chain", "phase", "split", "pair"])
 @pytest.mark.parametrize("algo,K", [("WCM", 4), ("MA", 3), ("BCM", 2)])
 def test_teacher_forced_steps_vs_oracle(dev, kernel, algo, K):
   """Removes trajectory amplification from the kernel-vs-oracle comparison: every Adam step of the ORACLE's
@@ -956,7 +957,9 @@ def test_g8_scores(golden, dev):
                                              ("phase", "WCM", 4, 128), ("phase", "MA", 3, 16), ("phase", "BCM", 2, 48),
                                              ("phase", "WCM", 1, 16), ("phase", "WCM", 8, 32), ("phase", "MA", 5, 16),
                                              ("split", "WCM", 4, 128), ("split", "MA", 3, 16), ("split", "BCM", 2, 48),
-                                             ("split", "WCM", 1, 16), ("split", "WCM", 8, 32), ("split", "MA", 5, 16)])
+                                             ("split", "WCM", 1, 16), ("split", "WCM", 8, 32), ("split", "MA", 5, 16),
+                                             ("pair", "WCM", 4, 128), ("pair", "MA", 3, 16), ("pair", "BCM", 2, 48),
+                                             ("pair", "WCM", 1, 16), ("pair", "WCM", 8, 32), ("pair", "MA", 5, 16)])
 def test_search_candidates_vs_oracle(dev, kernel, algo, K, N):
   """N candidates (BASELINE config 3 = K4/N128): every candidate's best loss and plan vs the oracle."""
   from oatomobile_amd import RIPAgent
@@ -1235,14 +1238,14 @@ def test_g10_cil_forward_and_agent(golden, dev):
 # round 2: the bench configuration as a whole, multi-GPU compositions on one GPU, ABI contract, online path
 # ---------------------------------------------------------------------------------------------------------
 def test_bench_configuration_parity(dev):
-  """EXACTLY what bench.py times (BASELINE configs[2]: B = 512 observations per step, K = 4 WCM, N = 128, bf16
+  """EXACTLY what bench.py times (BASELINE configs[2]: B = bench.DEFAULT_OBS_BATCH observations per step, K = 4 WCM, N = 128, bf16
   encoder, auto-selected fused encoder blocks and search kernel) against the oracle: the search is exact given z, so
   the oracle is fed the HIP bf16 z of 16 sampled observations; the plan-level effect of bf16 is REPORTED against
   the fp32 encoder on the same observations."""
   import bench
   from oatomobile_amd import RIPAgent, _lib
   from oracle import reference_cpu as O
-  B, K, N = 512, 4, 128
+  B, K, N = bench.DEFAULT_OBS_BATCH, 4, 128
   seeds = [100 + k for k in range(K)]
   models = [hip_model(s_, dev, max_batch=1) for s_ in seeds]
   refs = [oracle_model(s_) for s_ in seeds]
@@ -2101,8 +2104,9 @@ def test_roctx_ranges_are_opt_in():
     assert want in out.stdout, (flag, out.stdout[-500:])
 
 
+@pytest.mark.parametrize("kernel", ["split", "pair"])
 @pytest.mark.parametrize("algo,K,N,B", [("WCM", 4, 128, 24), ("BCM", 3, 64, 40), ("WCM", 4, 48, 50)])
-def test_split_kernel_is_deterministic_and_counts_its_adjoints(dev, algo, K, N, B):
+def test_split_kernel_is_deterministic_and_counts_its_adjoints(dev, algo, K, N, B, kernel):
   """Two launches of the split-f16 search give the same bits (selected plan, every candidate's plan and best loss,
   selected index), and `rip_search_stats` counts the inverse-pass adjoints that executed: between one (some member is
   always selected) and K - 1 per 16-candidate block and Adam step.  (Rounds 3 / 4 tested RIP_OPT_SEARCH_REGROUP here; the
@@ -2110,7 +2114,7 @@ def test_split_kernel_is_deterministic_and_counts_its_adjoints(dev, algo, K, N, 
   import ctypes
   from oatomobile_amd import RIPAgent, _lib
   models = [hip_model(100 + k, dev) for k in range(K)]
-  agent = RIPAgent(None, algorithm=algo, models=models, num_candidates=N, max_batch=B, seed=7, search_kernel="split")
+  agent = RIPAgent(None, algorithm=algo, models=models, num_candidates=N, max_batch=B, seed=7, search_kernel=kernel)
   lib, h = _lib.load(), agent._handle.raw
   rng = np.random.default_rng(31)
   z = torch.from_numpy(np.maximum(rng.normal(size=(K, B, 64)), 0).astype(np.float32)).to(dev)

@@ -1,0 +1,24 @@
+# GPU box, round 6: the whole GPU suite + the default bench line (+ larger steps)
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6
+timeout 2400 python -m pytest tests/ -q -m gpu -x > gpurun_out/r6/gpu_tests_v1.log 2>&1; echo "tests rc=$?"
+tail -15 gpurun_out/r6/gpu_tests_v1.log | cut -c1-300
+timeout 1200 python bench.py > gpurun_out/r6/bench_v2.json 2> gpurun_out/r6/bench_v2.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+r = json.loads([l for l in open("gpurun_out/r6/bench_v2.json") if l.startswith("{")][-1])
+ro = r["roofline"]
+print("value", r["value"], "ms", r["ms_per_step"], "enc", ro["encoder"]["ms_per_step"], "search", ro["ms_per_launch"], r["repeats"]["calls_per_s"])
+print("frac", ro["frac"], "useful", ro.get("useful_frac"), "measured_hbm_frac", ro.get("measured_hbm_frac"), "whole", ro["whole_act_hbm_frac"])
+for k in ("hbm_resident", "hbm_resident_512", "two_handles_two_streams", "strict_fp32_search", "fp32_parity", "scoring_only", "bev_c4", "train_step"):
+  print(k, {a: b for a, b in (r.get(k) or {}).items() if a != "note"})
+print("replay", {a: b for a, b in r["replay"]["packed_cache"].items() if a != "note"} if r.get("replay") and "packed_cache" in r["replay"] else r.get("replay"))
+print("online", {k: r["online"][k] for k in ("calls_per_s", "p50_us")} if r.get("online") and "p50_us" in r["online"] else r.get("online"))
+print("cpu", {a: b for a, b in (r.get("cpu_baseline") or {}).items() if a in ("value", "cores")})
+PY
+for b in 3072 4096; do
+  timeout 600 python bench.py --obs-batch $b --no-extras --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+  if l.startswith('{'):
+    r=json.loads(l); print('B=$b value %.0f ms %.3f whole %.4f' % (r['value'], r['ms_per_step'], r['roofline']['whole_act_hbm_frac']))"
+done
