@@ -112,6 +112,7 @@ __global__ __launch_bounds__(PWAVES * 64) void search_pair_kernel(SearchArgs a, 
   x.peer_ctl = (const volatile RIP_LDS unsigned*)sh.ctl[peer];
   x.seq = 0;
   if (lane < 2) sh.ctl[wave][lane] = 0u;
+  if (RIP_PAIR_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every arbitration otherwise
 
   // Adam state: lane (c, q) owns latent coordinates 2q, 2q+1 of candidate c — on BOTH waves of the pair (identical)
   float xv0 = a.x0[row * 8 + 2 * q], xv1 = a.x0[row * 8 + 2 * q + 1];

@@ -33,6 +33,13 @@ namespace split {
 // to a FLAT instruction with system scope and `s_waitcnt vmcnt(0) lgkmcnt(0)` — each poll of the peer's word waited for
 // the wave's outstanding global tape stores as well (first build: 3.58 ms per launch against the one-wave shape's 2.51).
 #define RIP_LDS __attribute__((address_space(3)))
+// wave priority around matrix bursts.  RIP_PAIR_PRIO: 0 = never touched, 1 = raised for MFMA bursts (flow_split_dev.h's scheme),
+// 2 = raised for the vector phases instead, 3 = static: the younger half of the workgroup (waves 4..7) runs at priority 1
+#ifndef RIP_PAIR_PRIO
+#define RIP_PAIR_PRIO 1
+#endif
+#define PAIR_PRIO_BURST() do { if (RIP_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(1); else if (RIP_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define PAIR_PRIO_VALU() do { if (RIP_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (RIP_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(1); } while (0)
 #ifdef RIP_ISA_MARKS  // development: comment lines in the ISA listing (tools/dev/isa_regions.py counts instructions between them)
 #define RIP_MARK(name_) asm volatile("; RIPMARK " name_)
 #else
@@ -100,150 +107,48 @@ __device__ __forceinline__ float pick4(const float4& v, int i) {  // i is wave-u
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// One GRU + head step, this wave's half (flow_split_dev.h:fwd_step).  `H` = the own 8 units of the state, `hs` = the B
-// operands of the WHOLE state; both are replaced by the new state's.  `o` = the head output (identical on both waves),
-// `mask8` = the ReLU mask of both a1 tiles.  Per wave: 8 + 1 + 5 fp32 and 36 + 6 f16 MFMAs.
-template <int SAVE>
-__device__ __forceinline__ void fwd_step_pair(const uint4* wl, int hw, float (&H)[8], HSplit& hs, float yp0, float yp1, int q,
-                                              unsigned lane, float4* __restrict__ tape, HalfTape* tr, PairXchg& x,
-                                              float (&o)[4], unsigned& mask8) {
-  RIP_MARK("fwd_begin");
-  const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
-  unsigned loff = lane * 16u;
-  asm volatile("" : "+v"(loff));
-  const float4 wxr = as_f4(wl[48 * 64]), wxz = as_f4(wl[49 * 64]), wxg = as_f4(wl[50 * 64]), wxh = as_f4(wl[51 * 64]);
-  // rows of (gate g, own tile u, K block, term): g * 16 + (2 hw + u) * 4 + kb * 2 + term; own K block kb = hw, peer 1 - hw
-  const uint4* wown = wl + (10 * hw) * 64;
-  const uint4* wpeer = wl + (6 * hw + 2) * 64;
+// ---- forward / inverse pass, this wave's half (flow_split_dev.h:fwd_step / pass_forward), software-pipelined over the
+// two exchanges of a step.  The 64-deep contraction of a unit tile is the sum of two K blocks, the wave's own (its own
+// units of h) and the peer's; the k-steps that multiply y_{t-1} go LAST into the same accumulators.  So the tile MFMAs
+// of step t + 1 are issued inside step t, where the wave would otherwise wait for its peer:
+//     k-steps(y_{t-1}) -> gates(t) -> split own h -> publish (a)
+//     -> own-K-block tile MFMAs of step t + 1, own-K-block head MFMAs        [the peer's K block is in flight]
+//     -> wait (a) -> peer-K-block head MFMAs, W2 -> publish (b)
+//     -> peer-K-block tile MFMAs of step t + 1                               [the peer's partial head output is in flight]
+//     -> wait (b) -> coupling(t)
+// (a) = the new state's own K block as B operands (hi, lo: 32 B per lane), (b) = the partial head output W2 relu(a1_own)
+// (4 floats) and the own a1 tile's ReLU mask.  `H` = the own 8 units of the state, `hs` = the B operands of the WHOLE state.
+struct TileAcc2 {
+  f32x4 a[2][3];  // own tiles u = 0, 1: pre_r, pre_z, gh_n (without their y / bias k-steps)
+};
+
+// the 2 x 9 tile MFMAs of one K block: rows (gate g, own tile u, term) at `wk` + (g * 16 + 4 u + term) * 64
+template <bool INIT>
+__device__ __forceinline__ void pair_tiles_kb(const uint4* wk, h16x8 bhi, h16x8 blo, h16x8 bhs, TileAcc2& t) {
   auto row = [](int g, int u, int term) { return (g * 16 + 4 * u + term) * 64; };
-  float Hn[8];
+  uint4 RH[2][3], RL[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) RH[0][g] = wk[row(g, 0, 0)];
+  PAIR_PRIO_BURST();
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int up = 2 * hw + u;
-    f32x4 acc[3], agn;
-    uint4 RH[3], RL[3], PH[3], PL[3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) RH[g] = wown[row(g, u, 0)];
+    for (int g = 0; g < 3; ++g) RL[g] = wk[row(g, u, 1)];
+    if (u == 0) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) RL[g] = wown[row(g, u, 1)];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) PH[g] = wpeer[row(g, u, 0)];
-    SPLIT_PRIO_BURST();
-    acc[0] = mfma4(pick4(wxr, up), bin, zero4());
-    acc[1] = mfma4(pick4(wxz, up), bin, zero4());
-    agn = mfma4(pick4(wxg, up), bin, zero4());
-    acc[2] = mfma4(pick4(wxh, up), bin, zero4());
-#pragma unroll
-    for (int g = 0; g < 3; ++g) PL[g] = wpeer[row(g, u, 1)];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfmah(as_h8(RH[g]), hs.own_hi, acc[g]);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfmah(as_h8(RH[g]), hs.own_lo, acc[g]);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfmah(as_h8(RL[g]), hs.own_hs, acc[g]);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfmah(as_h8(PH[g]), hs.peer_hi, acc[g]);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfmah(as_h8(PH[g]), hs.peer_lo, acc[g]);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfmah(as_h8(PL[g]), hs.peer_hs, acc[g]);
-    SPLIT_PRIO_VALU();
-    const f32x4 ahn = acc[2];
-    float rr[4], zz[4], nn[4];
-    gru_gates(acc[0], acc[1], agn, ahn, &H[u * 4], &Hn[u * 4], rr, zz, nn);
-    asm volatile("" : "+v"(Hn[u * 4]), "+v"(Hn[u * 4 + 1]), "+v"(Hn[u * 4 + 2]), "+v"(Hn[u * 4 + 3]));
-    if (SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) {
-      float4* tp = tape + (8 * hw + 4 * u) * 64;
-      tape_st(trow(tp, 0, loff), rr[0], rr[1], rr[2], rr[3]);
-      tape_st(trow(tp, 1, loff), zz[0], zz[1], zz[2], zz[3]);
-      tape_st(trow(tp, 3, loff), ahn[0], ahn[1], ahn[2], ahn[3]);
-      if (SAVE == SAVE_TAPE) tape_st(trow(tape + (16 + 2 * hw + u) * 64, 0, loff), H[u * 4], H[u * 4 + 1], H[u * 4 + 2], H[u * 4 + 3]);
-    }
-    if (SAVE == SAVE_REGS) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        tr->hp[u * 4 + r] = H[u * 4 + r];
-        tr->r[u * 4 + r] = rr[r];
-        tr->z[u * 4 + r] = zz[r];
-        tr->n[u * 4 + r] = nn[r];
-        tr->gh[u * 4 + r] = ahn[r];
-      }
+      for (int g = 0; g < 3; ++g) RH[1][g] = wk[row(g, 1, 0)];
     }
     __builtin_amdgcn_sched_barrier(0);
-  }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) H[i] = Hn[i];
-  RIP_MARK("fwd_tiles_done");
-  // ---- exchange (a): the new state's own K block ----
-  split8<false>(H, 1.f, hs.own_hi, hs.own_lo);
-  xch_begin(x);
-  x.my_rows[0] = h8_bits(hs.own_hi);
-  x.my_rows[64] = h8_bits(hs.own_lo);
-  xch_publish(x);
-  hs.own_hs = scale_hs(hs.own_hi);
-  // head rows of the own a1 tile mt = hw: 52 + (mt * 2 + kb) * 2 + term; fp32 rows 60..62
-  const uint4* h_own = wl + (52 + 6 * hw) * 64;
-  const uint4* h_peer = wl + (54 + 2 * hw) * 64;
-  const float bone = q == 2 ? 1.f : 0.f;
-  const float4 t60 = as_f4(wl[60 * 64]), t61 = as_f4(wl[61 * 64]), t62 = as_f4(wl[62 * 64]);
-  const uint4 woh = h_own[0], wol = h_own[64];
-  const uint4 wph = h_peer[0], wpl = h_peer[64];
-  SPLIT_PRIO_BURST();
-  f32x4 a0 = mfma4(hw ? t60.y : t60.x, bone, zero4());
-  a0 = mfmah(as_h8(woh), hs.own_hi, a0);
-  f32x4 a1 = mfmah(as_h8(woh), hs.own_lo, zero4());
-  a0 = mfmah(as_h8(wol), hs.own_hs, a0);
-  SPLIT_PRIO_VALU();
-  xch_wait(x);
-  {
-    const u32x4 ph = x.peer_rows[0], pl = x.peer_rows[64];
-    hs.peer_hi = __builtin_bit_cast(h16x8, ph);
-    hs.peer_lo = __builtin_bit_cast(h16x8, pl);
-  }
-  xch_done(x);
-  hs.peer_hs = scale_hs(hs.peer_hi);
-  SPLIT_PRIO_BURST();
-  a1 = mfmah(as_h8(wph), hs.peer_hi, a1);
-  a0 = mfmah(as_h8(wph), hs.peer_lo, a0);
-  a1 = mfmah(as_h8(wpl), hs.peer_hs, a1);
-  SPLIT_PRIO_VALU();
-  const f32x4 av = a0 + a1;
-  unsigned m4 = 0;
+    for (int g = 0; g < 3; ++g) t.a[u][g] = mfmah(as_h8(RH[u][g]), bhi, INIT ? zero4() : t.a[u][g]);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) m4 |= av[r] > 0.f ? (1u << r) : 0u;
-  // W2 k-steps of the own a1 tile: tile 0 = (t60.z, t60.w, t61.x, t61.y), tile 1 = (t61.z, t61.w, t62.x, t62.y); b2 = t62.z (wave 0)
-  SPLIT_PRIO_BURST();
-  f32x4 oa = mfma4(hw ? t61.z : t60.z, fmaxf(av[0], 0.f), zero4());
-  oa = mfma4(hw ? t61.w : t60.w, fmaxf(av[1], 0.f), oa);
-  oa = mfma4(hw ? t62.x : t61.x, fmaxf(av[2], 0.f), oa);
-  oa = mfma4(hw ? t62.y : t61.y, fmaxf(av[3], 0.f), oa);
-  oa = mfma4(hw ? 0.f : t62.z, bone, oa);
-  SPLIT_PRIO_VALU();
-  // ---- exchange (b): the partial head output and the tile's ReLU mask ----
-  xch_begin(x);
-  x.my_rows[0] = f4_bits(oa[0], oa[1], oa[2], oa[3]);
-  *x.my_extra = f32x2{__uint_as_float(m4), 0.f};
-  xch_publish(x);
-  xch_wait(x);
-  const u32x4 po = x.peer_rows[0];
-  const f32x2 pe = *x.peer_extra;
-  xch_done(x);
-  const unsigned m4p = __float_as_uint(pe.x);
-  o[0] = oa[0] + __uint_as_float(po[0]);
-  o[1] = oa[1] + __uint_as_float(po[1]);
-  o[2] = oa[2] + __uint_as_float(po[2]);
-  o[3] = oa[3] + __uint_as_float(po[3]);
-  mask8 = hw ? (m4p | (m4 << 4)) : (m4 | (m4p << 4));
-  if (SAVE == SAVE_REGS) tr->mask = mask8;
-  if ((SAVE == SAVE_TAPE || SAVE == SAVE_TAPE_NOHP) && RIP_ABL != 3)
-    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tape + TAPE_ROWS * 64) + (loff >> 2)) = mask8;  // (both waves: the same word)
-  RIP_MARK("fwd_end");
+    for (int g = 0; g < 3; ++g) t.a[u][g] = mfmah(as_h8(RH[u][g]), blo, t.a[u][g]);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) t.a[u][g] = mfmah(as_h8(RL[g]), bhs, t.a[u][g]);
+  }
+  PAIR_PRIO_VALU();
 }
 
-// forward (x -> y) or inverse pass of the current model, this wave's half (flow_split_dev.h:pass_forward).  `xs` = the
-// latent in, `ys` = y (out: MODE_FWD, in: MODE_INV), `st` = per-candidate scalars for the adjoint; xs / ys / st belong to
-// the PAIR: both waves write the same values.  MODE_FWD tapes to global memory, MODE_INV to registers (`last`).
 template <int MODE>
 __device__ __forceinline__ PassOut pass_forward_pair(const uint4* wl, int hw, const Prefix16& pre, const float (*xs)[8],
                                                      float (*ys)[8], float (*st)[6][CB], float4* __restrict__ tape,
@@ -293,51 +198,157 @@ __device__ __forceinline__ PassOut pass_forward_pair(const uint4* wl, int hw, co
     hs.own_hs = scale_hs(hs.own_hi);
     hs.peer_hs = scale_hs(hs.peer_hi);
   }
-  auto coupling = [&](int t, const float (&o)[4]) __attribute__((always_inline)) {
-    const float s0 = softplusf_(o[2]) + 1e-3f;  // sequence.py:133
-    const float s1 = softplusf_(o[3]) + 1e-3f;
-    float x0, x1, y0, y1;
-    if (MODE == MODE_FWD) {
-      x0 = xs[c][2 * t];
-      x1 = xs[c][2 * t + 1];
-      y0 = (yp0 + o[0]) + s0 * x0;  // sequence.py:136
-      y1 = (yp1 + o[1]) + s1 * x1;
-      if (q == 0) {
-        ys[c][2 * t] = y0;
-        ys[c][2 * t + 1] = y1;
-      }
-    } else {
-      y0 = ys[c][2 * t];
-      y1 = ys[c][2 * t + 1];
-      x0 = (y0 - (yp0 + o[0])) * rcpf_(s0);  // sequence.py:196
-      x1 = (y1 - (yp1 + o[1])) * rcpf_(s1);
-    }
-    po.sq = fmaf(x0, x0, fmaf(x1, x1, po.sq));
-    po.lad += __logf(s0 * s1);
-    if (q == 0) {
-      st[t][0][c] = x0;
-      st[t][1][c] = x1;
-      st[t][2][c] = s0;
-      st[t][3][c] = s1;
-      st[t][4][c] = softplus_gradf_(o[2]);
-      st[t][5][c] = softplus_gradf_(o[3]);
-    }
-    yp0 = y0;
-    yp1 = y1;
-  };
+  unsigned loff = lane * 16u;
+  asm volatile("" : "+v"(loff));
+  // operand rows (flow.h MHF_*): W_hh row of (gate g, tile up, K block kb, term) = g * 16 + up * 4 + kb * 2 + term with
+  // up = 2 hw + u; own K block kb = hw, the peer's 1 - hw.  Head rows of the own a1 tile mt = hw: 52 + (mt * 2 + kb) * 2 + term.
+  const uint4* wown = wl + (10 * hw) * 64;
+  const uint4* wpeer = wl + (6 * hw + 2) * 64;
+  const uint4* h_own = wl + (52 + 6 * hw) * 64;
+  const uint4* h_peer = wl + (54 + 2 * hw) * 64;
+  const float bone = q == 2 ? 1.f : 0.f;
+  TileAcc2 acc;
+  pair_tiles_kb<true>(wown, hs.own_hi, hs.own_lo, hs.own_hs, acc);
+  pair_tiles_kb<false>(wpeer, hs.peer_hi, hs.peer_lo, hs.peer_hs, acc);
 #pragma unroll
   for (int t = 1; t < T; ++t) {
-    float o[4];
-    unsigned m8;
+    RIP_MARK("fwd_begin");
     int zero = 0;
     asm volatile("" : "+v"(zero));  // the (loop-invariant) operand reads must not be merged across steps
-    if (MODE == MODE_INV)
-      fwd_step_pair<SAVE_REGS>(wl + zero, hw, H, hs, yp0, yp1, q, lane, nullptr, &last[t - 1], x, o, m8);
-    else if (t == 1)
-      fwd_step_pair<SAVE_TAPE_NOHP>(wl + zero, hw, H, hs, yp0, yp1, q, lane, tape, nullptr, x, o, m8);
-    else
-      fwd_step_pair<SAVE_TAPE>(wl + zero, hw, H, hs, yp0, yp1, q, lane, tape + (t - 1) * TAPE_STEP_F4, nullptr, x, o, m8);
-    coupling(t, o);
+    const uint4* wz = wl + zero;
+    float4* tp = MODE == MODE_FWD ? tape + (t - 1) * TAPE_STEP_F4 : nullptr;
+    HalfTape* tr = MODE == MODE_INV ? &last[t - 1] : nullptr;
+    // ---- the y / bias k-steps on top of the tile accumulators, then the gates of the own two tiles ----
+    const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
+    const float4 wxr = as_f4(wz[48 * 64]), wxz = as_f4(wz[49 * 64]), wxg = as_f4(wz[50 * 64]), wxh = as_f4(wz[51 * 64]);
+    float Hn[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int up = 2 * hw + u;
+      PAIR_PRIO_BURST();
+      const f32x4 ar = mfma4(pick4(wxr, up), bin, acc.a[u][0]);
+      const f32x4 az = mfma4(pick4(wxz, up), bin, acc.a[u][1]);
+      const f32x4 agn = mfma4(pick4(wxg, up), bin, zero4());
+      const f32x4 ahn = mfma4(pick4(wxh, up), bin, acc.a[u][2]);
+      PAIR_PRIO_VALU();
+      float rr[4], zz[4], nn[4];
+      gru_gates(ar, az, agn, ahn, &H[u * 4], &Hn[u * 4], rr, zz, nn);
+      asm volatile("" : "+v"(Hn[u * 4]), "+v"(Hn[u * 4 + 1]), "+v"(Hn[u * 4 + 2]), "+v"(Hn[u * 4 + 3]));
+      if (MODE == MODE_FWD) {
+        float4* tpu = tp + (8 * hw + 4 * u) * 64;
+        tape_st(trow(tpu, 0, loff), rr[0], rr[1], rr[2], rr[3]);
+        tape_st(trow(tpu, 1, loff), zz[0], zz[1], zz[2], zz[3]);
+        tape_st(trow(tpu, 3, loff), ahn[0], ahn[1], ahn[2], ahn[3]);
+        if (t > 1) tape_st(trow(tp + (16 + 2 * hw + u) * 64, 0, loff), H[u * 4], H[u * 4 + 1], H[u * 4 + 2], H[u * 4 + 3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          tr->hp[u * 4 + r] = H[u * 4 + r];
+          tr->r[u * 4 + r] = rr[r];
+          tr->z[u * 4 + r] = zz[r];
+          tr->n[u * 4 + r] = nn[r];
+          tr->gh[u * 4 + r] = ahn[r];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) H[i] = Hn[i];
+    RIP_MARK("fwd_tiles_done");
+    // ---- exchange (a): the new state's own K block ----
+    split8<false>(H, 1.f, hs.own_hi, hs.own_lo);
+    xch_begin(x);
+    x.my_rows[0] = h8_bits(hs.own_hi);
+    x.my_rows[64] = h8_bits(hs.own_lo);
+    xch_publish(x);
+    hs.own_hs = scale_hs(hs.own_hi);
+    if (t + 1 < T) pair_tiles_kb<true>(wown + zero, hs.own_hi, hs.own_lo, hs.own_hs, acc);  // step t + 1, own K block
+    const float4 t60 = as_f4(wz[60 * 64]), t61 = as_f4(wz[61 * 64]), t62 = as_f4(wz[62 * 64]);
+    const uint4 woh = (h_own + zero)[0], wol = (h_own + zero)[64];
+    const uint4 wph = (h_peer + zero)[0], wpl = (h_peer + zero)[64];
+    PAIR_PRIO_BURST();
+    f32x4 a0 = mfma4(hw ? t60.y : t60.x, bone, zero4());
+    a0 = mfmah(as_h8(woh), hs.own_hi, a0);
+    f32x4 a1 = mfmah(as_h8(woh), hs.own_lo, zero4());
+    a0 = mfmah(as_h8(wol), hs.own_hs, a0);
+    PAIR_PRIO_VALU();
+    xch_wait(x);
+    {
+      const u32x4 ph = x.peer_rows[0], pl = x.peer_rows[64];
+      hs.peer_hi = __builtin_bit_cast(h16x8, ph);
+      hs.peer_lo = __builtin_bit_cast(h16x8, pl);
+    }
+    xch_done(x);
+    hs.peer_hs = scale_hs(hs.peer_hi);
+    PAIR_PRIO_BURST();
+    a1 = mfmah(as_h8(wph), hs.peer_hi, a1);
+    a0 = mfmah(as_h8(wph), hs.peer_lo, a0);
+    a1 = mfmah(as_h8(wpl), hs.peer_hs, a1);
+    PAIR_PRIO_VALU();
+    const f32x4 av = a0 + a1;
+    unsigned m4 = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m4 |= av[r] > 0.f ? (1u << r) : 0u;
+    // W2 k-steps of the own a1 tile: tile 0 = (t60.z, t60.w, t61.x, t61.y), tile 1 = (t61.z, t61.w, t62.x, t62.y); b2 = t62.z (wave 0)
+    PAIR_PRIO_BURST();
+    f32x4 oa = mfma4(hw ? t61.z : t60.z, fmaxf(av[0], 0.f), zero4());
+    oa = mfma4(hw ? t61.w : t60.w, fmaxf(av[1], 0.f), oa);
+    oa = mfma4(hw ? t62.x : t61.x, fmaxf(av[2], 0.f), oa);
+    oa = mfma4(hw ? t62.y : t61.y, fmaxf(av[3], 0.f), oa);
+    oa = mfma4(hw ? 0.f : t62.z, bone, oa);
+    PAIR_PRIO_VALU();
+    // ---- exchange (b): the partial head output and the tile's ReLU mask ----
+    xch_begin(x);
+    x.my_rows[0] = f4_bits(oa[0], oa[1], oa[2], oa[3]);
+    *x.my_extra = f32x2{__uint_as_float(m4), 0.f};
+    xch_publish(x);
+    if (t + 1 < T) pair_tiles_kb<false>(wpeer + zero, hs.peer_hi, hs.peer_lo, hs.peer_hs, acc);  // step t + 1, the peer's K block
+    xch_wait(x);
+    const u32x4 pob = x.peer_rows[0];
+    const f32x2 pe = *x.peer_extra;
+    xch_done(x);
+    const unsigned m4p = __float_as_uint(pe.x);
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = oa[r] + __uint_as_float(pob[r]);
+    const unsigned mask8 = hw ? (m4p | (m4 << 4)) : (m4 | (m4p << 4));
+    if (MODE == MODE_INV) tr->mask = mask8;
+    if (MODE == MODE_FWD && RIP_ABL != 3)
+      *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tp + TAPE_ROWS * 64) + (loff >> 2)) = mask8;  // (both waves: the same word)
+    RIP_MARK("fwd_end");
+    // ---- coupling (sequence.py:133-136 / :193-196), on both waves ----
+    {
+      const float s0 = softplusf_(o[2]) + 1e-3f;
+      const float s1 = softplusf_(o[3]) + 1e-3f;
+      float x0, x1, y0, y1;
+      if (MODE == MODE_FWD) {
+        x0 = xs[c][2 * t];
+        x1 = xs[c][2 * t + 1];
+        y0 = (yp0 + o[0]) + s0 * x0;
+        y1 = (yp1 + o[1]) + s1 * x1;
+        if (q == 0) {
+          ys[c][2 * t] = y0;
+          ys[c][2 * t + 1] = y1;
+        }
+      } else {
+        y0 = ys[c][2 * t];
+        y1 = ys[c][2 * t + 1];
+        x0 = (y0 - (yp0 + o[0])) * rcpf_(s0);
+        x1 = (y1 - (yp1 + o[1])) * rcpf_(s1);
+      }
+      po.sq = fmaf(x0, x0, fmaf(x1, x1, po.sq));
+      po.lad += __logf(s0 * s1);
+      if (q == 0) {
+        st[t][0][c] = x0;
+        st[t][1][c] = x1;
+        st[t][2][c] = s0;
+        st[t][3][c] = s1;
+        st[t][4][c] = softplus_gradf_(o[2]);
+        st[t][5][c] = softplus_gradf_(o[3]);
+      }
+      yp0 = y0;
+      yp1 = y1;
+    }
   }
   return po;
 }
@@ -459,7 +470,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
     split8<true>(da1r, sa, ah, al);
     const uint4* t1 = tw + (1 + 4 * hw) * 64;
     const uint4 r0h = t1[0], r0l = t1[64], r1h = t1[128], r1l = t1[192];
-    SPLIT_PRIO_BURST();
+    PAIR_PRIO_BURST();
     f32x4 a[2];
     a[0] = mfmah(as_h8(r0h), ah, zero4());
     a[1] = mfmah(as_h8(r1h), ah, zero4());
@@ -467,7 +478,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
     a[1] = mfmah(as_h8(r1h), al, a[1]);
     a[0] = mfmah(as_h8(r0l), ah, a[0]);
     a[1] = mfmah(as_h8(r1l), ah, a[1]);
-    SPLIT_PRIO_VALU();
+    PAIR_PRIO_VALU();
 #pragma unroll
     for (int i = 0; i < 8; ++i) dh[i] = a[i >> 2][i & 3] * ia;
   }
@@ -537,7 +548,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
   // ---- du (own partial) = W_ih^T over the own K blocks hw, 2 + hw, 4 + hw: table entry ((kb * 2 + term) * 8) ----
   {
     f32x4 ua = zero4(), ul = zero4(), ub = zero4();
-    SPLIT_PRIO_BURST();
+    PAIR_PRIO_BURST();
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const h16x8 wh = as_h8(wtab[(j * 4 + 0) * 8]), wo = as_h8(wtab[(j * 4 + 1) * 8]);
@@ -547,7 +558,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
       ul = mfmah(wh, bl, ul);
       ub = mfmah(wo, bh, ub);
     }
-    SPLIT_PRIO_VALU();
+    PAIR_PRIO_VALU();
     cy.du0 = (ua[0] + (ul[0] + ub[0])) * ig;
     cy.du1 = (ua[1] + (ul[1] + ub[1])) * ig;
   }
@@ -557,7 +568,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
     auto contract = [&](const uint4* base, float (&out)[8]) __attribute__((always_inline)) {
       f32x4 a[2] = {zero4(), zero4()};
       uint4 RH[2], RL[2];
-      SPLIT_PRIO_BURST();
+      PAIR_PRIO_BURST();
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const h16x8 bh = j == 0 ? r_hi : (j == 1 ? z_hi : n_hi);
@@ -573,7 +584,7 @@ __device__ __forceinline__ void adj_step_pair(const uint4* tw_in, const uint4* w
         a[0] = mfmah(as_h8(RL[0]), bh, a[0]);
         a[1] = mfmah(as_h8(RL[1]), bh, a[1]);
       }
-      SPLIT_PRIO_VALU();
+      PAIR_PRIO_VALU();
 #pragma unroll
       for (int i = 0; i < 8; ++i) out[i] = a[i >> 2][i & 3] * ig;
     };
