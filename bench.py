@@ -507,7 +507,7 @@ def main():
 
   # the same resident step at 512 observations (rounds 2-5 ran `value` at 512 observations per step)
   hbm512 = None
-  if B > 512:
+  if B > 512 and not args.no_extras:  # (an extra: under rocprofv3 its launches would be averaged into the headline's kernels)
     b5 = 512
     small = [tuple(t[:b5] for t in bt) for bt in batches]
     x0_5, z5 = agent._x0(b5), torch.empty(K, b5, 64, device=dev)
@@ -565,7 +565,13 @@ def main():
     exec_flops = n16 * MFMA_F16[0] + n32 * MFMA_F32[0]
     pipe_cycles = n16 * MFMA_F16[1] + n32 * MFMA_F32[1]  # matrix-pipe issue cycles, summed over the SIMDs
     extras["mfma_instructions"] = {"f16_16x16x32": n16, "f32_16x16x4": n32}
-    useful_flops = n16 / 3.0 * MFMA_F16[0] + n32 * MFMA_F32[0]  # a two-term product is three f16 MFMAs: counted once
+    # `useful`: a two-term product (three f16 MFMAs) counted once; the round-6 forward step's input / bias k-steps (12 f16
+    # MFMAs of which 16 rows x 3 K x 16 candidates are arithmetic) and its W2 block (3 MFMAs for 4 rows x 32 K x 16) at the
+    # flops they stand for, not at the 16 x 32 x 16 the instruction executes
+    useful_flops = n16 / 3.0 * MFMA_F16[0] + n32 * MFMA_F32[0]
+    if plan_info["kernel"] == 4 and plan_info["pass"][1] == 0:
+      steps_fwd = blocks16 * 3 * ((S + 1) + S * (K - 1)) + B * K  # forward / inverse GRU + head steps of the launch (+ prefix steps)
+      useful_flops -= steps_fwd * (15 / 3.0 * MFMA_F16[0] - (12 * 2 * 16 * 3 * 16 + 2 * 4 * 32 * 16))
     extras["waves_per_workgroup"] = plan_info["waves_per_workgroup"]
     if plan_info["kernel"] == 4:
       # the same launch on the fp32-MFMA kernel (flow_phase.hip), for comparison with the fp32 floor of round 2
@@ -769,7 +775,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": ("bf16 encoder (bf16 storage, fp32 accumulate) + " if args.encoder_dtype == "bf16" else "fp32 encoder + ") +
-                 "flow/search: fp32 accumulate, GRU/head contractions as two-term binary16 (22-bit) operands on f16 MFMA",
+                 "flow/search: fp32 accumulate, GRU/head contractions as two-term binary16 (22-bit) operands on f16 MFMA "
+                 "(the waypoint / bias terms as three-term, 33-bit operands)",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: RIPAgent K=%d %s, N=%d candidate plans, %d Adam steps, 200x200x%d BEV, "
                                "%s encoder + fp32 flow" % (K, args.algorithm, N, S, C, args.encoder_dtype),

@@ -1114,7 +1114,7 @@ bool fold_and_pack(const EncoderPlan& plan, const float* packed, size_t numel, s
         }
   }
   // ---- operands of the split-f16 search kernel (flow_split.hip) ----
-  const float wmax = pack_split_operands(mw.data(), wih, whh, w1, mh);
+  const float wmax = pack_split_operands(mw.data(), wih, whh, w1, bih, bhh, b1, w2, b2, mh);
   if (split_wmax != nullptr) *split_wmax = wmax;
   return true;
 }

@@ -24,9 +24,14 @@ constexpr int MWB_F4 = 69;
 constexpr int MW_SIZE = MWF_FLOATS + MWB_F4 * 64 * 4;
 // split-f16 search kernel operands (flow_split.hip, packed by flow_split_pack.h), in dwords; a row = 64 lanes x 16 B.
 // Forward rows: 0..47 W_hh ((gate g, unit tile up, K block kb) x (hi, lo')), 48..51 the fp32 input / bias k-steps,
-// 52..59 W1 ((tile mt, kb) x (hi, lo')), 60..62 fp32 (b1, W2, b2).  Transposed rows: 0 = W2^T (fp32), 1..8 W1^T
-// (out tile ut x (hi, lo')), 9..56 W_hh^T ((kb 0..5, ut) x (hi, lo')); then the 96-entry W_ih^T table.
-constexpr int MHF_ROWS = 63, MHF_WHH = 0, MHF_WX = 48, MHF_W1 = 52, MHF_TAIL = 60;
+// 52..59 W1 ((tile mt, kb) x (hi, lo')), 60..62 fp32 (b1, W2, b2) — rows 0..62 are what flow_pair.hip stages (round 5's
+// forward step).  Round 6, flow_split.hip's forward step without fp32 MFMAs: 63..74 the input / bias k-steps as ONE f16 K
+// block per (gate r / z / gi_n, unit tile) (three-term weights x three-term y / 4), 75..78 b_hn as accumulator images
+// (lane (c, q): units 16 up + 4 q + r), 79, 80 b1 likewise, 81, 82 W2 x 4 (hi, lo') as one K block over the 32 head
+// units, 83 b2.  Transposed rows: 0 = W2^T (fp32), 1..8 W1^T (out tile ut x (hi, lo')), 9..56 W_hh^T ((kb 0..5, ut) x
+// (hi, lo')); then the 96-entry W_ih^T table.
+constexpr int MHF_BASE_ROWS = 63, MHF_WHH = 0, MHF_WX = 48, MHF_W1 = 52, MHF_TAIL = 60;
+constexpr int MHF_KS = 63, MHF_GHB = 75, MHF_B1 = 79, MHF_W2 = 81, MHF_B2 = 83, MHF_ROWS = 84;
 constexpr int MHT_ROWS = 57, MHT_W2T = 0, MHT_W1T = 1, MHT_WHHT = 9;
 constexpr int MH_TABLE_F4 = 96;
 constexpr int MH_SIZE = (MHF_ROWS + MHT_ROWS) * 256 + MH_TABLE_F4 * 4;

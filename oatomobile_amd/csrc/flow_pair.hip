@@ -25,7 +25,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int PWAVES = 8;   // waves per workgroup
 constexpr int PBLOCKS = 4;  // 16-candidate blocks (= pairs) per workgroup
-constexpr int F_ROWS = MHF_ROWS;
+constexpr int F_ROWS = MHF_BASE_ROWS;  // (round 5's forward rows: this kernel keeps the fp32 k-steps; its LDS has no room for more)
 constexpr int T_ROWS = MHT_ROWS;
 
 struct PairShared {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void load_fbuf(PairShared& sh, const uint32_t* __rest
   dma_rows8(reinterpret_cast<const uint4*>(mhk), sh.fbuf, F_ROWS, wave, lane);
 }
 __device__ __forceinline__ void load_tbuf(PairShared& sh, const uint32_t* __restrict__ mhk, int wave, int lane, int tid) {
-  const uint4* src = reinterpret_cast<const uint4*>(mhk) + F_ROWS * 64;
+  const uint4* src = reinterpret_cast<const uint4*>(mhk) + MHF_ROWS * 64;
   dma_rows8(src, sh.tbuf, T_ROWS, wave, lane);
   if (tid < MH_TABLE_F4) sh.wihc[tid] = src[T_ROWS * 64 + tid];
 }

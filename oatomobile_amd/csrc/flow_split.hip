@@ -26,12 +26,12 @@ using namespace split;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-constexpr int WPB_MAX = 8;
-constexpr int PARK_F4 = 3 * 64;  // per 16-candidate block: the Adam state of the 8-wave build between its uses
+constexpr int WPB_MAX = 8;       // (scratch is padded to 8 blocks: the paired shape, flow_pair.hip, shares the layout)
+constexpr int PARK_F4 = 3 * 64;  // per 16-candidate block: kept in the scratch layout (round 3-5's 8-wave build parked its Adam state here)
 constexpr int F_ROWS = MHF_ROWS;
 constexpr int T_ROWS = MHT_ROWS;
 #ifndef RIP_PAIR_COST
-#define RIP_PAIR_COST 9.0  // time of a round of paired workgroups relative to the 4-wave shape's (until measured: never picked)
+#define RIP_PAIR_COST 1.27  // time of a round of paired workgroups relative to the 4-wave shape's (measured)
 #endif
 #ifndef RIP_REGTAPE
 #define RIP_REGTAPE 1  // 4- / 2-wave workgroups keep the inverse passes' whole tape in registers
@@ -113,13 +113,15 @@ __global__ __launch_bounds__(64) void split_prefix_kernel(SearchArgs a, const ui
 #define TK_STOP(i_)
 #endif
 
-// WPB: waves per workgroup.  8 = two per SIMD (full launches); 4 / 2 for launches that would otherwise leave CUs idle
-// (one workgroup per CU holds the operand buffers: 128 observations x 8 blocks are 128 eight-wave workgroups on 256
-// CUs, but 256 four-wave ones).
+// WPB: waves per workgroup = 16-candidate blocks per workgroup (one workgroup per CU holds the operand buffers): 4 = one
+// wave per SIMD (full launches), 2 for launches that would otherwise leave CUs idle.  Rounds 3-5 also built WPB = 8 (two
+// waves per SIMD at 256 registers each: the tape in global memory, the Adam state parked there): never faster (2.66 vs
+// 2.50 ms, DESIGN_HISTORY), never selected by the cost model, and retired in round 6 — its LDS no longer fits beside the
+// forward step's new operand rows; the two-waves-per-SIMD experiment of round 6 is the paired shape (flow_pair.hip).
 template <bool TRACE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, const uint32_t* __restrict__ mh_all,
                                                                 const float* __restrict__ pre_all,
-                                                                float4* __restrict__ tape_all, float4* __restrict__ park_all) {
+                                                                float4* __restrict__ tape_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   PShared<WPB>& sh = *reinterpret_cast<PShared<WPB>*>(smem_raw);
   // operand-range guard: some |z| of this launch is beyond what the unscaled binary16 split carries -> the fp32-MFMA
@@ -150,8 +152,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
   // wave-uniform tape bases (scalar registers): lanes add their own 16-byte column at each access
   float4* tapeF = tape_all + ((size_t)item * 2 + (RIP_ABL == 4 ? 1 : 0)) * TAPE_SLOT_F4;  // ABL 4: aliased tapes
   float4* tapeI = tape_all + ((size_t)item * 2 + 1) * TAPE_SLOT_F4;
-  constexpr bool PARK = WPB == 8;
-  float4* park = park_all + (size_t)item * PARK_F4;  // PARK: 3 lane-major rows per block
+  static_assert(WPB <= 4, "one wave per SIMD: the inverse passes' tape lives in registers");
 
   // Adam state: lane (c, q) owns latent coordinates 2q, 2q+1 of candidate c
   float xv0 = a.x0[row * 8 + 2 * q], xv1 = a.x0[row * 8 + 2 * q + 1];
@@ -182,14 +183,6 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     // ================= F_0: x -> y (F-buf = model 0) =================
     io[c][2 * q] = final_pass ? xb0 : xv0;
     io[c][2 * q + 1] = final_pass ? xb1 : xv1;
-    if (PARK) {
-      // two waves per SIMD have 256 registers each and the passes need all of them: the Adam state (used once per step,
-      // at its end) waits in global memory instead of being spilled piecemeal around the hot loops
-      volatile f32x4* ps = reinterpret_cast<volatile f32x4*>(park) + lane;
-      ps[0] = f32x4{xv0, xv1, am0, am1};
-      ps[64] = f32x4{av0, av1, xb0, xb1};
-      ps[128] = f32x4{lbest, 0.f, 0.f, 0.f};
-    }
     TK_START();
     __syncthreads();  // F-buf (and, at step 0, T-buf) landed; io visible within the wave
     TK_STOP(0);
@@ -212,7 +205,7 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     // ================= models 1..K-1: inverse, adjoint, streaming aggregation =================
 #pragma unroll 1
     for (int k = 1; k < K; ++k) {
-      constexpr bool REGTAPE = RIP_REGTAPE && WPB <= 4;
+      constexpr bool REGTAPE = RIP_REGTAPE != 0;
       // (Requesting model k + 1's forward operands under model k's adjoint — the adjoint of a register-tape inverse pass
       // never reads the F-buf — was built twice.  Rounds 3 / 4: slower, 2.81 vs 2.77 ms; round 5 found why: the compiler
       // cannot tell an LDS-DMA's destination from any other LDS location and puts s_waitcnt vmcnt(0) in front of the
@@ -301,13 +294,6 @@ __global__ __launch_bounds__(WPB * 64) void search_split_kernel(SearchArgs a, co
     const float g0 = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
     const float g1 = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
     // ---- Adam (torch.optim.Adam defaults) + bookkeeping ----
-    if (PARK) {
-      const volatile f32x4* ps = reinterpret_cast<const volatile f32x4*>(park) + lane;
-      const f32x4 s0 = ps[0], s1 = ps[64], s2 = ps[128];
-      xv0 = s0.x, xv1 = s0.y, am0 = s0.z, am1 = s0.w;
-      av0 = s1.x, av1 = s1.y, xb0 = s1.z, xb1 = s1.w;
-      lbest = s2.x;
-    }
     b1p *= 0.9;
     b2p *= 0.999;
     const float step_size = (float)((double)a.lr / (1.0 - b1p));
@@ -376,57 +362,54 @@ size_t search_split_scratch_bytes(int B, int N, int K) {
 
 namespace {
 template <int WPB>
-hipError_t launch_split_wpb(const SearchArgs& a, const uint32_t* mh_all, const float* pre, float4* tape, float4* park, int items, hipStream_t s) {
+hipError_t launch_split_wpb(const SearchArgs& a, const uint32_t* mh_all, const float* pre, float4* tape, int items, hipStream_t s) {
   hipError_t e = allow_lds(reinterpret_cast<const void*>(search_split_kernel<false, WPB>));
   if (e != hipSuccess) return e;
   e = allow_lds(reinterpret_cast<const void*>(search_split_kernel<true, WPB>));
   if (e != hipSuccess) return e;
   const dim3 grid((items + WPB - 1) / WPB);
   if (wants_trace(a))
-    hipLaunchKernelGGL((search_split_kernel<true, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape, park);
+    hipLaunchKernelGGL((search_split_kernel<true, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape);
   else
-    hipLaunchKernelGGL((search_split_kernel<false, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape, park);
+    hipLaunchKernelGGL((search_split_kernel<false, WPB>), grid, dim3(WPB * 64), sizeof(PShared<WPB>), s, a, mh_all, pre, tape);
   return hipGetLastError();
 }
 }  // namespace
 
 // waves per workgroup of a launch over `items` 16-candidate blocks.  Cost model from the measurements (B = 512, K = 4,
 // N = 128, 10 Adam steps): the 4-wave workgroup (one wave per SIMD, the whole register file, the inverse passes' tape in
-// registers) takes 0.69 ms, the 2-wave one about as long for half the blocks (5.28 vs 2.75 ms per launch), and the
-// 8-wave build — two waves per SIMD with 256 registers each: late tape loads, the Adam state parked in global memory,
-// every inverse step but the last on the global tape (3x the tape bytes) — 1.53 ms (3.06 ms per launch): 2.2x, so it
-// only wins when it saves rounds.  A launch is ceil(workgroups / CUs) rounds of that.
-// development: RIP_SPLIT_WPB=8|4|2 in the environment pins the shape (A/B on full launches, one process each).
+// registers) takes 0.63 ms, the 2-wave one about as long for half the blocks.  A launch is ceil(workgroups / CUs) rounds
+// of that.  development: RIP_SPLIT_WPB=4|2|16 in the environment pins the shape (16 = the paired shape).
 static int split_pick_wpb(int items, int forced_shape = 0) {
   static const int env_forced = [] {
     const char* e = getenv("RIP_SPLIT_WPB");
     return e != nullptr ? atoi(e) : 0;
   }();
   const int forced = forced_shape != 0 ? forced_shape : env_forced;
-  if (forced == 8 || forced == 4 || forced == 2 || forced == SPLIT_SHAPE_PAIR) return forced;
+  if (forced == 4 || forced == 2 || forced == SPLIT_SHAPE_PAIR) return forced;
   const int cus = device_cu_count();
   auto rounds = [&](int wpb) { return (double)((items + wpb * cus - 1) / (wpb * cus)); };
-  // round 6: the paired shape (flow_pair.hip) — four blocks per workgroup like the 4-wave shape, two waves per block
-  const double c8 = 2.2 * rounds(8), c4 = rounds(4), c2 = 0.96 * rounds(2), cp = RIP_PAIR_COST * rounds(4);
-  if (cp <= c8 && cp <= c4 && cp <= c2) return SPLIT_SHAPE_PAIR;
-  if (c8 <= c4 && c8 <= c2) return 8;
+  // round 6: the paired shape (flow_pair.hip) — four blocks per workgroup like the 4-wave shape, two waves per block:
+  // measured 1.27x the 4-wave shape's time (profiles/r6/pair_kernel_v1.txt), so the model never picks it
+  const double c4 = rounds(4), c2 = 0.96 * rounds(2), cp = RIP_PAIR_COST * rounds(4);
+  if (cp <= c4 && cp <= c2) return SPLIT_SHAPE_PAIR;
   return c4 <= c2 ? 4 : 2;
 }
 
 // What a launch executes on the matrix cores, per 16-candidate block (bench.py's executed-flops count; checked against
 // rocprofv3 SQ_INSTS_MFMA in profiles/): [0] waves per workgroup, then (f16, fp32) MFMA instructions of [1,2] a
-// forward / inverse pass (3 steps of 84 + 27), [3,4] the adjoint of an inverse pass, [5,6] the adjoint of F_0, [7,8]
+// forward / inverse pass (3 steps of 99 + 0; rounds 3-5: 84 + 27), [3,4] the adjoint of an inverse pass, [5,6] the adjoint of F_0, [7,8]
 // the prefix step per (model, observation).  An adjoint step is 12 (W1^T) + 72 (W_hh^T; none at t = T-1) + 18 (W_ih^T)
 // f16 and 2 (W2^T) + 4 (gi_n, only when the step comes from the tape) fp32 instructions.
 void search_split_info(int B, int N, int K, int out[9], int shape) {
   (void)K;
   const int wpb = split_pick_wpb(B * (N / CB), shape);
-  const bool regtape = RIP_REGTAPE && wpb <= 4;
+  const bool regtape = RIP_REGTAPE != 0;
   out[0] = wpb;
-  out[1] = 3 * 84, out[2] = 3 * 27;
+  out[1] = 3 * 99, out[2] = 0;  // round 6: a forward step is 99 f16 MFMAs (84 + 12 k-steps + 3 W2), no fp32 MFMA
   out[3] = 30 + 2 * 102, out[4] = regtape ? 3 * 2 : 2 + 2 * 6;
   out[5] = 30 + 2 * 102, out[6] = 3 * 6;
-  out[7] = 84, out[8] = 27;
+  out[7] = 99, out[8] = 0;
   if (wpb == SPLIT_SHAPE_PAIR) {
     // the paired shape, both waves of a block together: a forward step is 84 f16 + 2 x (8 + 1 + 5) fp32 MFMAs (the b2
     // k-step and nothing else is issued twice), an adjoint step 2 x (6 + 9 + 36) f16 (none of the 36 at t = 1) + 2 x 2
@@ -447,13 +430,10 @@ hipError_t launch_search_split(const SearchArgs& a, const uint32_t* mh_all, void
   }
   hipLaunchKernelGGL(split_prefix_kernel, dim3(a.B, a.K), dim3(64), 0, s, a, mh_all, pre);
   const int items = a.B * (a.N / CB);
-  const size_t items_pad = ((size_t)items + WPB_MAX - 1) / WPB_MAX * WPB_MAX;
-  float4* park = tape + items_pad * 2 * TAPE_SLOT_F4;
   switch (split_pick_wpb(items, a.split_shape)) {
     case SPLIT_SHAPE_PAIR: return launch_search_pair(a, mh_all, pre, tape, items, s);
-    case 8: return launch_split_wpb<8>(a, mh_all, pre, tape, park, items, s);
-    case 4: return launch_split_wpb<4>(a, mh_all, pre, tape, park, items, s);
-    default: return launch_split_wpb<2>(a, mh_all, pre, tape, park, items, s);
+    case 4: return launch_split_wpb<4>(a, mh_all, pre, tape, items, s);
+    default: return launch_split_wpb<2>(a, mh_all, pre, tape, items, s);
   }
 }
 

@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "flow.h"
 #include "flow_math.h"
 
 namespace rip {
@@ -186,20 +187,44 @@ __device__ __forceinline__ void gru_gates(const f32x4& ar, const f32x4& az, cons
   }
 }
 
+// B operand of the input / bias k-steps (round 6): the K block flow_split_pack.h's MHF_KS rows contract against.
+// y / 4 as three binary16 terms (hi, mid, lo: 33 significant bits, i.e. the fp32 value exactly; the / 4 keeps waypoints up
+// to 2.6e5 m inside binary16, the rows hold W x 4), and their exact 2^-11 / 2^-22 multiples for the weights' second /
+// third terms:  slots 0..5 = y0 (hi, mid, lo, hi 2^-11, mid 2^-11, hi 2^-22), 6..11 = y1 likewise, 12..14 = (1, 2^-11,
+// 2^-22) for the bias terms, 15 = 0; lane block q = 0 holds slots 0..7, q = 1 slots 8..15, q = 2, 3 zeros.
+__device__ __forceinline__ h16x8 ybuild(float yp0, float yp1, int q) {
+  const f32x2 ys = f32x2{yp0, yp1} * f32x2{0.25f, 0.25f};
+  const h16x2 h = __builtin_convertvector(ys, h16x2);
+  const f32x2 r1 = ys - __builtin_convertvector(h, f32x2);
+  const h16x2 m = __builtin_convertvector(r1, h16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+  const h16x2 l = __builtin_convertvector(r2, h16x2);
+  const _Float16 k1 = (_Float16)LO_INV, k2 = (_Float16)(LO_INV * LO_INV);
+  const h16x2 hs = h * h16x2{k1, k1}, ms = m * h16x2{k1, k1}, hss = h * h16x2{k2, k2};
+  const h16x8 b0 = {h[0], m[0], l[0], hs[0], ms[0], hss[0], h[1], m[1]};
+  const h16x8 b1 = {l[1], hs[1], ms[1], hss[1], (_Float16)1.0f, k1, k2, (_Float16)0.0f};
+  const u32x4 u0 = __builtin_bit_cast(u32x4, b0), u1 = __builtin_bit_cast(u32x4, b1);
+  u32x4 u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = q == 0 ? u0[i] : (q == 1 ? u1[i] : 0u);
+  return __builtin_bit_cast(h16x8, u);
+}
+
 // One GRU + head step for 16 candidates.  `wl` = this lane's column of the forward operand rows in LDS (MHF_* in
 // flow.h); H = the hidden state (H layout), `hs` = its split B operands — both are replaced by the new state's.
-// Per unit tile: 4 fp32 MFMAs (input / bias k-steps: y is unbounded, they stay exact) + 2 K blocks x 3 gates x 3 f16
-// MFMAs; head: 2 + 12 + 9.  84 f16 + 27 fp32 MFMAs = 2208 matrix-pipe cycles (flow_phase.hip: 251 x 32 = 8032).
+// Round 6: no fp32 MFMA is left in the step (a wave's time is the SUM of its matrix-pipe and vector-issue cycles, and the
+// 27 K = 4 fp32 MFMAs of rounds 3-5 — input / bias k-steps, b1, W2, b2 — were 864 of its 2208 matrix cycles for 1 % of
+// its flops).  Per unit tile: 3 k-step MFMAs (one f16 K block each: ybuild) + 2 K blocks x 3 gates x 3 f16 MFMAs, b_hn as
+// the accumulator image of gh_n's chain; head: b1 as accumulator images, 12 MFMAs, then W2 as ONE K block over the 32
+// head units (3 MFMAs on the split ReLU output, b2 as the accumulator image).  99 f16 MFMAs = 1584 matrix-pipe cycles
+// (rounds 3-5: 2208; flow_phase.hip: 251 x 32 = 8032).
 template <int SAVE, bool PIPE = false>
 __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit& hs, float yp0, float yp1, int q,
                                          unsigned lane, float4* __restrict__ tape, StepTape* tr, float (&o)[4]) {
   (void)PIPE;  // (round 3's tile pipelining: MFMAs and vector work of one wave do not overlap, removed in round 5)
-  const float bin = q == 0 ? yp0 : (q == 1 ? yp1 : (q == 2 ? 1.f : 0.f));
   unsigned loff = lane * 16u;
   asm volatile("" : "+v"(loff));  // flow_phase.hip: keeps the tape addressing scalar base + one lane offset
-  const float4 wxr = as_f4(wl[48 * 64]), wxz = as_f4(wl[49 * 64]), wxg = as_f4(wl[50 * 64]), wxh = as_f4(wl[51 * 64]);
-  const float wxra[4] = {wxr.x, wxr.y, wxr.z, wxr.w}, wxza[4] = {wxz.x, wxz.y, wxz.z, wxz.w};
-  const float wxga[4] = {wxg.x, wxg.y, wxg.z, wxg.w}, wxha[4] = {wxh.x, wxh.y, wxh.z, wxh.w};
+  const h16x8 by = ybuild(yp0, yp1, q);
   // Operand rows of group gk = up * 2 + kb (one K block of one unit tile): hi row of gate g at
   // ((g * 4 + up) * 2 + kb) * 2, lo row behind it.  A group is nine MFMAs into the tile's three accumulators, ordered
   // (hi hi) r z n, (hi lo) r z n, (lo hi) r z n so that an accumulator is touched every THIRD instruction (back-to-back
@@ -217,15 +242,18 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
     f32x4 a[3], agn;  // pre_r, pre_z, gh_n; gi_n
   };
   auto issue = [&](int up, TileAcc& t) __attribute__((always_inline)) {
+    // the tile's k-step rows (r, z, gi_n) and the b_hn image: requested first, used first
+    const uint4 kr = wl[(MHF_KS + 0 + up) * 64], kz = wl[(MHF_KS + 4 + up) * 64], kn = wl[(MHF_KS + 8 + up) * 64];
+    const float4 bh = as_f4(wl[(MHF_GHB + up) * 64]);
     SPLIT_PRIO_BURST();
-    t.a[0] = mfma4(wxra[up], bin, zero4());
-    t.a[1] = mfma4(wxza[up], bin, zero4());
-    t.agn = mfma4(wxga[up], bin, zero4());
-    t.a[2] = mfma4(wxha[up], bin, zero4());
+    t.a[0] = mfmah(as_h8(kr), by, zero4());
+    t.a[1] = mfmah(as_h8(kz), by, zero4());
+    t.agn = mfmah(as_h8(kn), by, zero4());
+    t.a[2] = f32x4{bh.x, bh.y, bh.z, bh.w};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int gk = up * 2 + kb;
-      const h16x8 bh = hs.hi[kb], bl = hs.lo[kb], bs = hs.hs[kb];
+      const h16x8 bhh = hs.hi[kb], bl = hs.lo[kb], bs = hs.hs[kb];
 #pragma unroll
       for (int g = 0; g < 3; ++g) RL[g] = wl[row_of(gk, g, 1)];
       if (gk + 1 < 8) {
@@ -234,7 +262,7 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) t.a[g] = mfmah(as_h8(RH[gk & 1][g]), bh, t.a[g]);
+      for (int g = 0; g < 3; ++g) t.a[g] = mfmah(as_h8(RH[gk & 1][g]), bhh, t.a[g]);
 #pragma unroll
       for (int g = 0; g < 3; ++g) t.a[g] = mfmah(as_h8(RH[gk & 1][g]), bl, t.a[g]);
 #pragma unroll
@@ -277,11 +305,12 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
 #pragma unroll
   for (int i = 0; i < 16; ++i) H[i] = Hn[i];
   split16(H, hs);  // the head's B operands == the next step's
-  // ---- head: rows 52..59 = W1 ((tile mt, kb) x (hi, lo)), 60..62 fp32: (b1 t0, b1 t1, W2 k0, k1), W2 k2..5, (k6, k7, b2) ----
-  const float bone = q == 2 ? 1.f : 0.f;
-  const float4 t60 = as_f4(wl[60 * 64]), t61 = as_f4(wl[61 * 64]), t62 = as_f4(wl[62 * 64]);
+  // ---- head: rows 52..59 = W1 ((tile mt, kb) x (hi, lo)); MHF_B1 / MHF_B2 accumulator images, MHF_W2 (hi, lo') ----
+  const float4 b1a = as_f4(wl[(MHF_B1 + 0) * 64]), b1b = as_f4(wl[(MHF_B1 + 1) * 64]);
+  const uint4 w2h = wl[(MHF_W2 + 0) * 64], w2l = wl[(MHF_W2 + 1) * 64];
+  const float4 b2v = as_f4(wl[MHF_B2 * 64]);
   SPLIT_PRIO_BURST();
-  f32x4 a0 = mfma4(t60.x, bone, zero4()), a1 = mfma4(t60.y, bone, zero4());
+  f32x4 a0 = {b1a.x, b1a.y, b1a.z, b1a.w}, a1 = {b1b.x, b1b.y, b1b.z, b1b.w};
   {
     // rows 52 + (mt * 2 + kb) * 2 + term; 12 MFMAs, the two tiles' accumulators alternate
 #pragma unroll
@@ -296,6 +325,7 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
       a1 = mfmah(as_h8(w1l), hs.hs[kb], a1);
     }
   }
+  SPLIT_PRIO_VALU();
   if (SAVE != SAVE_NONE) {
     unsigned m = 0;
 #pragma unroll
@@ -309,19 +339,29 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
       *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tape + TAPE_ROWS * 64) + (loff >> 2)) = m;
     }
   }
-  f32x4 oa = zero4(), ob = zero4();
-  oa = mfma4(t60.z, fmaxf(a0[0], 0.f), oa);
-  ob = mfma4(t61.z, fmaxf(a1[0], 0.f), ob);
-  oa = mfma4(t60.w, fmaxf(a0[1], 0.f), oa);
-  ob = mfma4(t61.w, fmaxf(a1[1], 0.f), ob);
-  oa = mfma4(t61.x, fmaxf(a0[2], 0.f), oa);
-  ob = mfma4(t62.x, fmaxf(a1[2], 0.f), ob);
-  oa = mfma4(t61.y, fmaxf(a0[3], 0.f), oa);
-  ob = mfma4(t62.y, fmaxf(a1[3], 0.f), ob);
-  oa = mfma4(t62.z, bone, oa);
-  SPLIT_PRIO_VALU();
+  // W2 relu(a1): the lane's 8 head units (tile 0: 4q + r, tile 1: 16 + 4q + r) ARE K slots 8q .. 8q + 7 of the W2 K block
+  // (the permutation lives in the rows); relu(a1) / 4 as two binary16 terms (a1 up to 2.6e5: |h| < 2^14 times a W1 row sum
+  // of 16), the rows hold W2 x 4
+  {
+    float av[8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = oa[r] + ob[r];
+    for (int r = 0; r < 4; ++r) {
+      av[r] = fmaxf(a0[r], 0.f);
+      av[4 + r] = fmaxf(a1[r], 0.f);
+    }
+    h16x8 ah, al;
+    split8<true>(av, 0.25f, ah, al);
+    const _Float16 k = (_Float16)LO_INV;
+    const h16x8 k8 = {k, k, k, k, k, k, k, k};
+    const h16x8 as = ah * k8;
+    SPLIT_PRIO_BURST();
+    f32x4 oa = mfmah(as_h8(w2h), ah, f32x4{b2v.x, b2v.y, b2v.z, b2v.w});
+    oa = mfmah(as_h8(w2h), al, oa);
+    oa = mfmah(as_h8(w2l), as, oa);
+    SPLIT_PRIO_VALU();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = oa[r];
+  }
 }
 
 

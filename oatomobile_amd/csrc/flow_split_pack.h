@@ -47,7 +47,8 @@ inline void split_f16_tw(float w, uint16_t* hi, uint16_t* lo) {
 // Returns the largest |w| of the split weights: the transposed rows hold w * 2^8 as binary16 (max 65504), so a model
 // with a flow weight of magnitude >= SPLIT_W_LIMIT cannot use this kernel (rip_abi.hip routes its searches to the
 // fp32-MFMA kernel; no trained or random-initialised GRU comes near it).
-inline float pack_split_operands(const float* mw, const float* wih, const float* whh, const float* w1,
+inline float pack_split_operands(const float* mw, const float* wih, const float* whh, const float* w1, const float* bih,
+                                 const float* bhh, const float* b1, const float* w2, const float* b2,
                                  std::vector<uint32_t>& out) {
   out.assign(MH_SIZE, 0u);
   float wmax = 0.f;
@@ -91,6 +92,55 @@ inline float pack_split_operands(const float* mw, const float* wih, const float*
       for (int ut = 0; ut < 4; ++ut)
         for (int i = 0; i < 8; ++i)
           put2(MHF_ROWS + MHT_WHHT + (kb * 4 + ut) * 2, lane, i, whh[(size_t)gate_row(8 * kb + i, q) * 64 + 16 * ut + m]);
+  }
+  // ---- round 6: the forward step's former fp32 MFMAs as f16 K blocks / accumulator images (flow.h MHF_KS ..) ----
+  // three binary16 terms of an fp32 value: v ~= t0 + t1 2^-11 + t2 2^-22 (33 significant bits: an fp32 value exactly)
+  auto split3 = [](float v, uint16_t t[3]) {
+    const _Float16 h = (_Float16)v;
+    const float r1 = (v - (float)h) * SPLIT_LO_SCALE;
+    const _Float16 m = (_Float16)r1;
+    const float r2 = (r1 - (float)m) * SPLIT_LO_SCALE;
+    t[0] = split_f16_bits((float)h);
+    t[1] = split_f16_bits((float)m);
+    t[2] = split_f16_bits(r2);
+  };
+  auto putf = [&](int row, int lane, int comp, float v) { std::memcpy(&out[(size_t)row * 256 + (size_t)lane * 4 + comp], &v, 4); };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, q = lane >> 4;
+    // k-steps: K slots (lane block q = 0: 0..7, q = 1: 8..15) against the B operand of fwd_step (`ybuild`):
+    //   0..5  = W[.][0] 4 (t0, t0, t0, t1, t1, t2)  x  y0 / 4 (hi, mid, lo, hi 2^-11, mid 2^-11, hi 2^-22)
+    //   6..11 = W[.][1] 4 (...)                       x  y1 / 4 (...)
+    //   12..14 = bias (t0, t1, t2)                    x  (1, 2^-11, 2^-22)
+    for (int g = 0; g < 3; ++g)
+      for (int up = 0; up < 4; ++up) {
+        const int j = 16 * up + m;
+        uint16_t k[16] = {0};
+        for (int d = 0; d < 2; ++d) {
+          uint16_t t[3];
+          split3(4.0f * wih[(g * 64 + j) * 2 + d], t);
+          const uint16_t six[6] = {t[0], t[0], t[0], t[1], t[1], t[2]};
+          for (int i = 0; i < 6; ++i) k[6 * d + i] = six[i];
+        }
+        uint16_t t[3];
+        split3(g < 2 ? bih[g * 64 + j] + bhh[g * 64 + j] : bih[g * 64 + j], t);
+        k[12] = t[0], k[13] = t[1], k[14] = t[2];
+        if (q < 2)
+          for (int i = 0; i < 8; ++i) put((size_t)(MHF_KS + g * 4 + up) * 256, lane, i, k[8 * q + i]);
+      }
+    // accumulator images: lane (c, q) register r <-> unit 16 up + 4 q + r (the C operand of a tile's first MFMA)
+    for (int up = 0; up < 4; ++up)
+      for (int r = 0; r < 4; ++r) putf(MHF_GHB + up, lane, r, bhh[128 + 16 * up + 4 * q + r]);
+    for (int mt = 0; mt < 2; ++mt)
+      for (int r = 0; r < 4; ++r) putf(MHF_B1 + mt, lane, r, b1[16 * mt + 4 * q + r]);
+    // W2 x 4 over the 32 head units as ONE K block: slot 8 q + i <-> unit (i < 4 ? 4 q + i : 16 + 4 q + i - 4), A row m = W2 row m & 3
+    for (int i = 0; i < 8; ++i) {
+      const int unit = i < 4 ? 4 * q + i : 16 + 4 * q + (i - 4);
+      uint16_t h, l;
+      split_f16(4.0f * w2[(m & 3) * 32 + unit], &h, &l);
+      put((size_t)MHF_W2 * 256, lane, i, h);
+      put((size_t)(MHF_W2 + 1) * 256, lane, i, l);
+    }
+    for (int r = 0; r < 4; ++r) putf(MHF_B2, lane, r, b2[r]);
   }
   // fp32 rows shared with the fp32 kernels' blob: forward rows 48..51 and 60..62, transposed row 0
   for (int r : {48, 49, 50, 51, 60, 61, 62}) std::memcpy(&out[(size_t)r * 256], mw + (size_t)r * 256, 1024);

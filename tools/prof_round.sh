@@ -35,6 +35,6 @@ with open(os.path.join(O, "pmc_summary.csv"), "w") as out:
 print(open(os.path.join(O, "pmc_summary.csv")).read()[:6000])
 PY
 # HBM-side bytes per launch in the form bench.py reads (copy to profiles/measured.json with the summary it condenses)
-python tools/pmc_measured.py $O/pmc_summary.csv "profiles/r5/pmc_summary_${1:-vN}.csv" > $O/measured.json
+python tools/pmc_measured.py $O/pmc_summary.csv "profiles/${ROUND:-r6}/pmc_summary_${1:-vN}.csv" $(python -c "import bench; print(bench.DEFAULT_OBS_BATCH)") > $O/measured.json
 cat $O/measured.json
 head -40 $O/bench_kernel_stats.csv
