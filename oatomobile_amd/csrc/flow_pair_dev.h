@@ -40,11 +40,7 @@ namespace split {
 #endif
 #define PAIR_PRIO_BURST() do { if (RIP_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(1); else if (RIP_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
 #define PAIR_PRIO_VALU() do { if (RIP_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (RIP_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(1); } while (0)
-#ifdef RIP_ISA_MARKS  // development: comment lines in the ISA listing (tools/dev/isa_regions.py counts instructions between them)
-#define RIP_MARK(name_) asm volatile("; RIPMARK " name_)
-#else
-#define RIP_MARK(name_)
-#endif
+
 struct PairXchg {
   volatile RIP_LDS u32x4* my_rows;          // + lane; row r at [r * 64]  (native vectors: HIP's uint4 is a struct without volatile members)
   const volatile RIP_LDS u32x4* peer_rows;

@@ -55,7 +55,13 @@ __device__ __forceinline__ void dma_rows(const uint4* __restrict__ src, uint4* d
 }
 template <int WPB>
 __device__ __forceinline__ void load_fbuf(PShared<WPB>& sh, const uint32_t* __restrict__ mhk, int wave, int lane) {
-  dma_rows<WPB>(reinterpret_cast<const uint4*>(mhk), sh.fbuf, F_ROWS, wave, lane);
+  // rows 48, 49, 51 (fp32 k-steps of r, z, gh_n) and 60..62 (fp32 b1 / W2 / b2) belong to round 5's forward step
+  // (flow_pair.hip still stages them): this kernel reads row 50 (gi_n, the F_0 adjoint's recompute) and nothing else of them
+  const uint4* src = reinterpret_cast<const uint4*>(mhk);
+  dma_rows<WPB>(src, sh.fbuf, 48, wave, lane);
+  if (wave == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + 50 * 64 + lane), (lds_ptr_t)(sh.fbuf + 50 * 64), 16, 0, 0);
+  dma_rows<WPB>(src + 52 * 64, sh.fbuf + 52 * 64, 8, wave, lane);
+  dma_rows<WPB>(src + MHF_KS * 64, sh.fbuf + MHF_KS * 64, MHF_ROWS - MHF_KS, wave, lane);
 }
 template <int WPB>
 __device__ __forceinline__ void load_tbuf(PShared<WPB>& sh, const uint32_t* __restrict__ mhk, int wave, int lane, int tid) {

@@ -120,6 +120,11 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
   inv = __builtin_ldexpf(1.0f, e - 14 - TW_SHIFT);  // (the transposed weight rows carry 2^TW_SHIFT)
 }
 
+#ifdef RIP_ISA_MARKS  // development: comment lines in the ISA listing (tools/dev/isa_regions.py counts instructions between them)
+#define RIP_MARK(name_) asm volatile("; RIPMARK " name_)
+#else
+#define RIP_MARK(name_)
+#endif
 #ifndef RIP_PRIO
 #define RIP_PRIO 1
 #endif
@@ -222,6 +227,7 @@ template <int SAVE, bool PIPE = false>
 __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit& hs, float yp0, float yp1, int q,
                                          unsigned lane, float4* __restrict__ tape, StepTape* tr, float (&o)[4]) {
   (void)PIPE;  // (round 3's tile pipelining: MFMAs and vector work of one wave do not overlap, removed in round 5)
+  RIP_MARK("fwd_begin");
   unsigned loff = lane * 16u;
   asm volatile("" : "+v"(loff));  // flow_phase.hip: keeps the tape addressing scalar base + one lane offset
   const h16x8 by = ybuild(yp0, yp1, q);
@@ -304,6 +310,7 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) H[i] = Hn[i];
+  RIP_MARK("fwd_tiles_done");
   split16(H, hs);  // the head's B operands == the next step's
   // ---- head: rows 52..59 = W1 ((tile mt, kb) x (hi, lo)); MHF_B1 / MHF_B2 accumulator images, MHF_W2 (hi, lo') ----
   const float4 b1a = as_f4(wl[(MHF_B1 + 0) * 64]), b1b = as_f4(wl[(MHF_B1 + 1) * 64]);
@@ -362,6 +369,7 @@ __device__ __forceinline__ void fwd_step(const uint4* wl, float (&H)[16], BSplit
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = oa[r];
   }
+  RIP_MARK("fwd_end");
 }
 
 
@@ -528,6 +536,7 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
                                          GSplit& gs, float& carry0, float& carry1, float (&res)[8]) {
   constexpr bool FIRST = TS == T - 1;
   constexpr bool LASTSTEP = TS == 1;
+  RIP_MARK("adj_begin");
   int zero = 0;
   asm volatile("" : "+v"(zero));  // keeps the operand reads of this step from being merged with another step's
   const uint4* tw = tw_in + zero;
@@ -757,6 +766,7 @@ __device__ __forceinline__ void adj_step(const uint4* tw_in, const uint4* wtab_i
   SPLIT_PRIO_VALU();
   carry0 = c0 + (ua[0] + (ul[0] + ub[0])) * ig;  // (three accumulators: one would make the 18 MFMAs a dependent chain)
   carry1 = c1 + (ua[1] + (ul[1] + ub[1])) * ig;
+  RIP_MARK("adj_end");
 }
 
 // adjoint pass of the current model (flow_phase.hip:pass_backward)
