@@ -301,7 +301,11 @@ int rip_train_num_layers(const rip_trainer* t);
  *         waves per SIMD; N % 16 == 0, any K <= 8, trace outputs),
  *     4 = split-f16 phase-sequential kernel: the same decomposition with the GRU / head contractions on
  *         v_mfma_f32_16x16x32_f16, both operands carried as two binary16 terms (22 significant bits, fp32
- *         accumulation; same shapes and outputs as 3).  auto picks it.  All implement rip/agent.py:78-137.
+ *         accumulation; same shapes and outputs as 3; round 6: the waypoint / bias terms as three-term operands, no fp32
+ *         MFMA in the forward step).  auto picks it.
+ *     5 = kernel 4 with the PAIRED workgroup shape forced (round 6, flow_pair.hip: a 16-candidate block on a pair of waves
+ *         that split the hidden units, two waves per SIMD; same arithmetic per product, same gates; measured 1.27x slower
+ *         than the one-wave shape, so auto never picks it).  All implement rip/agent.py:78-137.
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.
