@@ -22,7 +22,9 @@ void note_kernel(dim3 grid, dim3 block, const char* fmt, ...) __attribute__((for
 enum {
   ENC_VAR_IRB_ROUND3 = 1,    // features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit)
   ENC_VAR_FRONT_ROUND3 = 2,  // stem + features.1 on round 3's front kernel
-  ENC_VAR_IRB2_ALL = 4,      // the matrix-core depthwise kernel on features.5-7 as well
+  ENC_VAR_ROWS_F5_7 = 4,     // features.5-7 on round 1's row-streaming kernel (depthwise on the vector unit): the selection of rounds 1-5.
+                             // Round 6: with bf16-valued taps the matrix-core depthwise (irb2) is five MFMAs per tile and wins there too
+                             // (56 / 56 / 39 us against 77 / 78 / 46), so it runs features.2-7; this bit restores the old kernel
   ENC_VAR_F17_LAYERWISE = 8, // features.17 as three layer-wise launches (round 4: persistent GEMMs + row-streaming depthwise) instead of a tile block
 };
 

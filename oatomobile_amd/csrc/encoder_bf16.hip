@@ -1215,7 +1215,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
   for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-    const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_IRB2_ALL) != 0);
+    const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_ROWS_F5_7) == 0);
     const bool rows = rows2 || irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
     const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_F17_LAYERWISE) != 0);
     if (!rows && !tile) continue;

@@ -66,6 +66,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, int
   void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+#ifndef RIP_DW_TAPS_LO
+#define RIP_DW_TAPS_LO 0  // (encoder_bf16_irb2.hip: the depthwise taps are bf16 values since round 6; their low K blocks are not issued)
+#endif
+constexpr bool DW_TAPS_LO = RIP_DW_TAPS_LO != 0;
 constexpr int OOB = 0x40000000;
 constexpr unsigned ONES = 0x3F803F80u;  // two bf16 1.0
 
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, OCC) void front2_bf16_kernel(Front2Args a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             c = mfma_bf16(ad[g][j], bt[u][g][j], c);
-            c = mfma_bf16(ad[g][5 + j], bt[u][g][j], c);
+            if (DW_TAPS_LO) c = mfma_bf16(ad[g][5 + j], bt[u][g][j], c);
           }
           d[g][0] = pack_bf16(relu6(c[0]), relu6(c[1]));
           d[g][1] = pack_bf16(relu6(c[2]), relu6(c[3]));

@@ -80,6 +80,16 @@ __device__ unsigned long long g_irb2_ticks[8];
 #else
 #define IRB2_TICK(slot_) do { } while (0)
 #endif
+// Round 6: the bf16 encoder's depthwise taps are bf16 VALUES (rip_abi.hip: the blob these kernels read has them rounded;
+// oracle/bf16_encoder.py dw_weights_bf16 = True) — "activations + weights bf16, fp32 accumulate", BASELINE configs[2].  The
+// low terms of the taps are then exactly zero and their four K blocks per tile are not issued: five MFMAs per (16 pixels x
+// 16 channels) instead of nine.  The oracle says what it costs: z against the fp32 encoder moves by mean 0.026 / 0.020
+// instead of 0.026 / 0.015 (two models, six observations; max 0.17 / 0.19 instead of 0.15 / 0.18) — inside the storage
+// format's own noise.  1 = rounds 4-5's 16-bit (hi + lo) taps, for a blob that still carries them.
+#ifndef RIP_DW_TAPS_LO
+#define RIP_DW_TAPS_LO 0
+#endif
+constexpr bool DW_TAPS_LO = RIP_DW_TAPS_LO != 0;
 constexpr int OOB = 0x40000000;  // byte offset beyond any row descriptor: loads return 0, stores are dropped
 constexpr unsigned ONES = 0x3F803F80u;  // two bf16 1.0
 
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void irb2_bf16_kernel(Irb2Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           c = mfma_bf16(ad[gl][j], bt[it % BTD][j], c);
-          c = mfma_bf16(ad[gl][5 + j], bt[it % BTD][j], c);
+          if (DW_TAPS_LO) c = mfma_bf16(ad[gl][5 + j], bt[it % BTD][j], c);
         }
         __builtin_amdgcn_sched_barrier(0);
         u32x2 o;
@@ -462,11 +472,12 @@ hipError_t launch_irb2(Irb2Args a, int B, int kc, hipStream_t s) {
 
 }  // namespace
 
-// The shapes of torchvision's features.2 .. features.7 behind a 100 x 100 network input.  `shipped_only`: the blocks for
-// which this kernel is the faster one at 512 observations x 4 models (profiles/r4: features.2 287 -> 172 us, features.3
-// 230 -> 196, features.4 111 -> 92); the 13x13 / 7x7-output blocks (one pixel tile per row: 39 MFMAs of dependent chains
-// per wave and row at two waves per SIMD, 80 -> 87 us and 55 -> 70 us) stay on round 3's kernel (encoder_bf16_irb.hip)
-// unless `everywhere` (RIP_OPT_ENCODER_VARIANT bit ENC_VAR_IRB2_ALL) asks for this one there too (tests run both).
+// The shapes of torchvision's features.2 .. features.7 behind a 100 x 100 network input.  Rounds 4-5 shipped this kernel
+// for features.2-4 only (profiles/r4: 287 -> 172, 230 -> 196, 111 -> 92 us at 512 observations x 4 models) and kept the
+// 13x13 / 7x7-output blocks on round 1's row-streaming kernel (encoder_bf16_irb.hip): with nine-MFMA depthwise chains this
+// one was 87 / 70 us there against 80 / 55.  Round 6: with bf16-valued taps the chains are five MFMAs and it wins on
+// features.5-7 as well (56 / 56 / 39 us against 77 / 78 / 46): `all` is the default, RIP_OPT_ENCODER_VARIANT bit
+// ENC_VAR_ROWS_F5_7 restores round 1's kernel there (tests run both).
 bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, bool all) {
   if (le == nullptr) return false;
   const int cin = le->cin, hid = ld.cout, cout = lp.cout, s = ld.stride, hi = ld.h_in, ho = ld.h_out;
@@ -500,8 +511,12 @@ hipError_t launch_irb2_bf16(const Layer* le, const Layer& ld, const Layer& lp, c
   // to four waves per SIMD) measured slower: they spill, and every wave re-loads the block input and re-expands all
   // pixels for fewer channels (profiles/r4/irb2_variants.txt).  BTD = 1 where two operand sets do not fit.
   //                                   S CIN HID COUT H_IN H_OUT NW NG RES  OCC BTD
+  // Round 6 (bf16-valued taps: 20 instead of 36 depthwise A operand registers per group): features.3 takes the second operand
+  // set (154 -> 147 us), features.5-7 moved here from round 1's kernel; the other shapes were re-swept and stand
+  // (profiles/r6/bf16_taps_v1.txt: 6 x 1 / 2 x 3 on features.2 186 / 177 us against 137; 9 x 1 on features.3 / 4 176 / 84
+  // against 147 / 63; 6 x 2, 3 x 4, 12 x 1 on features.5-7 80 / 60 / 75 us against 56).
   if (hid == 96) return launch_irb2<2, 16, 96, 24, 50, 25, 3, 2, false, 2, 2>(a, B, kc, s);                     // features.2
-  if (hid == 144 && st == 1) return launch_irb2<1, 24, 144, 24, 25, 25, 3, 3, true, 2, 1>(a, B, kc, s);         // features.3
+  if (hid == 144 && st == 1) return launch_irb2<1, 24, 144, 24, 25, 25, 3, 3, true, 2, 2>(a, B, kc, s);         // features.3
   if (hid == 144) return launch_irb2<2, 24, 144, 32, 25, 13, 3, 3, false, 2, 1>(a, B, kc, s);                   // features.4
   if (hid == 192 && st == 1) return launch_irb2<1, 32, 192, 32, 13, 13, 4, 3, true, 2, 2>(a, B, kc, s);         // features.5, 6
   if (hid == 192 && cout == 64) return launch_irb2<2, 32, 192, 64, 13, 7, 4, 3, false, 2, 2>(a, B, kc, s);      // features.7

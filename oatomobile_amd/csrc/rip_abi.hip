@@ -30,6 +30,9 @@ struct rip_handle {
   EncoderPlan plan;
   float* enc_w = nullptr;   // [K][plan.blob_floats]
   unsigned short* enc_wh = nullptr;  // [K][plan.blob_floats] bf16 copy of the folded blob (bf16 encoder)
+  float* enc_wt = nullptr;  // [K][plan.blob_floats] the fp32 blob with the DEPTHWISE taps rounded to bf16 values (round 6): what the
+                            // bf16 encoder reads its fp32 words from — "activations + weights bf16" (BASELINE configs[2]) for every
+                            // convolution but the stem; biases and the stem's taps are the fp32 blob's
   float* flow_w = nullptr;  // [K][FW_SIZE]
   float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the fp32 MFMA search kernels
   uint32_t* split_w = nullptr;  // [K][MH_SIZE] operands of the split-f16 search kernel
@@ -230,6 +233,7 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     }                                                                             \
   } while (0)
   ALLOC(h->enc_w, (size_t)K * h->plan.blob_floats);
+  ALLOC(h->enc_wt, (size_t)K * h->plan.blob_floats);
   {
     float* tmp = nullptr;
     ALLOC(tmp, ((size_t)K * h->plan.blob_floats + 1) / 2);
@@ -292,7 +296,7 @@ int rip_destroy(rip_handle* h) {
   if (h->mega_status != nullptr) (void)hipHostFree(h->mega_status);
   if (h->mega_sync != nullptr) (void)hipFree(h->mega_sync);
   if (h->mega_arena != nullptr) (void)hipFree(h->mega_arena);
-  float* ptrs[] = {h->enc_w, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x, reinterpret_cast<float*>(h->stats)};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
@@ -363,7 +367,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
       h->encoder_mega = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_VARIANT:
-      REQUIRE(value >= 0 && value <= 15, "encoder variant mask %d not in [0,15] (1 round-3 row-streaming blocks, 2 round-3 front, 4 matrix-core depthwise on features.5-7, 8 features.17 layer-wise)", value);
+      REQUIRE(value >= 0 && value <= 15, "encoder variant mask %d not in [0,15] (1 round-3 row-streaming blocks, 2 round-3 front, 4 features.5-7 on round 1's row-streaming kernel, 8 features.17 layer-wise)", value);
       h->encoder_variant = value;
       return RIP_OK;
     case RIP_OPT_KERNEL_LOG:
@@ -410,6 +414,19 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
       wh[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
     }
     HIP_TRY(hipMemcpy(h->enc_wh + (size_t)k * h->plan.blob_floats, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+  }
+  {
+    std::vector<float> wt(enc);
+    for (const Layer& l : h->plan.layers) {
+      if (l.kind != L_DW) continue;
+      for (size_t i = 0; i < (size_t)9 * l.cout; ++i) {  // [tap][channel] at w_off: round to nearest even, keep as fp32
+        unsigned u;
+        std::memcpy(&u, &wt[l.w_off + i], 4);
+        u = ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16) << 16;
+        std::memcpy(&wt[l.w_off + i], &u, 4);
+      }
+    }
+    HIP_TRY(hipMemcpy(h->enc_wt + (size_t)k * h->plan.blob_floats, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -464,7 +481,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   TraceRange range_(enc_dtype == RIP_ENC_BF16 ? "rip_encode (bf16)" : "rip_encode (fp32)");
   KernelLogScope log_(h);
   if (enc_dtype == RIP_ENC_BF16) {
-    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
+    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_wt, h->enc_wh, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev,
                                 feat_dev, h->encoder_fused, (hipStream_t)stream, nullptr, h->encoder_variant));
     return RIP_OK;
   }
@@ -505,7 +522,7 @@ int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin,
   tap.layer = layer;
   tap.dst = dst_dev;
   if (enc_dtype == RIP_ENC_BF16)
-    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_w, h->enc_wh, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
+    HIP_TRY(launch_encoder_bf16(h->plan, h->enc_wt, h->enc_wh, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
                                 h->encoder_fused, (hipStream_t)stream, &tap, h->encoder_variant));
   else
     HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,

@@ -434,7 +434,7 @@ def test_bf16_block_kernels_everywhere(dev):
   bit 2 round 3's front kernel: the teacher-forced block test runs under each selection (the kernel log proves the
   selection took effect)."""
   from oatomobile_amd import _lib
-  for variant, must in ((_lib.ENC_VAR_IRB2_ALL, "irb2_bf16_kernel<1,32,192,32"), (_lib.ENC_VAR_IRB_ROUND3, "irb_rows_bf16_kernel<2,2,true,3"),
+  for variant, must in ((_lib.ENC_VAR_ROWS_F5_7, "irb_rows_bf16_kernel<1,2,true,4"), (_lib.ENC_VAR_IRB_ROUND3, "irb_rows_bf16_kernel<2,2,true,3"),
                         (_lib.ENC_VAR_FRONT_ROUND3, "front_bf16_kernel<2>"), (_lib.ENC_VAR_F17_LAYERWISE, "dw_")):
     for B in (3, 64):
       log = _fused_blocks_vs_oracle(dev, B, 2, 22, variant=variant)

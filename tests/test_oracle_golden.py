@@ -291,9 +291,11 @@ def test_bf16_oracle_layer_list_is_the_architecture():
     assert layers[i].residual_from == (first - 1 if b.residual else None), b
     i += 1
   assert i == 51 and layers[0].kind == "stem" and layers[0].stride == 2 and layers[51].kind == "pw"
-  # pointwise weights are bf16 values, stem / depthwise taps and all biases are not rounded
+  # pointwise weights and (round 6) depthwise taps are bf16 values, the stem's taps and all biases are not rounded
   for l in layers:
-    if l.kind == "pw":
+    if l.kind in ("pw", "dw"):
       assert torch.equal(BE.bf16_round(l.w), l.w)
   assert not torch.equal(BE.bf16_round(layers[0].w), layers[0].w)
+  unrounded = BE.folded_layers(model(21), dw_weights_bf16=False)  # rounds 4-5's definition is still selectable
+  assert any(not torch.equal(BE.bf16_round(l.w), l.w) for l in unrounded if l.kind == "dw")
   assert sum(int(l.residual_from is not None) for l in layers) == 10
