@@ -329,8 +329,9 @@ int rip_train_num_layers(const rip_trainer* t);
  *   RIP_OPT_DEBUG_ENCODER_FAULT (tests only): value 1 / 2 raises the one-launch encoder's failure word as its kernel
  *     would after a placement miss / barrier timeout (RIP_ESTATE unless RIP_OPT_ENCODER_MEGA = 1 set the protocol up).
  *   RIP_OPT_ENCODER_VARIANT (development / tests; default 0 = what ships): bit mask of alternative bf16 encoder
- *     kernels kept for A/B runs — 1: features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit),
- *     2: stem + features.1 on round 3's front kernel, 4: features.5-7 on round 1's row-streaming kernel (rounds 1-5's selection; since round 6 the matrix-core depthwise kernel runs features.2-7),
+ *     kernels kept for A/B runs — 2: stem + features.1 on round 3's front kernel,
+ *     (1 and 4 selected round 1's row-streaming kernel for features.2-7 / 5-7: retired in round 6 — the matrix-core
+ *     depthwise kernel is faster on all six blocks since the depthwise taps are bf16 values; accepted, no effect),
  *     8: features.17 as three layer-wise launches (round 4's persistent GEMMs + row-streaming depthwise) instead of a tile block.
  *     Same arithmetic definition; the teacher-forced block tests run every setting.
  *   RIP_OPT_KERNEL_LOG (tests; default 0): 1 = every rip_encode / rip_encode_raw* / rip_encode_tap* call records the

@@ -20,11 +20,10 @@ void note_kernel(dim3 grid, dim3 block, const char* fmt, ...) __attribute__((for
 
 // Development / test selections of the bf16 encoder (option RIP_OPT_ENCODER_VARIANT, a bit mask; 0 = what ships):
 enum {
-  ENC_VAR_IRB_ROUND3 = 1,    // features.2-7 on round 3's row-streaming kernel (depthwise on the vector unit)
+  ENC_VAR_IRB_ROUND3 = 1,    // RETIRED in round 6 (accepted, no effect): features.2-7 on round 1's row-streaming kernel (depthwise on the
+  ENC_VAR_ROWS_F5_7 = 4,     // vector unit) / features.5-7 on it.  With bf16-valued taps the matrix-core depthwise kernel is faster on
+                             // all six blocks (encoder_bf16_irb2.hip); encoder_bf16_irb.hip is gone
   ENC_VAR_FRONT_ROUND3 = 2,  // stem + features.1 on round 3's front kernel
-  ENC_VAR_ROWS_F5_7 = 4,     // features.5-7 on round 1's row-streaming kernel (depthwise on the vector unit): the selection of rounds 1-5.
-                             // Round 6: with bf16-valued taps the matrix-core depthwise (irb2) is five MFMAs per tile and wins there too
-                             // (56 / 56 / 39 us against 77 / 78 / 46), so it runs features.2-7; this bit restores the old kernel
   ENC_VAR_F17_LAYERWISE = 8, // features.17 as three layer-wise launches (round 4: persistent GEMMs + row-streaming depthwise) instead of a tile block
 };
 
@@ -124,17 +123,13 @@ hipError_t launch_tail(const EncoderPlan& plan, const float* enc_w, int k0, int 
 // bf16 encoder (encoder_bf16.hip): bf16 NHWC activations, bf16 pointwise weights (enc_wh: same offsets as the fp32
 // blob, 2 bytes per element), fp32 accumulation / bias / ReLU6 / residual math; features.18 is written in fp32.
 //   fused_blocks: the first `fused_blocks` inverted-residual blocks (at most the large-image stages the fused kernel
-//   supports) run as one row-streaming kernel each (encoder_bf16_irb.hip); -1 = choose by batch.
+//   supports) run as one row-streaming kernel each (encoder_bf16_irb2.hip); -1 = choose by batch.
 hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, const unsigned short* enc_wh, int k0, int kc,
                                const float* visual, const float* vec, int B, float* const bufs[4], float* z,
                                float* feat, int fused_blocks, hipStream_t s, EncoderTap* tap = nullptr, int variant = 0);
 
-bool irb_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp);
-hipError_t launch_irb_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
-                           const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
-                           const unsigned short* x, unsigned short* y, hipStream_t s);
-
-// round 4: the same blocks with the depthwise on the matrix cores as well (encoder_bf16_irb2.hip)
+// features.2-7: expand -> depthwise -> project as one row-streaming kernel, all three convolutions on the matrix cores
+// (encoder_bf16_irb2.hip, round 4; round 1's vector-unit version, encoder_bf16_irb.hip, was retired in round 6)
 bool irb2_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, bool everywhere = false);
 hipError_t launch_irb2_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                             const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
@@ -161,7 +156,7 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
 hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                               size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);
 
-// Row bands per observation for the row-streaming blocks (encoder_bf16_irb.hip, encoder_bf16_irb2.hip): `slots` resident
+// Row bands per observation for the row-streaming blocks (encoder_bf16_irb2.hip): `slots` resident
 // workgroups walk pairs * bands (model, observation, band) items; an item costs its rows plus ~2 rows of halo / prologue.
 // The band count that minimises rounds * (rows + 2) — 768 pairs on 512 slots: one band is two rounds of 27, two bands are
 // three rounds of 15 (round 5: features.2 at 192 observations x 4 models 81 us with one band per observation).  A

@@ -1211,15 +1211,15 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
   std::vector<char> tiled(plan.blocks.size(), 0);
-  const bool irb_old = (variant & ENC_VAR_IRB_ROUND3) != 0;  // A/B hook (round 3's kernel)
   for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-    const bool rows2 = !irb_old && irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_ROWS_F5_7) == 0);
-    const bool rows = rows2 || irb_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project]);
+    // features.2-7: the row-streaming kernel with the matrix-core depthwise (round 1's vector-unit kernel, which ran
+    // features.5-7 until round 5 and everything under a variant bit, is retired: encoder_bf16_irb2.hip is faster on all six)
+    const bool rows = irb2_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], true);
     const bool tile = !rows && tile_ok && irb_tile_bf16_supported(le, plan.layers[fb.dw], plan.layers[fb.project], (variant & ENC_VAR_F17_LAYERWISE) != 0);
     if (!rows && !tile) continue;
-    tiled[bi] = tile ? 1 : (rows2 ? 2 : 0);
+    tiled[bi] = tile ? 1 : 2;
     if (fb.expand >= 0) in_block[fb.expand] = 1;
     in_block[fb.dw] = 1;
     in_block[fb.project] = 2;  // the block is launched where its last layer sits
@@ -1248,7 +1248,7 @@ hipError_t launch_encoder_bf16(const EncoderPlan& plan, const float* enc_w, cons
     if (in_block[li] == 2) {
       const FusedBlock& fb = plan.blocks[block_of[li]];
       const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-      hipError_t e = (tiled[block_of[li]] == 1 ? launch_irb_tile_bf16 : (tiled[block_of[li]] == 2 ? launch_irb2_bf16 : launch_irb_bf16))(
+      hipError_t e = (tiled[block_of[li]] == 1 ? launch_irb_tile_bf16 : launch_irb2_bf16)(
           le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wh, ms, k0, kc, B,
           reinterpret_cast<const unsigned short*>(bufs[fb.src]), reinterpret_cast<unsigned short*>(bufs[fb.dst]), s);
       if (e != hipSuccess) return e;

@@ -3,7 +3,7 @@
 // the matrix cores.
 //
 // torchvision v0.6.0 `InvertedResidual` (reference call site oatomobile/torch/networks/perception.py:36-51), BN folded.
-// Round 3's kernel (encoder_bf16_irb.hip) ran the depthwise on the vector unit: per output row and wave 130 bf16 -> fp32
+// Round 3's kernel (encoder_bf16_irb.hip, retired in round 6) ran the depthwise on the vector unit: per output row and wave 130 bf16 -> fp32
 // unpacks + 72 packed FMAs + window bookkeeping against 16 MFMAs — the block was bound by the VALU stream and its
 // dependent latencies while the matrix pipe idled at 5 %.  Here the depthwise is a block-diagonal contraction:
 //     out[px][c] = sum_tap  x[px + tap][c] * w[tap][c]

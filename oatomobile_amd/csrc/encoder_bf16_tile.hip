@@ -6,7 +6,7 @@
 // (features.8 at 512 observations x 4 models: 77 MB each way per layer for 13 MB of block input); they were half of
 // the bf16 encoder's time.  Here the expanded tensor only ever exists as 64-channel slices in LDS.
 //
-// Decomposition (the row-streaming kernel of encoder_bf16_irb.hip does not fit: a 7x7 map has no rows to stream):
+// Decomposition (the row-streaming kernels of encoder_bf16_irb2.hip do not fit: a 7x7 map has no rows to stream):
 // a workgroup owns G whole observations of one model (G*H*H pixel rows) and walks the hidden dimension in chunks of
 // 64 channels.  Its 8 waves are SPECIALISED and pipelined over the chunks, one barrier per step:
 //   waves 0-3 (matrix waves), step s:  expand chunk s    -> E[s & 1]      project chunk s-2  <- D[s & 1]

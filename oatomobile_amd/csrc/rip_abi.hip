@@ -367,7 +367,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
       h->encoder_mega = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_VARIANT:
-      REQUIRE(value >= 0 && value <= 15, "encoder variant mask %d not in [0,15] (1 round-3 row-streaming blocks, 2 round-3 front, 4 features.5-7 on round 1's row-streaming kernel, 8 features.17 layer-wise)", value);
+      REQUIRE(value >= 0 && value <= 15, "encoder variant mask %d not in [0,15] (2 round-3 front, 8 features.17 layer-wise; 1 and 4 selected round 1's row-streaming kernel, retired in round 6: accepted, no effect)", value);
       h->encoder_variant = value;
       return RIP_OK;
     case RIP_OPT_KERNEL_LOG:

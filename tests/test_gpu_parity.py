@@ -429,16 +429,17 @@ def test_bf16_fused_blocks_four_channel_bev_vs_bf16_oracle(dev):
 
 
 def test_bf16_block_kernels_everywhere(dev):
-  """The matrix-core depthwise kernel ships for features.2-4 only (it is slower on the 13x13 / 7x7-output blocks);
-  RIP_OPT_ENCODER_VARIANT bit 4 runs it on features.5-7 as well, bit 1 runs round 3's row-streaming kernel everywhere,
-  bit 2 round 3's front kernel: the teacher-forced block test runs under each selection (the kernel log proves the
-  selection took effect)."""
+  """The retained A/B kernels under the teacher-forced block test (the kernel log proves the selection took effect):
+  RIP_OPT_ENCODER_VARIANT bit 2 = round 3's front kernel, bit 8 = features.17 layer-wise.  Bits 1 and 4 selected round 1's
+  row-streaming kernel until round 5; it is retired (the matrix-core depthwise kernel is faster on all of features.2-7
+  since the depthwise taps are bf16 values): the bits are accepted and change nothing."""
   from oatomobile_amd import _lib
-  for variant, must in ((_lib.ENC_VAR_ROWS_F5_7, "irb_rows_bf16_kernel<1,2,true,4"), (_lib.ENC_VAR_IRB_ROUND3, "irb_rows_bf16_kernel<2,2,true,3"),
-                        (_lib.ENC_VAR_FRONT_ROUND3, "front_bf16_kernel<2>"), (_lib.ENC_VAR_F17_LAYERWISE, "dw_")):
+  for variant, must in ((_lib.ENC_VAR_FRONT_ROUND3, "front_bf16_kernel<2>"), (_lib.ENC_VAR_F17_LAYERWISE, "dw_"),
+                        (_lib.ENC_VAR_IRB_ROUND3 | _lib.ENC_VAR_ROWS_F5_7, "irb2_bf16_kernel<1,32,192,32")):
     for B in (3, 64):
       log = _fused_blocks_vs_oracle(dev, B, 2, 22, variant=variant)
       assert any(l.startswith(must) for l in log), (variant, must, log)
+      assert not any(l.startswith("irb_rows") for l in log), log
 
 
 def _headline_kernel_names(variant):

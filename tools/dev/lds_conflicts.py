@@ -1,4 +1,4 @@
-"""LDS bank-conflict check for the row-streaming encoder block kernel (encoder_bf16_irb.hip): which pixel-slot pitch
+"""LDS bank-conflict check for the row-streaming encoder block kernel (round 1's encoder_bf16_irb.hip, retired in round 6: kept as the record of that sweep): which pixel-slot pitch
 (ELD, bf16 elements) keeps the depthwise B-operand ds_read_b128 and the expansion's ds_write_b64 conflict-free.
 Lane groups / bank rule: /opt/skills/guides/MI355X_MICROARCH.md, LDS section.  python tools/dev/lds_conflicts.py"""
 G128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
