@@ -73,6 +73,24 @@ def test_library_exports_every_declared_symbol():
   assert lib.rip_abi_version() == _lib.ABI_VERSION == 4
 
 
+def test_search_kernel_names_are_checked():
+  """`search_kernel=` of the agents goes through `_lib.search_kernel_id`: an unknown name is a `ValueError` that lists the
+  valid kernels ("mfma", removed in round 5, used to surface as a bare KeyError), and every name maps to the
+  option value include/rip_hip.h documents."""
+  from oatomobile_amd import _lib
+  assert _lib.SEARCH_KERNELS == {"auto": 0, "chain": 1, "phase": 3, "split": 4, "pair": 5}
+  for name, value in _lib.SEARCH_KERNELS.items():
+    assert _lib.search_kernel_id(name) == value
+  with pytest.raises(ValueError, match="removed") as e:
+    _lib.search_kernel_id("mfma")
+  assert all(name in str(e.value) for name in _lib.SEARCH_KERNELS)
+  with pytest.raises(ValueError, match="unknown search_kernel"):
+    _lib.search_kernel_id("Split")
+  header = open(os.path.join(ROOT, "include", "rip_hip.h")).read()
+  for value in (1, 3, 4, 5):
+    assert re.search(r"\*\s+%d = " % value, header), value
+
+
 def test_docs_quote_the_header_and_the_tests_as_they_are():
   """The documents that describe the boundary quote the number of C-ABI entry points and cite GPU tests by name: both
   are checked against include/rip_hip.h and tests/test_gpu_parity.py (doc drift was a finding of two reviews)."""
