@@ -85,6 +85,7 @@ ENC_DTYPES = {"fp32": 0, "bf16": 1}
 OPT_SEARCH_KERNEL, OPT_ENCODER_FUSED, OPT_SEARCH_REGROUP, OPT_ENCODER_MEGA, OPT_DEBUG_ENCODER_FAULT = 0, 1, 2, 3, 4
 OPT_ENCODER_VARIANT, OPT_KERNEL_LOG = 5, 6
 ENC_VAR_IRB_ROUND3, ENC_VAR_FRONT_ROUND3, ENC_VAR_ROWS_F5_7, ENC_VAR_F17_LAYERWISE = 1, 2, 4, 8
+ENC_VAR_FP32_LAYERWISE = 16  # fp32 encoder without the split-f16 tile blocks (encoder_split_tile.hip)
 SEARCH_KERNELS = {"auto": 0, "chain": 1, "phase": 3, "split": 4, "pair": 5}  # "pair": split-f16, paired workgroup shape forced
 
 

@@ -25,7 +25,16 @@ enum {
                              // all six blocks (encoder_bf16_irb2.hip); encoder_bf16_irb.hip is gone
   ENC_VAR_FRONT_ROUND3 = 2,  // stem + features.1 on round 3's front kernel
   ENC_VAR_F17_LAYERWISE = 8, // features.17 as three layer-wise launches (round 4: persistent GEMMs + row-streaming depthwise) instead of a tile block
+  ENC_VAR_FP32_LAYERWISE = 16,  // fp32 encoder: no split-f16 tile blocks (encoder_split_tile.hip), every layer outside the
+                                // fused leading blocks as its own true-fp32 launch (rounds 1-5)
 };
+
+// The fp32 encoder's split-f16 blocks read the pointwise weights as two binary16 planes of w * 2^8 (rip_abi.hip: enc_ws);
+// a model whose pointwise weights reach this magnitude keeps the layer-wise fp32 kernels (binary16 max 65504 / 2^8).
+constexpr float SPLIT_ENC_W_SCALE = 256.0f;
+constexpr float SPLIT_ENC_W_LIMIT = 240.0f;
+// (model, observation) pairs from which the split-f16 tile blocks replace the layer-wise fp32 launches
+constexpr int SPLIT_TILE_MIN_PAIRS = 32;
 
 // Workgroup barrier for kernels whose waves talk to each other through LDS only.  `__syncthreads()` is a workgroup-scope
 // release / acquire fence over ALL address spaces: the compiler puts `s_waitcnt vmcnt(0)` in front of the s_barrier, so
@@ -101,9 +110,12 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
 //   enc_w: [K_total][plan.blob_floats]; visual [B,C,100,100]; vec [B,5]; bufs[4]: each >= kc*B*max_act floats.
 //   fused_blocks: the first `fused_blocks` inverted-residual blocks run as one kernel each (encoder_fused.hip),
 //   the rest layer by layer.
+//   enc_wsh / enc_wsl: binary16 (hi, lo) planes of the blobs times 2^8, or nullptr: with them features.8-17 run as
+//   split-f16 tile blocks (encoder_split_tile.hip) when the launch has >= SPLIT_TILE_MIN_PAIRS (model, observation) pairs.
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s, EncoderTap* tap = nullptr);
+                          hipStream_t s, EncoderTap* tap = nullptr, const unsigned short* enc_wsh = nullptr,
+                          const unsigned short* enc_wsl = nullptr);
 
 // The whole fp32 encoder of a small batch as ONE persistent launch, model k on XCD k % 8 (encoder.hip:
 // encoder_mega_kernel).  arena: kc * arena_model_stride floats, arena_model_stride >= encoder_mega_arena_floats(B);
@@ -152,6 +164,12 @@ bool irb_tile_bf16_supported(const Layer* le, const Layer& ld, const Layer& lp, 
 hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                                 const unsigned short* enc_wh, size_t model_stride, int k0, int kc, int B,
                                 const unsigned short* x, unsigned short* y, hipStream_t s);
+
+// fp32-grade tile blocks of the fp32 encoder (features.8-17): fp32 activations, two-term binary16 pointwise operands
+bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp);
+hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
+                                 const unsigned short* enc_wsh, const unsigned short* enc_wsl, size_t model_stride, int k0,
+                                 int kc, int B, const float* x, float* y, hipStream_t s);
 
 hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                               size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);

@@ -1171,7 +1171,7 @@ hipError_t launch_tap_copy(const void* src, bool src_bf16, size_t n, float* dst,
 
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s, EncoderTap* tap) {
+                          hipStream_t s, EncoderTap* tap, const unsigned short* enc_wsh, const unsigned short* enc_wsl) {
   // the tap: after the launch that completes layer `li`, copy its output out and stop
   auto tapped = [&](size_t li) -> bool {
     if (tap == nullptr || tap->layer != (int)li) return false;
@@ -1183,23 +1183,34 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     return true;
   };
   const size_t ms = plan.blob_floats;
+  // per layer: 0 = its own launch, 1 = interior of a block, 2 / 3 = last layer of a block (the block is launched there):
+  // 2 = the fp32 fused block of encoder_fused.hip (the leading `fused_blocks`), 3 = a split-f16 tile block
   std::vector<char> in_block(plan.layers.size(), 0);
-  {
-    for (size_t bi = 0; bi < plan.blocks.size() && (int)bi < fused_blocks; ++bi) {
-      const FusedBlock& fb = plan.blocks[bi];
-      if (fb.expand >= 0) in_block[fb.expand] = 1;
-      in_block[fb.dw] = 1;
-      in_block[fb.project] = 2;  // the block is launched where its last layer sits
-    }
+  std::vector<int> block_of(plan.layers.size(), -1);
+  const bool split_tiles = enc_wsh != nullptr && enc_wsl != nullptr && (long)B * kc >= SPLIT_TILE_MIN_PAIRS;
+  for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
+    const FusedBlock& fb = plan.blocks[bi];
+    const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
+    int how = 0;
+    if ((int)bi < fused_blocks) how = 2;
+    else if (split_tiles && fb.src != fb.dst && irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 3;
+    if (how == 0) continue;
+    if (fb.expand >= 0) in_block[fb.expand] = 1;
+    in_block[fb.dw] = 1;
+    in_block[fb.project] = (char)how;  // the block is launched where its last layer sits
+    block_of[fb.project] = (int)bi;
   }
-  size_t next_block = 0;
   for (size_t li = 0; li < plan.layers.size(); ++li) {
     const Layer& l = plan.layers[li];
     if (in_block[li] == 1) continue;
-    if (in_block[li] == 2) {
-      const FusedBlock& fb = plan.blocks[next_block++];
-      hipError_t e = launch_fused_block(fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr, plan.layers[fb.dw],
-                                        plan.layers[fb.project], enc_w, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
+    if (in_block[li] >= 2) {
+      const FusedBlock& fb = plan.blocks[block_of[li]];
+      const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
+      hipError_t e = in_block[li] == 2
+                         ? launch_fused_block(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, ms, k0, kc, B,
+                                              bufs[fb.src], bufs[fb.dst], s)
+                         : launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wsh, enc_wsl, ms, k0,
+                                                 kc, B, bufs[fb.src], bufs[fb.dst], s);
       if (e != hipSuccess) return e;
       if (tapped(li)) return hipGetLastError();
       continue;

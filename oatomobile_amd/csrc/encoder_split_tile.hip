@@ -1,0 +1,423 @@
+// fp32-GRADE fused inverted-residual block for the small-image stages of the fp32 (parity-mode) encoder on gfx950:
+// expand 1x1 -> depthwise 3x3 -> project 1x1 (+ residual) in one kernel, fp32 activations in HBM, the two pointwise
+// convolutions on the binary16 matrix pipe with TWO-TERM operands.
+//
+// torchvision v0.6.0 `InvertedResidual` (reference call site oatomobile/torch/networks/perception.py:36-51), BN
+// folded.  Layer by layer (encoder.hip: pw_kernel / dw_kernel, true fp32 MFMA) the blocks features.8-17 are 30 launches,
+// 3.9 ms of the 9.1 ms the fp32 encoder takes for 512 observations x 4 models: the 6x expanded tensors make two round
+// trips through HBM and the fp32 matrix pipe (v_mfma_f32_16x16x4_f32) is 1/16 of the binary16 one.  Here:
+//   * the expanded tensor exists only as 64-channel slices in LDS (the structure of encoder_bf16_tile.hip: a workgroup
+//     owns G whole observations of one model and walks the hidden dimension in chunks of 64 channels);
+//   * a pointwise product is three v_mfma_f32_16x16x32_f16 (the plan search's scheme, flow_split_dev.h):
+//         W x ~= Whi xhi + Wlo xhi + Whi xlo,   fp32 accumulation, the dropped Wlo xlo term is 2^-22 relative.
+//     Weights are split on the host as w 2^8 = hi + lo (rip_abi.hip: enc_ws; |w| < 255 is checked there — a model
+//     outside keeps the layer-wise kernels): the residual of an ordinary weight is then a normal binary16 and the 2^-8
+//     is one exact multiply in the epilogue.  Activations are split in the kernel, hi = f16(x), lo = f16(x - hi): the
+//     expanded / depthwise tensors are ReLU6-bounded; the block input must stay below 65504 in magnitude (a
+//     BatchNorm-folded MobileNetV2 is orders of magnitude inside; beyond it the result is inf / NaN, not a wrong number).
+//     For |x| < 1/8 the low term is a binary16 subnormal, quantised at 2^-24: at most 2^-25 |w| per product, below the
+//     fp32 accumulation error of the sum it joins.
+//   * the depthwise stays on the vector unit in fp32 (fp32 taps, fp32 E tile in LDS); its ReLU6 output is split into the
+//     two binary16 planes the projection reads as B operands.
+// Unlike the bf16 kernel the waves are NOT specialised: with fp32 tiles LDS holds one E and one D buffer, so a step is
+// expand -> barrier -> depthwise -> barrier -> project with all eight waves in every phase (two waves per SIMD fill
+// each other's operand waits).
+// Contract: the fp32 oracle at 1e-4 on z (tests/test_gpu_parity.py, the fp32 encoder gates); NOT bit-identical to the
+// layer-wise fp32 kernels (22 significant bits per operand instead of 24, another summation order).
+#include <cstdio>
+
+#include "encoder.h"
+#include "flow.h"  // device_cu_count
+
+namespace rip {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+typedef unsigned short h16_t;
+
+__device__ __forceinline__ h16x8 as_h8(u32x4 u) { return __builtin_bit_cast(h16x8, u); }
+__device__ __forceinline__ f32x4 mfmah(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(a), as_h8(b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x2 relu6_2(f32x2 v) {
+  return __builtin_elementwise_min(__builtin_elementwise_max(v, f32x2{0.f, 0.f}), f32x2{6.f, 6.f});
+}
+// two fp32 -> (hi, lo) packed binary16 pairs, lo = f16(x - hi)
+__device__ __forceinline__ u32x2 split2(f32x2 x) {  // .x = hi pair, .y = lo pair
+  const h16x2 h = __builtin_convertvector(x, h16x2);
+  const f32x2 back = __builtin_convertvector(h, f32x2);
+  const h16x2 l = __builtin_convertvector(x - back, h16x2);
+  return u32x2{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
+}
+
+constexpr int HC = 64;        // hidden channels per chunk
+constexpr int LDE = HC + 4;   // fp32 elements per E pixel row (272 B: an odd multiple of 16 bytes)
+constexpr int LDD = HC + 8;   // binary16 elements per D pixel row (144 B)
+constexpr float W_INV = 1.0f / 256.0f;  // the split weight planes carry w * 2^8 (SPLIT_ENC_W_SCALE in encoder.h)
+
+struct SplitTileArgs {
+  const float* x;       // [K][B][HIN][HIN][CIN] fp32
+  float* y;             // [K][B][HOUT][HOUT][COUT] fp32
+  const float* wbase;   // fp32 folded blobs (biases, depthwise taps)
+  const h16_t* wsh;     // binary16 hi plane of the blobs times 2^8 (pointwise weights), same offsets
+  const h16_t* wsl;     // lo plane: f16(w 2^8 - hi)
+  size_t model_stride;
+  int k0;
+  size_t we_off, be_off, wd_off, bd_off, wp_off, bp_off;
+  int B, HID, residual, G;
+};
+
+template <int HIN, int STRIDE, int G>
+struct SplitGeom {
+  static constexpr int HOUT = STRIDE == 1 ? HIN : (HIN + 1) / 2;
+  static constexpr int HWI = HIN * HIN, HWO = HOUT * HOUT;
+  static constexpr int PW = HIN + 2;                           // padded row: zero, HIN pixels, zero
+  static constexpr int E_DUMP = G * HIN * PW;                  // row that takes the stores of lanes without a pixel
+  static constexpr int E_ROWS = E_DUMP + 1;
+  static constexpr int D_ROWS = ((G * HWO + 15) / 16) * 16;
+  static constexpr size_t E_BYTES = (size_t)E_ROWS * LDE * sizeof(float);
+  static constexpr size_t D_PLANE = (size_t)D_ROWS * LDD;      // binary16 elements per plane
+  static constexpr size_t D_BYTES = 2 * D_PLANE * sizeof(h16_t);
+  // + the block's depthwise taps [9][HID] and biases [HID] (fp32)
+  static constexpr size_t lds_bytes(int hid) { return E_BYTES + D_BYTES + (size_t)10 * hid * sizeof(float); }
+};
+
+// G: observations per workgroup at most (G * HOUT * 16 <= 512 depthwise threads: one per (observation, output column, 4 channels)).
+// WCH: the eight waves split as (8 / WCH pixel partitions) x (WCH channel partitions) in both matrix phases.
+// CTG: channel tiles per projection pass (the weights of one pass are live at a time).
+template <int HIN, int STRIDE, int CIN, int COUT, int G, int WCH, int CTG_>
+__global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
+  using Geo = SplitGeom<HIN, STRIDE, G>;
+  constexpr int HOUT = Geo::HOUT, HWI = Geo::HWI, HWO = Geo::HWO, PW = Geo::PW;
+  constexpr int WP = 8 / WCH;
+  constexpr int NPT_IN = (G * HWI + 15) / 16, NPT_OUT = (G * HWO + 15) / 16;  // 16-pixel tiles of a full group
+  constexpr int TIN = (NPT_IN + WP - 1) / WP, TOUT = (NPT_OUT + WP - 1) / WP;
+  constexpr int KSX = CIN / 32, NHT = HC / 16 / WCH, NCT = COUT / 16 / WCH, NKP = HC / 32;
+  constexpr int CTG = CTG_ > 0 ? CTG_ : NCT;
+  static_assert(CIN % 32 == 0 && (COUT / 16) % WCH == 0 && (HC / 16) % WCH == 0 && NCT % CTG == 0, "partitions");
+  static_assert(G * HOUT * 16 <= 512, "depthwise threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* const E = reinterpret_cast<float*>(smem_raw);                                 // [E_ROWS][LDE]
+  h16_t* const Dh = reinterpret_cast<h16_t*>(smem_raw + Geo::E_BYTES);                 // [D_ROWS][LDD] hi
+  h16_t* const Dl = Dh + Geo::D_PLANE;                                                 // lo
+  float* const Tl = reinterpret_cast<float*>(smem_raw + Geo::E_BYTES + Geo::D_BYTES);  // [9][HID] taps, [HID] biases
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int wpix = w / WCH, wch = w % WCH;
+  const int ht0 = wch * NHT, ct0w = wch * NCT;
+  const int k = blockIdx.z;
+  const int HID = a.HID;
+  const int nch = HID / HC;
+  const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
+  const h16_t* Wsh = a.wsh + (size_t)(a.k0 + k) * a.model_stride;
+  const h16_t* Wsl = a.wsl + (size_t)(a.k0 + k) * a.model_stride;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // prologue: zero E once (the padding columns are never written again), the block's taps and biases
+  for (int e = tid; e < Geo::E_ROWS * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E)[e] = zero4;
+  for (int e = tid; e < 9 * HID / 4; e += 512) reinterpret_cast<float4*>(Tl)[e] = *reinterpret_cast<const float4*>(W + a.wd_off + 4 * e);
+  for (int e = tid; e < HID / 4; e += 512) reinterpret_cast<float4*>(Tl + 9 * HID)[e] = *reinterpret_cast<const float4*>(W + a.bd_off + 4 * e);
+  lds_barrier();
+
+  // depthwise role of this thread: (observation, output column, 4-channel group)
+  const int cg = tid & 15, dcol = (tid >> 4) % HOUT, dimg = (tid >> 4) / HOUT;
+  const int dimg_c = dimg < G ? dimg : 0;  // (threads beyond G * HOUT * 16 never work; their addresses stay inside the buffers)
+  const int e_off = (dimg_c * HIN * PW + dcol * STRIDE) * LDE + 4 * cg;  // first of the three padded columns
+  const int d_off = (dimg_c * HWO + dcol) * LDD + 4 * cg;
+
+  // persistent over observation groups: workgroup wgx walks the groups wgx, wgx + gridDim.x, ... of its model
+  const int n_groups = (a.B + a.G - 1) / a.G;
+  const int ng = (n_groups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+  auto tile_on = [&](int t, int npt) { return !(WP * t + WP - 1 >= npt && wpix + WP * t >= npt); };  // compile-time but for the last t
+
+#pragma unroll 1
+  for (int j = 0; j < ng; ++j) {
+    const int img0 = ((int)blockIdx.x + j * (int)gridDim.x) * a.G;
+    const int n_img = min(a.G, a.B - img0);
+    const int m_in = n_img * HWI, m_out = n_img * HWO;
+    const float* xg = a.x + ((size_t)k * a.B + img0) * HWI * CIN;
+    float* yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
+    const bool dw_on = dimg < G && dimg * HWI < m_in;
+
+    // block input of this wave's pixel tiles as two-term B operands, resident for all chunks
+    u32x4 xh[TIN][KSX], xl[TIN][KSX];
+    int erow[TIN];
+    {
+      int n_ = n, q_ = q;  // (opaque copies: the per-lane offsets are group-invariant and would be hoisted and spilled)
+      asm volatile("" : "+v"(n_), "+v"(q_));
+#pragma unroll
+      for (int t = 0; t < TIN; ++t) {
+        const int px = 16 * (wpix + WP * t) + n_;
+        const bool on = px < m_in;
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+          if (on) {
+            v0 = *reinterpret_cast<const f32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q_);
+            v1 = *reinterpret_cast<const f32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q_ + 4);
+          }
+          const u32x2 s0 = split2(f32x2{v0[0], v0[1]}), s1 = split2(f32x2{v0[2], v0[3]});
+          const u32x2 s2 = split2(f32x2{v1[0], v1[1]}), s3 = split2(f32x2{v1[2], v1[3]});
+          xh[t][ks] = u32x4{s0.x, s1.x, s2.x, s3.x};
+          xl[t][ks] = u32x4{s0.y, s1.y, s2.y, s3.y};
+        }
+        const int g = px / HWI, r = px - g * HWI, iy = r / HIN, ix = r - iy * HIN;
+        erow[t] = on ? g * HIN * PW + iy * PW + ix + 1 : Geo::E_DUMP;
+      }
+    }
+    f32x4 acc[TOUT][NCT];
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+      // ---------------- expand chunk c -> E ----------------
+      {
+        u32x4 aeh[NHT][KSX], ael[NHT][KSX];
+        float4 be[NHT];
+        {
+          int n_ = n, q_ = q;
+          asm volatile("" : "+v"(n_), "+v"(q_));
+#pragma unroll
+          for (int ht = 0; ht < NHT; ++ht) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+              const size_t o = a.we_off + (size_t)(c * HC + 16 * (ht0 + ht) + n_) * CIN + 32 * ks + 8 * q_;
+              aeh[ht][ks] = *reinterpret_cast<const u32x4*>(Wsh + o);
+              ael[ht][ks] = *reinterpret_cast<const u32x4*>(Wsl + o);
+            }
+            be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q_);
+          }
+        }
+        f32x4 v[2][NHT];
+        auto mm = [&](int t, f32x4(&o)[NHT]) {
+#pragma unroll
+          for (int ht = 0; ht < NHT; ++ht) o[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) {
+              o[ht] = mfmah(ael[ht][ks], xh[t][ks], o[ht]);  // small terms first
+              o[ht] = mfmah(aeh[ht][ks], xl[t][ks], o[ht]);
+              o[ht] = mfmah(aeh[ht][ks], xh[t][ks], o[ht]);
+            }
+        };
+        auto epi = [&](int t, const f32x4(&o)[NHT]) {
+#pragma unroll
+          for (int ht = 0; ht < NHT; ++ht) {
+            const f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{o[ht][0], o[ht][1]}, f32x2{W_INV, W_INV}, f32x2{be[ht].x, be[ht].y}));
+            const f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{o[ht][2], o[ht][3]}, f32x2{W_INV, W_INV}, f32x2{be[ht].z, be[ht].w}));
+            *reinterpret_cast<f32x4*>(E + (size_t)erow[t] * LDE + 16 * (ht0 + ht) + 4 * q) = f32x4{v0.x, v0.y, v1.x, v1.y};
+          }
+        };
+        if (tile_on(0, NPT_IN)) mm(0, v[0]);
+#pragma unroll
+        for (int t = 0; t < TIN; ++t) {
+          if (t + 1 < TIN && tile_on(t + 1, NPT_IN)) mm(t + 1, v[(t + 1) & 1]);
+          if (tile_on(t, NPT_IN)) epi(t, v[t & 1]);
+        }
+      }
+      lds_barrier();
+      // ---------------- depthwise chunk c: E -> D (hi, lo) ----------------
+      if (dw_on) {
+        f32x2 wt[9][2], bd[2];
+        {
+          const float* wd = Tl + c * HC + 4 * cg;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wd + (size_t)t * HID);
+            wt[t][0] = f32x2{w0.x, w0.y};
+            wt[t][1] = f32x2{w0.z, w0.w};
+          }
+          const float4 b0 = *reinterpret_cast<const float4*>(Tl + 9 * HID + c * HC + 4 * cg);
+          bd[0] = f32x2{b0.x, b0.y};
+          bd[1] = f32x2{b0.z, b0.w};
+        }
+        f32x2 sacc[HOUT][2];
+#pragma unroll
+        for (int iy = 0; iy < HIN; ++iy) {
+          const float* r = E + e_off + iy * PW * LDE;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(r);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(r + LDE);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(r + 2 * LDE);
+          const f32x2 f[3][2] = {{f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}},
+                                 {f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}},
+                                 {f32x2{v2[0], v2[1]}, f32x2{v2[2], v2[3]}}};
+#pragma unroll
+          for (int oy = 0; oy < HOUT; ++oy) {
+            const int ky = iy - oy * STRIDE + 1;  // compile-time after unrolling
+            if (ky < 0 || ky > 2) continue;
+            if (ky == 0 || (ky == 1 && oy * STRIDE - 1 < 0)) {  // first row of this output that lies inside the map
+              sacc[oy][0] = bd[0];
+              sacc[oy][1] = bd[1];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) sacc[oy][e] = __builtin_elementwise_fma(f[kx][e], wt[ky * 3 + kx][e], sacc[oy][e]);
+            if (ky == 2 || iy == HIN - 1) {  // last row of this output inside the map: finish it
+              const u32x2 s0 = split2(relu6_2(sacc[oy][0])), s1 = split2(relu6_2(sacc[oy][1]));
+              *reinterpret_cast<u32x2*>(Dh + d_off + oy * HOUT * LDD) = u32x2{s0.x, s1.x};
+              *reinterpret_cast<u32x2*>(Dl + d_off + oy * HOUT * LDD) = u32x2{s0.y, s1.y};
+            }
+          }
+        }
+      }
+      lds_barrier();
+      // ---------------- project chunk c: D -> acc ----------------
+#pragma unroll
+      for (int cg0 = 0; cg0 < NCT; cg0 += CTG) {
+        u32x4 aph[CTG][NKP], apl[CTG][NKP];
+        {
+          int n_ = n, q_ = q;
+          asm volatile("" : "+v"(n_), "+v"(q_));
+          const size_t o = a.wp_off + (size_t)(16 * (ct0w + cg0) + n_) * HID + c * HC + 8 * q_;
+#pragma unroll
+          for (int ct = 0; ct < CTG; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < NKP; ++ks) {
+              aph[ct][ks] = *reinterpret_cast<const u32x4*>(Wsh + o + (size_t)16 * ct * HID + 32 * ks);
+              apl[ct][ks] = *reinterpret_cast<const u32x4*>(Wsl + o + (size_t)16 * ct * HID + 32 * ks);
+            }
+        }
+        u32x4 bh[2][NKP], bl[2][NKP];  // (a ragged group's missing pixels read rows of D nobody wrote: never stored)
+        auto rd = [&](int t, u32x4(&oh)[NKP], u32x4(&ol)[NKP]) {
+#pragma unroll
+          for (int ks = 0; ks < NKP; ++ks) {
+            const size_t o = (size_t)(16 * (wpix + WP * t) + n) * LDD + 32 * ks + 8 * q;
+            oh[ks] = *reinterpret_cast<const u32x4*>(Dh + o);
+            ol[ks] = *reinterpret_cast<const u32x4*>(Dl + o);
+          }
+        };
+        if (tile_on(0, NPT_OUT)) rd(0, bh[0], bl[0]);
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) {
+          if (t + 1 < TOUT && tile_on(t + 1, NPT_OUT)) rd(t + 1, bh[(t + 1) & 1], bl[(t + 1) & 1]);
+          if (!tile_on(t, NPT_OUT)) continue;
+#pragma unroll
+          for (int ks = 0; ks < NKP; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < CTG; ++ct) {
+              f32x4 s = acc[t][cg0 + ct];
+              s = mfmah(apl[ct][ks], bh[t & 1][ks], s);
+              s = mfmah(aph[ct][ks], bl[t & 1][ks], s);
+              s = mfmah(aph[ct][ks], bh[t & 1][ks], s);
+              acc[t][cg0 + ct] = s;
+            }
+        }
+      }
+      // (no barrier here: the next expansion writes E, which the depthwise is done with; the next depthwise writes D
+      // behind the barrier that follows that expansion, which every wave reaches after this projection)
+    }
+
+    // ---------------- epilogue: 2^-8, bias (+ residual = block input), fp32 out ----------------
+    {
+      int n_ = n, q_ = q;
+      asm volatile("" : "+v"(n_), "+v"(q_));
+#pragma unroll
+      for (int t = 0; t < TOUT; ++t) {
+        const int p = 16 * (wpix + WP * t) + n_;
+        if (!tile_on(t, NPT_OUT) || p >= m_out) continue;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int ch = 16 * (ct0w + ct) + 4 * q_;
+          const float4 bp = *reinterpret_cast<const float4*>(W + a.bp_off + ch);
+          f32x4 v = {fmaf(acc[t][ct][0], W_INV, bp.x), fmaf(acc[t][ct][1], W_INV, bp.y), fmaf(acc[t][ct][2], W_INV, bp.z),
+                     fmaf(acc[t][ct][3], W_INV, bp.w)};
+          if (a.residual) v += *reinterpret_cast<const f32x4*>(xg + (size_t)p * CIN + ch);
+          *reinterpret_cast<f32x4*>(yg + (size_t)p * COUT + ch) = v;
+        }
+      }
+    }
+    // (no barrier between groups either: the next group's first expansion writes E, and its first depthwise writes D
+    // behind the barrier after that expansion)
+  }
+}
+
+template <int HIN, int STRIDE, int CIN, int COUT, int GMAX, int WCH, int CTG = 0>
+hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
+  using Geo = SplitGeom<HIN, STRIDE, GMAX>;
+  static_assert(Geo::lds_bytes(6 * CIN) <= 160 * 1024, "LDS budget");
+  if (a.HID != 6 * CIN) return hipErrorInvalidValue;
+  // observations per workgroup: one workgroup per CU when the launch is large enough, never more than GMAX
+  int G = (int)(((long)a.B * kc + 255) / 256);
+  if (G > GMAX) G = GMAX;
+  if (G < 1) G = 1;
+  a.G = G;
+  static bool attr_set[64] = {};  // per device: > 64 KB of dynamic LDS needs the opt-in
+  auto kern = irb_split_tile_kernel<HIN, STRIDE, CIN, COUT, GMAX, WCH, CTG>;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Geo::lds_bytes(6 * CIN));
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const int n_groups = (a.B + G - 1) / G;
+  int gx = device_cu_count() / kc;
+  if (gx < 1) gx = 1;
+  if (gx > n_groups) gx = n_groups;
+  note_kernel(dim3(gx, 1, kc), dim3(512), "irb_split_tile_kernel<%d,%d,%d,%d,%d,%d> G=%d", HIN, STRIDE, CIN, COUT, GMAX, WCH, G);
+  hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp) {
+  if (le == nullptr) return false;
+  const int cin = le->cin, hid = ld.cout, cout = lp.cout;
+  if (hid != 6 * cin || hid % HC != 0) return false;
+  if (ld.h_in == 7 && ld.stride == 1) return (cin == 64 && (cout == 64 || cout == 96)) || (cin == 96 && cout == 96);
+  if (ld.h_in == 7 && ld.stride == 2) return cin == 96 && cout == 160;
+  if (ld.h_in == 4 && ld.stride == 1) return cin == 160 && (cout == 160 || cout == 320);
+  return false;
+}
+
+hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
+                                 const unsigned short* enc_wsh, const unsigned short* enc_wsl, size_t model_stride, int k0,
+                                 int kc, int B, const float* x, float* y, hipStream_t s) {
+  SplitTileArgs a;
+  a.x = x;
+  a.y = y;
+  a.wbase = enc_w;
+  a.wsh = enc_wsh;
+  a.wsl = enc_wsl;
+  a.model_stride = model_stride;
+  a.k0 = k0;
+  a.we_off = le->w_off;
+  a.be_off = le->b_off;
+  a.wd_off = ld.w_off;
+  a.bd_off = ld.b_off;
+  a.wp_off = lp.w_off;
+  a.bp_off = lp.b_off;
+  a.B = B;
+  a.HID = ld.cout;
+  a.residual = lp.residual;
+  a.G = 1;
+  const int cin = le->cin, cout = lp.cout;
+  //                                                HIN S CIN COUT GMAX WCH CTG
+  if (ld.h_in == 7 && ld.stride == 1) {
+    if (cin == 64 && cout == 64) return launch_split_tile<7, 1, 64, 64, 4, 2>(a, kc, s);    // features.8-10
+    if (cin == 64 && cout == 96) return launch_split_tile<7, 1, 64, 96, 4, 2>(a, kc, s);    // features.11
+    if (cin == 96 && cout == 96) return launch_split_tile<7, 1, 96, 96, 3, 2>(a, kc, s);    // features.12, 13
+  }
+  if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_split_tile<7, 2, 96, 160, 3, 2>(a, kc, s);  // 14
+  if (ld.h_in == 4 && ld.stride == 1 && cin == 160) {
+    if (cout == 160) return launch_split_tile<4, 1, 160, 160, 8, 2>(a, kc, s);              // features.15, 16
+    if (cout == 320) return launch_split_tile<4, 1, 160, 320, 4, 2, 5>(a, kc, s);           // features.17
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace rip

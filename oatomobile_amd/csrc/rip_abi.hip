@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -33,6 +34,9 @@ struct rip_handle {
   float* enc_wt = nullptr;  // [K][plan.blob_floats] the fp32 blob with the DEPTHWISE taps rounded to bf16 values (round 6): what the
                             // bf16 encoder reads its fp32 words from — "activations + weights bf16" (BASELINE configs[2]) for every
                             // convolution but the stem; biases and the stem's taps are the fp32 blob's
+  unsigned short* enc_ws = nullptr;  // [2][K][plan.blob_floats] binary16 (hi, lo) planes of the fp32 blob times 2^8: the two-term pointwise
+                                     // operands of the fp32 encoder's split-f16 tile blocks (encoder_split_tile.hip)
+  bool enc_split_ok[RIP_MAX_MODELS] = {false};  // the model's pointwise weights are inside SPLIT_ENC_W_LIMIT
   float* flow_w = nullptr;  // [K][FW_SIZE]
   float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the fp32 MFMA search kernels
   uint32_t* split_w = nullptr;  // [K][MH_SIZE] operands of the split-f16 search kernel
@@ -239,6 +243,11 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     ALLOC(tmp, ((size_t)K * h->plan.blob_floats + 1) / 2);
     h->enc_wh = reinterpret_cast<unsigned short*>(tmp);
   }
+  {
+    float* tmp = nullptr;
+    ALLOC(tmp, (size_t)K * h->plan.blob_floats);  // two 2-byte planes
+    h->enc_ws = reinterpret_cast<unsigned short*>(tmp);
+  }
   ALLOC(h->flow_w, (size_t)K * FW_SIZE);
   ALLOC(h->mfma_w, (size_t)K * MW_SIZE);
   {
@@ -296,7 +305,7 @@ int rip_destroy(rip_handle* h) {
   if (h->mega_status != nullptr) (void)hipHostFree(h->mega_status);
   if (h->mega_sync != nullptr) (void)hipFree(h->mega_sync);
   if (h->mega_arena != nullptr) (void)hipFree(h->mega_arena);
-  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), reinterpret_cast<float*>(h->enc_ws), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x, reinterpret_cast<float*>(h->stats)};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
@@ -367,7 +376,7 @@ int rip_set_option(rip_handle* h, int option, int value) {
       h->encoder_mega = value;
       return RIP_OK;
     case RIP_OPT_ENCODER_VARIANT:
-      REQUIRE(value >= 0 && value <= 15, "encoder variant mask %d not in [0,15] (2 round-3 front, 8 features.17 layer-wise; 1 and 4 selected round 1's row-streaming kernel, retired in round 6: accepted, no effect)", value);
+      REQUIRE(value >= 0 && value <= 31, "encoder variant mask %d not in [0,31] (2 round-3 front, 8 features.17 layer-wise, 16 fp32 encoder without split-f16 tile blocks; 1 and 4 selected round 1's row-streaming kernel, retired in round 6: accepted, no effect)", value);
       h->encoder_variant = value;
       return RIP_OK;
     case RIP_OPT_KERNEL_LOG:
@@ -428,6 +437,26 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
     }
     HIP_TRY(hipMemcpy(h->enc_wt + (size_t)k * h->plan.blob_floats, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  {
+    // two-term binary16 planes of w * 2^8 (encoder.h: SPLIT_ENC_W_SCALE): hi = f16(256 w), lo = f16(256 w - hi)
+    std::vector<unsigned short> hi(enc.size()), lo(enc.size());
+    for (size_t i = 0; i < enc.size(); ++i) {
+      const float v = enc[i] * SPLIT_ENC_W_SCALE;
+      const _Float16 a = (_Float16)v;
+      const _Float16 b = (_Float16)(v - (float)a);
+      std::memcpy(&hi[i], &a, 2);
+      std::memcpy(&lo[i], &b, 2);
+    }
+    bool ok = true;  // only the pointwise layers are read from these planes
+    for (const Layer& l : h->plan.layers) {
+      if (l.kind != L_PW) continue;
+      for (size_t i = 0; i < (size_t)l.cin * l.cout; ++i) ok = ok && std::fabs(enc[l.w_off + i]) < SPLIT_ENC_W_LIMIT;  // (false for NaN)
+    }
+    h->enc_split_ok[k] = ok;
+    const size_t plane = (size_t)h->K * h->plan.blob_floats;
+    HIP_TRY(hipMemcpy(h->enc_ws + (size_t)k * h->plan.blob_floats, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->enc_ws + plane + (size_t)k * h->plan.blob_floats, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->split_w + (size_t)k * MH_SIZE, mh.data(), mh.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -470,6 +499,22 @@ int rip_encoder_status(rip_handle* h) {
   return *h->mega_status;
 }
 
+// The two-term binary16 weight planes of the fp32 encoder's split-f16 tile blocks, or NULLs (layer-wise fp32 kernels):
+// every model of the launch must be inside the operand range, and RIP_OPT_ENCODER_VARIANT bit 16 turns the blocks off.
+struct SplitPlanes {
+  const unsigned short* hi = nullptr;
+  const unsigned short* lo = nullptr;
+};
+static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
+  SplitPlanes sp;
+  if (h->encoder_variant & ENC_VAR_FP32_LAYERWISE) return sp;
+  for (int k = k_begin; k < k_begin + k_count; ++k)
+    if (!h->enc_split_ok[k]) return sp;
+  sp.hi = h->enc_ws;
+  sp.lo = h->enc_ws + (size_t)h->K * h->plan.blob_floats;
+  return sp;
+}
+
 int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int B, int k_begin, int k_count,
                int enc_dtype, float* z_dev, float* feat_dev, rip_stream_t stream) {
   int rc = check_models(h, k_begin, k_count);
@@ -491,8 +536,9 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
                                 (hipStream_t)stream));
     return RIP_OK;
   }
+  const SplitPlanes sp = split_planes(h, k_begin, k_count);
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
-                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream));
+                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, nullptr, sp.hi, sp.lo));
   return RIP_OK;
 }
 
@@ -524,12 +570,14 @@ int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin,
   if (enc_dtype == RIP_ENC_BF16)
     HIP_TRY(launch_encoder_bf16(h->plan, h->enc_wt, h->enc_wh, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
                                 h->encoder_fused, (hipStream_t)stream, &tap, h->encoder_variant));
-  else
+  else {
+    const SplitPlanes sp = split_planes(h, k_begin, k_count);  // the same kernel selection as rip_encode
     HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
-                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap));
+                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap, sp.hi, sp.lo));
+  }
   if (!tap.served)
-    return fail(RIP_EINVAL, "layer %d is inside a fused block under the current RIP_OPT_ENCODER_FUSED setting: its output "
-                "never reaches memory (tap the block's last layer, or set the option to 0)", layer);
+    return fail(RIP_EINVAL, "layer %d is inside a fused block under the current RIP_OPT_ENCODER_FUSED setting / kernel selection: its output "
+                "never reaches memory (tap the block's last layer, or set the option to 0 and RIP_OPT_ENCODER_VARIANT bit 16)", layer);
   return RIP_OK;
 }
 

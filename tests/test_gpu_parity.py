@@ -182,6 +182,80 @@ def test_layerwise_encoder_matches_fused(golden, dev):
       np.testing.assert_allclose(z[i], g["z_w5_o%d" % os_], atol=TOL, err_msg="fused_blocks=%d" % nfused)
 
 
+def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
+  """Round 6: features.8-17 of the fp32 encoder as split-f16 tile blocks (encoder_split_tile.hip: fp32 activations,
+  two-term binary16 pointwise operands, fp32 accumulation) from 32 (model, observation) pairs per launch.
+  (a) 40 observations of one model against the fp32 ORACLE at the suite's 1e-4 (one observation per workgroup);
+  (b) K = 3 models x B = 601 observations (1803 pairs: 4 / 3 / 8 observations per workgroup, every block's last group
+      ragged, persistent workgroups walking two groups) against the layer-wise true-fp32 kernels of the same handle
+      (`RIP_OPT_ENCODER_VARIANT` bit 16), z and every block output that reaches memory; B - 1 observations reproduce
+      the first B - 1 rows bit for bit (observations are independent, the LDS rows of a ragged group are stale)."""
+  from oatomobile_amd import _lib, RIPAgent, arch
+  from oracle import reference_cpu as O
+  m, mo = hip_model(31, dev, max_batch=48), oracle_model(31)
+  obs = [synth_observation(np.random.default_rng(3100 + i)) for i in range(40)]
+  ctx = ctx_tensors(obs, dev)
+  m._handle().set_option(_lib.OPT_KERNEL_LOG, 1)
+  z = m._params(**ctx).cpu().numpy()
+  log = m._handle().kernel_log()
+  assert sum(l.startswith("irb_split_tile_kernel") for l in log) == 10, log
+  zo = O.params(mo, **{k: v.cpu() for k, v in ctx.items()}).numpy()
+  print("fp32 encoder with split-f16 tile blocks vs fp32 oracle (40 observations): max|dz| = %.3g of max|z| = %.3g" % (np.abs(z - zo).max(), np.abs(zo).max()))
+  np.testing.assert_allclose(z, zo, atol=TOL)
+  m._handle().set_option(_lib.OPT_ENCODER_VARIANT, _lib.ENC_VAR_FP32_LAYERWISE)
+  z_lw = m._params(**ctx).cpu().numpy()
+  assert not any(l.startswith("irb_split_tile_kernel") for l in m._handle().kernel_log())
+  print("   the layer-wise fp32 kernels on the same observations: max|dz| = %.3g" % np.abs(z_lw - zo).max())
+
+  K, B, C = 3, 601, 2
+  models = [hip_model(500 + k, dev, max_batch=1) for k in range(K)]
+  agent = RIPAgent(None, algorithm="WCM", models=models, num_candidates=16, max_batch=B, device=dev)
+  h, lib = agent._handle, _lib.load()
+  h.set_option(_lib.OPT_KERNEL_LOG, 1)
+  rng = np.random.default_rng(77)
+  vis = torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32))
+  vis = (vis * (torch.from_numpy(rng.random((B, C, 100, 100), dtype=np.float32)) < 0.3)).to(dev)
+  vec = torch.from_numpy(rng.normal(0, 2, size=(B, 5)).astype(np.float32)).to(dev)
+
+  def encode(variant, b):
+    h.set_option(_lib.OPT_ENCODER_VARIANT, variant)
+    zz = torch.full((K, b, 64), float("nan"), device=dev)
+    _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), b, 0, K, _lib.ENC_DTYPES["fp32"], _lib.ptr(zz), None, h.stream()))
+    return zz.cpu().numpy(), h.kernel_log()
+
+  z_s, log_s = encode(0, B)
+  z_l, log_l = encode(_lib.ENC_VAR_FP32_LAYERWISE, B)
+  tiles = [l for l in log_s if l.startswith("irb_split_tile_kernel")]
+  assert len(tiles) == 10 and {l.split(" ")[1] for l in tiles} == {"G=4", "G=3", "G=8"}, tiles
+  assert not any(l.startswith("irb_split_tile_kernel") for l in log_l)
+  assert np.isfinite(z_s).all()
+  d = np.abs(z_s - z_l).max()
+  print("K = 3 x B = 601, split-f16 tile blocks vs layer-wise fp32: max|dz| = %.3g of max|z| = %.3g" % (d, np.abs(z_l).max()))
+  assert d <= TOL
+  z_r, _ = encode(0, B - 1)
+  np.testing.assert_array_equal(z_r, z_s[:, :B - 1])
+  # every block output (the selection differs in features.8-17 only; the inputs of a block differ by the blocks before it)
+  layers = arch.conv_layers(C)
+  worst = 0.0
+  for i, spec in enumerate(layers[:-1]):
+    outs = []
+    for variant in (0, _lib.ENC_VAR_FP32_LAYERWISE):
+      h.set_option(_lib.OPT_ENCODER_VARIANT, variant)
+      out = torch.empty((K, B, spec.h_out, spec.h_out, spec.cout), device=dev)
+      rc = lib.rip_encode_tap_k(h.raw, _lib.ptr(vis), B, 0, K, _lib.ENC_DTYPES["fp32"], i, _lib.ptr(out), out.numel(), h.stream())
+      outs.append(None if rc == _lib.RIP_EINVAL else out)
+      if rc != _lib.RIP_EINVAL:
+        _lib.check(rc)
+    if outs[0] is None:
+      continue  # interior to a block of the shipped selection
+    assert outs[1] is not None
+    e = float((outs[0] - outs[1]).abs().max()) / max(1e-6, float(outs[1].abs().max()))
+    worst = max(worst, e)
+    assert e <= 2e-5, "layer %d: split-f16 block output differs from the layer-wise kernels by %.3g of its range" % (i, e)
+  print("   block outputs: largest difference %.3g of a tensor's range" % worst)
+  h.set_option(_lib.OPT_ENCODER_VARIANT, 0)
+
+
 def _status(handle):
   from oatomobile_amd import _lib
   return _lib.load().rip_encoder_status(handle.raw)
