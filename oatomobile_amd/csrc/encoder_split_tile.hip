@@ -56,6 +56,18 @@ __device__ __forceinline__ u32x2 split2(f32x2 x) {  // .x = hi pair, .y = lo pai
   return u32x2{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
 
+#ifdef RIP_SPLIT_TICKS  // development (tools/dev/split_ticks.sh): shader cycles per phase of wave 0, summed over the workgroups
+__device__ unsigned long long g_split_ticks[16];
+#define SPLIT_TICK(slot_)                                           \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    tk[slot_] += now_ - tlast;                                      \
+    tlast = now_;                                                   \
+  } while (0)
+#else
+#define SPLIT_TICK(slot_) do { } while (0)
+#endif
+
 constexpr int HC = 64;        // hidden channels per chunk
 constexpr int LDE = HC + 4;   // fp32 elements per E pixel row (272 B: an odd multiple of 16 bytes)
 constexpr int LDD = HC + 8;   // binary16 elements per D pixel row (144 B)
@@ -73,7 +85,10 @@ struct SplitTileArgs {
   int B, HID, residual, G;
 };
 
-template <int HIN, int STRIDE, int G>
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int HIN, int STRIDE, int CIN, int COUT, int G>
 struct SplitGeom {
   static constexpr int HOUT = STRIDE == 1 ? HIN : (HIN + 1) / 2;
   static constexpr int HWI = HIN * HIN, HWO = HOUT * HOUT;
@@ -84,29 +99,41 @@ struct SplitGeom {
   static constexpr size_t E_BYTES = (size_t)E_ROWS * LDE * sizeof(float);
   static constexpr size_t D_PLANE = (size_t)D_ROWS * LDD;      // binary16 elements per plane
   static constexpr size_t D_BYTES = 2 * D_PLANE * sizeof(h16_t);
-  // + the block's depthwise taps [9][HID] and biases [HID] (fp32)
-  static constexpr size_t lds_bytes(int hid) { return E_BYTES + D_BYTES + (size_t)10 * hid * sizeof(float); }
+  static constexpr size_t TP_BYTES = (size_t)2 * 3 * 1024;     // two buffers of a chunk's taps [9][64] + biases [64] (fp32): 160 lanes x 16 B, three DMA rows
+  static constexpr int NFE = (HC / 16) * (CIN / 32) * 2;       // 1 KB operand fragments of a chunk's expansion weights (channel tile, K block, term)
+  static constexpr int NFP = (COUT / 16) * (HC / 32) * 2;      // ... of its projection weights
+  static constexpr size_t LDS_BYTES = E_BYTES + D_BYTES + TP_BYTES + (size_t)(NFE + NFP) * 1024;
 };
 
 // G: observations per workgroup at most (G * HOUT * 16 <= 512 depthwise threads: one per (observation, output column, 4 channels)).
 // WCH: the eight waves split as (8 / WCH pixel partitions) x (WCH channel partitions) in both matrix phases.
-// CTG: channel tiles per projection pass (the weights of one pass are live at a time).
-template <int HIN, int STRIDE, int CIN, int COUT, int G, int WCH, int CTG_>
+//
+// WEIGHTS GO THROUGH LDS (round 6, second version).  The first version read a phase's A operands from global memory
+// into registers, every wave its own: 8 waves x 256 workgroups asking the same few L2 lines for 64-byte pieces — 4 k
+// requests per L2 channel and phase, 7 k + 3.3 k cycles of a 13.6 k cycle step waiting for them however early they were
+// requested (tools/dev/split_ticks.sh, profiles/r6/split_tile_v1.txt).  Now a chunk's weights are copied ONCE per
+// workgroup, as the MFMA operand fragments they will be used as (`global_load_lds`: lane (n, q) of fragment (tile, K
+// block, term) fetches its 16 bytes, they land lane-linear), while the depthwise runs:
+//   expand(c) | barrier | requests: projection weights of c, expansion weights and taps of c + 1 | depthwise(c) |
+//   wait for the own requests | barrier | project(c) | expand(c + 1) ...
+template <int HIN, int STRIDE, int CIN, int COUT, int G, int WCH>
 __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
-  using Geo = SplitGeom<HIN, STRIDE, G>;
+  using Geo = SplitGeom<HIN, STRIDE, CIN, COUT, G>;
   constexpr int HOUT = Geo::HOUT, HWI = Geo::HWI, HWO = Geo::HWO, PW = Geo::PW;
   constexpr int WP = 8 / WCH;
   constexpr int NPT_IN = (G * HWI + 15) / 16, NPT_OUT = (G * HWO + 15) / 16;  // 16-pixel tiles of a full group
   constexpr int TIN = (NPT_IN + WP - 1) / WP, TOUT = (NPT_OUT + WP - 1) / WP;
   constexpr int KSX = CIN / 32, NHT = HC / 16 / WCH, NCT = COUT / 16 / WCH, NKP = HC / 32;
-  constexpr int CTG = CTG_ > 0 ? CTG_ : NCT;
-  static_assert(CIN % 32 == 0 && (COUT / 16) % WCH == 0 && (HC / 16) % WCH == 0 && NCT % CTG == 0, "partitions");
+  constexpr int NFE = Geo::NFE, NFP = Geo::NFP;
+  static_assert(CIN % 32 == 0 && (COUT / 16) % WCH == 0 && (HC / 16) % WCH == 0, "partitions");
   static_assert(G * HOUT * 16 <= 512, "depthwise threads");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* const E = reinterpret_cast<float*>(smem_raw);                                 // [E_ROWS][LDE]
   h16_t* const Dh = reinterpret_cast<h16_t*>(smem_raw + Geo::E_BYTES);                 // [D_ROWS][LDD] hi
   h16_t* const Dl = Dh + Geo::D_PLANE;                                                 // lo
-  float* const Tl = reinterpret_cast<float*>(smem_raw + Geo::E_BYTES + Geo::D_BYTES);  // [9][HID] taps, [HID] biases
+  float* const TP = reinterpret_cast<float*>(smem_raw + Geo::E_BYTES + Geo::D_BYTES);  // [2][768]: taps [9][64] + biases [64] of a chunk
+  u32x4* const WE = reinterpret_cast<u32x4*>(smem_raw + Geo::E_BYTES + Geo::D_BYTES + Geo::TP_BYTES);  // [NFE][64]
+  u32x4* const WPj = WE + (size_t)NFE * 64;                                             // [NFP][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
@@ -120,11 +147,43 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
   const h16_t* Wsl = a.wsl + (size_t)(a.k0 + k) * a.model_stride;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  // prologue: zero E once (the padding columns are never written again), the block's taps and biases
+  // requests.  The compiler puts `s_waitcnt vmcnt(0)` in front of the first LDS read that follows a `global_load_lds` in
+  // program order (it cannot tell the copy's destination from the rows that read addresses), so a wave that went on to
+  // the depthwise would wait for its copies right there.  The copies are therefore issued by the waves that have NO
+  // depthwise work (DWW .. 7: the depthwise occupies G * HOUT * 16 threads), which then wait for them and join the
+  // barrier.  Wave w issues the fragments w - DWW, + (8 - DWW), ...; fragment id = (tile * K blocks + K block) * 2 + term.
+  constexpr int DWW = (G * HOUT * 16 + 63) / 64, NDW = 8 - DWW;
+  static_assert(NDW >= 1, "a wave without depthwise work issues the weight copies");
+  auto dma_we = [&](int c, int w0, int nw) {
+    for (int id = w0; id < NFE; id += nw) {
+      const int term = id & 1, ks = (id >> 1) % KSX, ht = (id >> 1) / KSX;
+      const h16_t* src = (term ? Wsl : Wsh) + a.we_off + (size_t)(c * HC + 16 * ht + n) * CIN + 32 * ks + 8 * q;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(WE + (size_t)id * 64), 16, 0, 0);
+    }
+  };
+  auto dma_wp = [&](int c, int w0, int nw) {
+    for (int id = w0; id < NFP; id += nw) {
+      const int term = id & 1, ks = (id >> 1) % NKP, ct = (id >> 1) / NKP;
+      const h16_t* src = (term ? Wsl : Wsh) + a.wp_off + (size_t)(16 * ct + n) * HID + c * HC + 32 * ks + 8 * q;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(WPj + (size_t)id * 64), 16, 0, 0);
+    }
+  };
+  auto dma_tp = [&](int c) {  // 160 lanes x 16 B: lane L fetches tap row L / 16 (9 = the biases), channels 4 (L % 16) ..; three copies
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int L = 64 * r + lane, t = L >> 4, i = L & 15;
+      const float* src = (t < 9 ? W + a.wd_off + (size_t)t * HID : W + a.bd_off) + c * HC + 4 * i;
+      if (L < 160) __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(TP + (size_t)(c & 1) * 768 + 256 * r), 16, 0, 0);
+    }
+  };
+
+#ifdef RIP_SPLIT_TICKS
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+  // prologue: zero E once (the padding columns are never written again)
   for (int e = tid; e < Geo::E_ROWS * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E)[e] = zero4;
-  for (int e = tid; e < 9 * HID / 4; e += 512) reinterpret_cast<float4*>(Tl)[e] = *reinterpret_cast<const float4*>(W + a.wd_off + 4 * e);
-  for (int e = tid; e < HID / 4; e += 512) reinterpret_cast<float4*>(Tl + 9 * HID)[e] = *reinterpret_cast<const float4*>(W + a.bd_off + 4 * e);
-  lds_barrier();
+  SPLIT_TICK(0);
 
   // depthwise role of this thread: (observation, output column, 4-channel group)
   const int cg = tid & 15, dcol = (tid >> 4) % HOUT, dimg = (tid >> 4) / HOUT;
@@ -146,6 +205,10 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
     float* yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
     const bool dw_on = dimg < G && dimg * HWI < m_in;
 
+    // the first chunk's expansion weights and taps (every wave is past the previous group's last expansion / depthwise:
+    // they sit in front of that group's last two barriers)
+    dma_we(0, w, 8);
+    if (w == 7) dma_tp(0);
     // block input of this wave's pixel tiles as two-term B operands, resident for all chunks
     u32x4 xh[TIN][KSX], xl[TIN][KSX];
     int erow[TIN];
@@ -177,68 +240,73 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
     for (int t = 0; t < TOUT; ++t)
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's requests have landed
+    lds_barrier();                       // ... and everybody's (also: the E zeroing of the prologue)
+    SPLIT_TICK(1);
 
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
       // ---------------- expand chunk c -> E ----------------
       {
-        u32x4 aeh[NHT][KSX], ael[NHT][KSX];
         float4 be[NHT];
-        {
-          int n_ = n, q_ = q;
-          asm volatile("" : "+v"(n_), "+v"(q_));
 #pragma unroll
-          for (int ht = 0; ht < NHT; ++ht) {
-#pragma unroll
-            for (int ks = 0; ks < KSX; ++ks) {
-              const size_t o = a.we_off + (size_t)(c * HC + 16 * (ht0 + ht) + n_) * CIN + 32 * ks + 8 * q_;
-              aeh[ht][ks] = *reinterpret_cast<const u32x4*>(Wsh + o);
-              ael[ht][ks] = *reinterpret_cast<const u32x4*>(Wsl + o);
-            }
-            be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q_);
-          }
+        for (int ht = 0; ht < NHT; ++ht) {  // the bias of this lane's four channels: the taps' biases are the depthwise's; this one from global (L1 / L2)
+          int q_ = q;
+          asm volatile("" : "+v"(q_));
+          be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q_);
         }
-        f32x4 v[2][NHT];
-        auto mm = [&](int t, f32x4(&o)[NHT]) {
 #pragma unroll
-          for (int ht = 0; ht < NHT; ++ht) o[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ht = 0; ht < NHT; ++ht) {
+          f32x4 v[TIN];
 #pragma unroll
-          for (int ks = 0; ks < KSX; ++ks)
+          for (int t = 0; t < TIN; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ht = 0; ht < NHT; ++ht) {
-              o[ht] = mfmah(ael[ht][ks], xh[t][ks], o[ht]);  // small terms first
-              o[ht] = mfmah(aeh[ht][ks], xl[t][ks], o[ht]);
-              o[ht] = mfmah(aeh[ht][ks], xh[t][ks], o[ht]);
-            }
-        };
-        auto epi = [&](int t, const f32x4(&o)[NHT]) {
+          for (int ks = 0; ks < KSX; ++ks) {
+            const u32x4 ah = WE[(size_t)(((ht0 + ht) * KSX + ks) * 2) * 64 + lane];
+            const u32x4 al = WE[(size_t)(((ht0 + ht) * KSX + ks) * 2 + 1) * 64 + lane];
 #pragma unroll
-          for (int ht = 0; ht < NHT; ++ht) {
-            const f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{o[ht][0], o[ht][1]}, f32x2{W_INV, W_INV}, f32x2{be[ht].x, be[ht].y}));
-            const f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{o[ht][2], o[ht][3]}, f32x2{W_INV, W_INV}, f32x2{be[ht].z, be[ht].w}));
+            for (int t = 0; t < TIN; ++t)
+              if (tile_on(t, NPT_IN)) v[t] = mfmah(al, xh[t][ks], v[t]);  // small terms first
+#pragma unroll
+            for (int t = 0; t < TIN; ++t)
+              if (tile_on(t, NPT_IN)) v[t] = mfmah(ah, xl[t][ks], v[t]);
+#pragma unroll
+            for (int t = 0; t < TIN; ++t)
+              if (tile_on(t, NPT_IN)) v[t] = mfmah(ah, xh[t][ks], v[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < TIN; ++t) {
+            if (!tile_on(t, NPT_IN)) continue;
+            const f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{v[t][0], v[t][1]}, f32x2{W_INV, W_INV}, f32x2{be[ht].x, be[ht].y}));
+            const f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{v[t][2], v[t][3]}, f32x2{W_INV, W_INV}, f32x2{be[ht].z, be[ht].w}));
             *reinterpret_cast<f32x4*>(E + (size_t)erow[t] * LDE + 16 * (ht0 + ht) + 4 * q) = f32x4{v0.x, v0.y, v1.x, v1.y};
           }
-        };
-        if (tile_on(0, NPT_IN)) mm(0, v[0]);
-#pragma unroll
-        for (int t = 0; t < TIN; ++t) {
-          if (t + 1 < TIN && tile_on(t + 1, NPT_IN)) mm(t + 1, v[(t + 1) & 1]);
-          if (tile_on(t, NPT_IN)) epi(t, v[t & 1]);
         }
       }
+      SPLIT_TICK(2);
       lds_barrier();
+      SPLIT_TICK(3);
+      // requests that land under the depthwise: this chunk's projection weights (every wave is past project(c - 1)), the
+      // next chunk's expansion weights (every wave is past expand(c)) and taps (the other buffer)
+      if (w >= DWW) {
+        dma_wp(c, w - DWW, NDW);
+        if (c + 1 < nch) {
+          dma_we(c + 1, w - DWW, NDW);
+          if (w == 7) dma_tp(c + 1);
+        }
+      }
       // ---------------- depthwise chunk c: E -> D (hi, lo) ----------------
       if (dw_on) {
         f32x2 wt[9][2], bd[2];
         {
-          const float* wd = Tl + c * HC + 4 * cg;
+          const float* wd = TP + (size_t)(c & 1) * 768 + 4 * cg;
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
-            const float4 w0 = *reinterpret_cast<const float4*>(wd + (size_t)t * HID);
+            const float4 w0 = *reinterpret_cast<const float4*>(wd + t * 64);
             wt[t][0] = f32x2{w0.x, w0.y};
             wt[t][1] = f32x2{w0.z, w0.w};
           }
-          const float4 b0 = *reinterpret_cast<const float4*>(Tl + 9 * HID + c * HC + 4 * cg);
+          const float4 b0 = *reinterpret_cast<const float4*>(wd + 9 * 64);
           bd[0] = f32x2{b0.x, b0.y};
           bd[1] = f32x2{b0.z, b0.w};
         }
@@ -272,81 +340,111 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
           }
         }
       }
+      SPLIT_TICK(4);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's weight / tap requests have landed
       lds_barrier();
+      SPLIT_TICK(5);
       // ---------------- project chunk c: D -> acc ----------------
+      {
+        u32x4 bh[TOUT][NKP], bl[TOUT][NKP];  // (a ragged group's missing pixels read rows of D nobody wrote: never stored)
 #pragma unroll
-      for (int cg0 = 0; cg0 < NCT; cg0 += CTG) {
-        u32x4 aph[CTG][NKP], apl[CTG][NKP];
-        {
-          int n_ = n, q_ = q;
-          asm volatile("" : "+v"(n_), "+v"(q_));
-          const size_t o = a.wp_off + (size_t)(16 * (ct0w + cg0) + n_) * HID + c * HC + 8 * q_;
-#pragma unroll
-          for (int ct = 0; ct < CTG; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < NKP; ++ks) {
-              aph[ct][ks] = *reinterpret_cast<const u32x4*>(Wsh + o + (size_t)16 * ct * HID + 32 * ks);
-              apl[ct][ks] = *reinterpret_cast<const u32x4*>(Wsl + o + (size_t)16 * ct * HID + 32 * ks);
-            }
-        }
-        u32x4 bh[2][NKP], bl[2][NKP];  // (a ragged group's missing pixels read rows of D nobody wrote: never stored)
-        auto rd = [&](int t, u32x4(&oh)[NKP], u32x4(&ol)[NKP]) {
+        for (int t = 0; t < TOUT; ++t) {
+          if (!tile_on(t, NPT_OUT)) continue;
 #pragma unroll
           for (int ks = 0; ks < NKP; ++ks) {
             const size_t o = (size_t)(16 * (wpix + WP * t) + n) * LDD + 32 * ks + 8 * q;
-            oh[ks] = *reinterpret_cast<const u32x4*>(Dh + o);
-            ol[ks] = *reinterpret_cast<const u32x4*>(Dl + o);
+            bh[t][ks] = *reinterpret_cast<const u32x4*>(Dh + o);
+            bl[t][ks] = *reinterpret_cast<const u32x4*>(Dl + o);
           }
-        };
-        if (tile_on(0, NPT_OUT)) rd(0, bh[0], bl[0]);
-#pragma unroll
-        for (int t = 0; t < TOUT; ++t) {
-          if (t + 1 < TOUT && tile_on(t + 1, NPT_OUT)) rd(t + 1, bh[(t + 1) & 1], bl[(t + 1) & 1]);
-          if (!tile_on(t, NPT_OUT)) continue;
-#pragma unroll
-          for (int ks = 0; ks < NKP; ++ks)
-#pragma unroll
-            for (int ct = 0; ct < CTG; ++ct) {
-              f32x4 s = acc[t][cg0 + ct];
-              s = mfmah(apl[ct][ks], bh[t & 1][ks], s);
-              s = mfmah(aph[ct][ks], bl[t & 1][ks], s);
-              s = mfmah(aph[ct][ks], bh[t & 1][ks], s);
-              acc[t][cg0 + ct] = s;
-            }
         }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int ks = 0; ks < NKP; ++ks) {
+            const u32x4 ah = WPj[(size_t)(((ct0w + ct) * NKP + ks) * 2) * 64 + lane];
+            const u32x4 al = WPj[(size_t)(((ct0w + ct) * NKP + ks) * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < TOUT; ++t)
+              if (tile_on(t, NPT_OUT)) acc[t][ct] = mfmah(al, bh[t][ks], acc[t][ct]);
+#pragma unroll
+            for (int t = 0; t < TOUT; ++t)
+              if (tile_on(t, NPT_OUT)) acc[t][ct] = mfmah(ah, bl[t][ks], acc[t][ct]);
+#pragma unroll
+            for (int t = 0; t < TOUT; ++t)
+              if (tile_on(t, NPT_OUT)) acc[t][ct] = mfmah(ah, bh[t][ks], acc[t][ct]);
+          }
       }
-      // (no barrier here: the next expansion writes E, which the depthwise is done with; the next depthwise writes D
-      // behind the barrier that follows that expansion, which every wave reaches after this projection)
+      SPLIT_TICK(6);
+      // (no barrier here: the next expansion writes E, which the depthwise is done with, and reads WE, published by the
+      // barrier above; the next requests / depthwise sit behind the barrier that follows that expansion)
     }
 
     // ---------------- epilogue: 2^-8, bias (+ residual = block input), fp32 out ----------------
     {
       int n_ = n, q_ = q;
       asm volatile("" : "+v"(n_), "+v"(q_));
+      // (all operand requests first: one memory latency for the epilogue, not one per pixel tile)
+      float4 bp[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) bp[ct] = *reinterpret_cast<const float4*>(W + a.bp_off + 16 * (ct0w + ct) + 4 * q_);
+      if (a.residual) {
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) {
+          const int p = 16 * (wpix + WP * t) + n_;
+          if (!tile_on(t, NPT_OUT) || p >= m_out) continue;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(xg + (size_t)p * CIN + 16 * (ct0w + ct) + 4 * q_);
+            acc[t][ct] = __builtin_elementwise_fma(r, f32x4{256.f, 256.f, 256.f, 256.f}, acc[t][ct]);  // (the accumulators carry 2^8; exact)
+          }
+        }
+      }
 #pragma unroll
       for (int t = 0; t < TOUT; ++t) {
         const int p = 16 * (wpix + WP * t) + n_;
         if (!tile_on(t, NPT_OUT) || p >= m_out) continue;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-          const int ch = 16 * (ct0w + ct) + 4 * q_;
-          const float4 bp = *reinterpret_cast<const float4*>(W + a.bp_off + ch);
-          f32x4 v = {fmaf(acc[t][ct][0], W_INV, bp.x), fmaf(acc[t][ct][1], W_INV, bp.y), fmaf(acc[t][ct][2], W_INV, bp.z),
-                     fmaf(acc[t][ct][3], W_INV, bp.w)};
-          if (a.residual) v += *reinterpret_cast<const f32x4*>(xg + (size_t)p * CIN + ch);
-          *reinterpret_cast<f32x4*>(yg + (size_t)p * COUT + ch) = v;
+          const f32x4 v = {fmaf(acc[t][ct][0], W_INV, bp[ct].x), fmaf(acc[t][ct][1], W_INV, bp[ct].y),
+                           fmaf(acc[t][ct][2], W_INV, bp[ct].z), fmaf(acc[t][ct][3], W_INV, bp[ct].w)};
+          *reinterpret_cast<f32x4*>(yg + (size_t)p * COUT + 16 * (ct0w + ct) + 4 * q_) = v;
         }
       }
     }
-    // (no barrier between groups either: the next group's first expansion writes E, and its first depthwise writes D
-    // behind the barrier after that expansion)
+    SPLIT_TICK(7);
   }
+#ifdef RIP_SPLIT_TICKS
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_split_ticks[i], tk[i]);
+    atomicAdd(&g_split_ticks[8], 1ull);
+    atomicAdd(&g_split_ticks[9], (unsigned long long)ng);
+  }
+#endif
 }
 
-template <int HIN, int STRIDE, int CIN, int COUT, int GMAX, int WCH, int CTG = 0>
+// development sweeps (tools/dev/split_sweep.sh rebuilds with -D...)
+#ifndef RIP_ST_G64
+#define RIP_ST_G64 3
+#endif
+#ifndef RIP_ST_G96
+#define RIP_ST_G96 3
+#endif
+#ifndef RIP_ST_G160
+#define RIP_ST_G160 4
+#endif
+#ifndef RIP_ST_G320
+#define RIP_ST_G320 2
+#endif
+#ifndef RIP_ST_W17
+#define RIP_ST_W17 4
+#endif
+constexpr int ST_G64 = RIP_ST_G64, ST_G96 = RIP_ST_G96, ST_G160 = RIP_ST_G160, ST_G320 = RIP_ST_G320, ST_W17 = RIP_ST_W17;
+
+template <int HIN, int STRIDE, int CIN, int COUT, int GMAX, int WCH>
 hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
-  using Geo = SplitGeom<HIN, STRIDE, GMAX>;
-  static_assert(Geo::lds_bytes(6 * CIN) <= 160 * 1024, "LDS budget");
+  using Geo = SplitGeom<HIN, STRIDE, CIN, COUT, GMAX>;
+  static_assert(Geo::LDS_BYTES <= 160 * 1024, "LDS budget");
   if (a.HID != 6 * CIN) return hipErrorInvalidValue;
   // observations per workgroup: one workgroup per CU when the launch is large enough, never more than GMAX
   int G = (int)(((long)a.B * kc + 255) / 256);
@@ -354,12 +452,12 @@ hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
   if (G < 1) G = 1;
   a.G = G;
   static bool attr_set[64] = {};  // per device: > 64 KB of dynamic LDS needs the opt-in
-  auto kern = irb_split_tile_kernel<HIN, STRIDE, CIN, COUT, GMAX, WCH, CTG>;
+  auto kern = irb_split_tile_kernel<HIN, STRIDE, CIN, COUT, GMAX, WCH>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)Geo::lds_bytes(6 * CIN));
+                                       (int)Geo::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
@@ -368,7 +466,21 @@ hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx > n_groups) gx = n_groups;
   note_kernel(dim3(gx, 1, kc), dim3(512), "irb_split_tile_kernel<%d,%d,%d,%d,%d,%d> G=%d", HIN, STRIDE, CIN, COUT, GMAX, WCH, G);
-  hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::lds_bytes(a.HID), s, a);
+  hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::LDS_BYTES, s, a);
+#ifdef RIP_SPLIT_TICKS
+  {
+    unsigned long long t[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_split_ticks), sizeof(t));
+    const double n = t[8] > 0 ? (double)t[8] : 1.0, st = (double)(a.HID / HC) * (double)t[9] / n;
+    fprintf(stderr, "split tile<%d,%d,%d,%d,G%d,%d> cycles per workgroup (%.1f groups): prologue %.0f | per group: setup %.0f epilogue %.0f | per step (%d): "
+            "expand %.0f barrier %.0f depthwise %.0f barrier %.0f project %.0f\n",
+            HIN, STRIDE, CIN, COUT, G, WCH, t[9] / n, t[0] / n, t[1] / (double)t[9], t[7] / (double)t[9], a.HID / HC, t[2] / n / st, t[3] / n / st,
+            t[4] / n / st, t[5] / n / st, t[6] / n / st);
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_ticks), z, sizeof(z));
+  }
+#endif
   return hipGetLastError();
 }
 
@@ -406,16 +518,16 @@ hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& 
   a.residual = lp.residual;
   a.G = 1;
   const int cin = le->cin, cout = lp.cout;
-  //                                                HIN S CIN COUT GMAX WCH CTG
+  //                                                HIN S CIN COUT GMAX WCH
   if (ld.h_in == 7 && ld.stride == 1) {
-    if (cin == 64 && cout == 64) return launch_split_tile<7, 1, 64, 64, 4, 2>(a, kc, s);    // features.8-10
-    if (cin == 64 && cout == 96) return launch_split_tile<7, 1, 64, 96, 4, 2>(a, kc, s);    // features.11
-    if (cin == 96 && cout == 96) return launch_split_tile<7, 1, 96, 96, 3, 2>(a, kc, s);    // features.12, 13
+    if (cin == 64 && cout == 64) return launch_split_tile<7, 1, 64, 64, ST_G64, 2>(a, kc, s);    // features.8-10
+    if (cin == 64 && cout == 96) return launch_split_tile<7, 1, 64, 96, ST_G64, 2>(a, kc, s);    // features.11
+    if (cin == 96 && cout == 96) return launch_split_tile<7, 1, 96, 96, ST_G96, 2>(a, kc, s);    // features.12, 13
   }
-  if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_split_tile<7, 2, 96, 160, 3, 2>(a, kc, s);  // 14
+  if (ld.h_in == 7 && ld.stride == 2 && cin == 96 && cout == 160) return launch_split_tile<7, 2, 96, 160, ST_G96, 2>(a, kc, s);  // 14
   if (ld.h_in == 4 && ld.stride == 1 && cin == 160) {
-    if (cout == 160) return launch_split_tile<4, 1, 160, 160, 8, 2>(a, kc, s);              // features.15, 16
-    if (cout == 320) return launch_split_tile<4, 1, 160, 320, 4, 2, 5>(a, kc, s);           // features.17
+    if (cout == 160) return launch_split_tile<4, 1, 160, 160, ST_G160, 2>(a, kc, s);            // features.15, 16
+    if (cout == 320) return launch_split_tile<4, 1, 160, 320, ST_G320, ST_W17>(a, kc, s);       // features.17
   }
   return hipErrorInvalidValue;
 }
