@@ -112,10 +112,12 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
 //   the rest layer by layer.
 //   enc_wsh / enc_wsl: binary16 (hi, lo) planes of the blobs times 2^8, or nullptr: with them features.8-17 run as
 //   split-f16 tile blocks (encoder_split_tile.hip) when the launch has >= SPLIT_TILE_MIN_PAIRS (model, observation) pairs.
+//   enc_wr: operand fragments of the split-f16 row-streaming blocks (features.2-7, encoder_split_rows.hip;
+//   `pack_split_rows`, models wr_stride halves apart), or nullptr.
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
                           hipStream_t s, EncoderTap* tap = nullptr, const unsigned short* enc_wsh = nullptr,
-                          const unsigned short* enc_wsl = nullptr);
+                          const unsigned short* enc_wsl = nullptr, const unsigned short* enc_wr = nullptr, size_t wr_stride = 0);
 
 // The whole fp32 encoder of a small batch as ONE persistent launch, model k on XCD k % 8 (encoder.hip:
 // encoder_mega_kernel).  arena: kc * arena_model_stride floats, arena_model_stride >= encoder_mega_arena_floats(B);
@@ -170,6 +172,18 @@ bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp)
 hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                                  const unsigned short* enc_wsh, const unsigned short* enc_wsl, size_t model_stride, int k0,
                                  int kc, int B, const float* x, float* y, hipStream_t s);
+
+// fp32-grade row-streaming blocks of the fp32 encoder (features.2-7): encoder_split_rows.hip
+struct SplitRowsLayout {
+  std::vector<size_t> off;  // per plan block: offset (binary16 elements) of its operand fragments in a model's blob; (size_t)-1 = not a row-streaming block
+  size_t total = 0;         // binary16 elements per model
+};
+SplitRowsLayout split_rows_layout(const EncoderPlan& plan);
+void pack_split_rows(const EncoderPlan& plan, const SplitRowsLayout& L, const float* enc_blob, unsigned short* out);
+bool irb_split_rows_supported(const Layer* le, const Layer& ld, const Layer& lp);
+hipError_t launch_irb_split_rows(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wfrag,
+                                 size_t wr_stride, size_t model_stride, int k0, int kc, int B, const float* x, float* y,
+                                 hipStream_t s);
 
 hipError_t launch_fused_block(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
                               size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);

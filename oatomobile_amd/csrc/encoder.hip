@@ -1171,7 +1171,8 @@ hipError_t launch_tap_copy(const void* src, bool src_bf16, size_t n, float* dst,
 
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s, EncoderTap* tap, const unsigned short* enc_wsh, const unsigned short* enc_wsl) {
+                          hipStream_t s, EncoderTap* tap, const unsigned short* enc_wsh, const unsigned short* enc_wsl,
+                          const unsigned short* enc_wr, size_t wr_stride) {
   // the tap: after the launch that completes layer `li`, copy its output out and stop
   auto tapped = [&](size_t li) -> bool {
     if (tap == nullptr || tap->layer != (int)li) return false;
@@ -1183,8 +1184,9 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     return true;
   };
   const size_t ms = plan.blob_floats;
-  // per layer: 0 = its own launch, 1 = interior of a block, 2 / 3 = last layer of a block (the block is launched there):
-  // 2 = the fp32 fused block of encoder_fused.hip (the leading `fused_blocks`), 3 = a split-f16 tile block
+  // per layer: 0 = its own launch, 1 = interior of a block, 2 / 3 / 4 = last layer of a block (the block is launched there):
+  // 2 = the fp32 fused block of encoder_fused.hip (the leading `fused_blocks`), 3 = a split-f16 tile block, 4 = a split-f16
+  // row-streaming block (which takes features.2 / 3 over from the fused fp32 kernel when the launch is large enough)
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
   const bool split_tiles = enc_wsh != nullptr && enc_wsl != nullptr && (long)B * kc >= SPLIT_TILE_MIN_PAIRS;
@@ -1192,7 +1194,8 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
     int how = 0;
-    if ((int)bi < fused_blocks) how = 2;
+    if (split_tiles && enc_wr != nullptr && irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 4;
+    else if ((int)bi < fused_blocks) how = 2;
     else if (split_tiles && fb.src != fb.dst && irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 3;
     if (how == 0) continue;
     if (fb.expand >= 0) in_block[fb.expand] = 1;
@@ -1206,11 +1209,16 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     if (in_block[li] >= 2) {
       const FusedBlock& fb = plan.blocks[block_of[li]];
       const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-      hipError_t e = in_block[li] == 2
-                         ? launch_fused_block(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, ms, k0, kc, B,
-                                              bufs[fb.src], bufs[fb.dst], s)
-                         : launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wsh, enc_wsl, ms, k0,
-                                                 kc, B, bufs[fb.src], bufs[fb.dst], s);
+      hipError_t e;
+      if (in_block[li] == 2)
+        e = launch_fused_block(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
+      else if (in_block[li] == 3)
+        e = launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wsh, enc_wsl, ms, k0, kc, B,
+                                  bufs[fb.src], bufs[fb.dst], s);
+      else
+        e = launch_irb_split_rows(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w,
+                                  enc_wr + split_rows_layout(plan).off[block_of[li]], wr_stride, ms, k0, kc, B, bufs[fb.src],
+                                  bufs[fb.dst], s);
       if (e != hipSuccess) return e;
       if (tapped(li)) return hipGetLastError();
       continue;

@@ -36,6 +36,8 @@ struct rip_handle {
                             // convolution but the stem; biases and the stem's taps are the fp32 blob's
   unsigned short* enc_ws = nullptr;  // [2][K][plan.blob_floats] binary16 (hi, lo) planes of the fp32 blob times 2^8: the two-term pointwise
                                      // operands of the fp32 encoder's split-f16 tile blocks (encoder_split_tile.hip)
+  unsigned short* enc_wr = nullptr;  // [K][rows_layout.total] operand fragments of the split-f16 row-streaming blocks (encoder_split_rows.hip)
+  SplitRowsLayout rows_layout;
   bool enc_split_ok[RIP_MAX_MODELS] = {false};  // the model's pointwise weights are inside SPLIT_ENC_W_LIMIT
   float* flow_w = nullptr;  // [K][FW_SIZE]
   float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the fp32 MFMA search kernels
@@ -248,6 +250,12 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     ALLOC(tmp, (size_t)K * h->plan.blob_floats);  // two 2-byte planes
     h->enc_ws = reinterpret_cast<unsigned short*>(tmp);
   }
+  h->rows_layout = split_rows_layout(h->plan);
+  {
+    float* tmp = nullptr;
+    ALLOC(tmp, ((size_t)K * h->rows_layout.total + 1) / 2);
+    h->enc_wr = reinterpret_cast<unsigned short*>(tmp);
+  }
   ALLOC(h->flow_w, (size_t)K * FW_SIZE);
   ALLOC(h->mfma_w, (size_t)K * MW_SIZE);
   {
@@ -305,7 +313,7 @@ int rip_destroy(rip_handle* h) {
   if (h->mega_status != nullptr) (void)hipHostFree(h->mega_status);
   if (h->mega_sync != nullptr) (void)hipFree(h->mega_sync);
   if (h->mega_arena != nullptr) (void)hipFree(h->mega_arena);
-  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), reinterpret_cast<float*>(h->enc_ws), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), reinterpret_cast<float*>(h->enc_ws), reinterpret_cast<float*>(h->enc_wr), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x, reinterpret_cast<float*>(h->stats)};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
@@ -456,6 +464,9 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
     const size_t plane = (size_t)h->K * h->plan.blob_floats;
     HIP_TRY(hipMemcpy(h->enc_ws + (size_t)k * h->plan.blob_floats, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->enc_ws + plane + (size_t)k * h->plan.blob_floats, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    std::vector<unsigned short> frag(h->rows_layout.total);
+    pack_split_rows(h->plan, h->rows_layout, enc.data(), frag.data());
+    HIP_TRY(hipMemcpy(h->enc_wr + (size_t)k * h->rows_layout.total, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -504,6 +515,8 @@ int rip_encoder_status(rip_handle* h) {
 struct SplitPlanes {
   const unsigned short* hi = nullptr;
   const unsigned short* lo = nullptr;
+  const unsigned short* rows = nullptr;  // operand fragments of the row-streaming blocks
+  size_t rows_stride = 0;
 };
 static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
   SplitPlanes sp;
@@ -512,6 +525,8 @@ static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
     if (!h->enc_split_ok[k]) return sp;
   sp.hi = h->enc_ws;
   sp.lo = h->enc_ws + (size_t)h->K * h->plan.blob_floats;
+  sp.rows = h->enc_wr;
+  sp.rows_stride = h->rows_layout.total;
   return sp;
 }
 
@@ -538,7 +553,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   }
   const SplitPlanes sp = split_planes(h, k_begin, k_count);
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
-                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, nullptr, sp.hi, sp.lo));
+                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, nullptr, sp.hi, sp.lo, sp.rows, sp.rows_stride));
   return RIP_OK;
 }
 
@@ -573,7 +588,7 @@ int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin,
   else {
     const SplitPlanes sp = split_planes(h, k_begin, k_count);  // the same kernel selection as rip_encode
     HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
-                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap, sp.hi, sp.lo));
+                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap, sp.hi, sp.lo, sp.rows, sp.rows_stride));
   }
   if (!tap.served)
     return fail(RIP_EINVAL, "layer %d is inside a fused block under the current RIP_OPT_ENCODER_FUSED setting / kernel selection: its output "

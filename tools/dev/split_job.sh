@@ -1,4 +1,5 @@
-# GPU box: the fp32 encoder's split-f16 tile blocks: parity test, per-phase cycles, stage times
+# GPU box: the fp32 encoder's split-f16 blocks: parity test, kernel timeline
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "split_tile or layerwise_encoder or g5_params" 2>&1 | grep -v "^$" | tail -12
-bash tools/dev/split_sweep.sh "$1"
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "split_tile or layerwise_encoder or g5_params" 2>&1 | grep -v "^$" | tail -${2:-14}
+bash tools/dev/ktrace32.sh 2>&1 | grep -v "pw_kernel\|dw_kernel" | tail -24
+python tools/stage_times.py --obs-batch 512 --iters 8 --enc fp32 2>&1 | tail -1
