@@ -181,6 +181,11 @@ struct SplitRowsLayout {
 SplitRowsLayout split_rows_layout(const EncoderPlan& plan);
 void pack_split_rows(const EncoderPlan& plan, const SplitRowsLayout& L, const float* enc_blob, unsigned short* out);
 bool irb_split_rows_supported(const Layer* le, const Layer& ld, const Layer& lp);
+// stem + features.1 in the same structure (fp32 stem on the vector unit, split-f16 projection; C = 2)
+bool front_split_supported(const Layer& ls, const Layer& ld, const Layer& lp);
+hipError_t launch_front_split(const Layer& ls, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wfrag,
+                              size_t wr_stride, size_t model_stride, int k0, int kc, int B, const float* visual, float* y,
+                              hipStream_t s);
 hipError_t launch_irb_split_rows(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wfrag,
                                  size_t wr_stride, size_t model_stride, int k0, int kc, int B, const float* x, float* y,
                                  hipStream_t s);

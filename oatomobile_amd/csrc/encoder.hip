@@ -1185,7 +1185,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
   };
   const size_t ms = plan.blob_floats;
   // per layer: 0 = its own launch, 1 = interior of a block, 2 / 3 / 4 = last layer of a block (the block is launched there):
-  // 2 = the fp32 fused block of encoder_fused.hip (the leading `fused_blocks`), 3 = a split-f16 tile block, 4 = a split-f16
+  // 2 = the fp32 fused block of encoder_fused.hip (the leading `fused_blocks`), 3 = a split-f16 tile block, 5 = stem + features.1, 4 = a split-f16
   // row-streaming block (which takes features.2 / 3 over from the fused fp32 kernel when the launch is large enough)
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
@@ -1194,7 +1194,11 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
     int how = 0;
-    if (split_tiles && enc_wr != nullptr && irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 4;
+    if (split_tiles && enc_wr != nullptr && bi == 0 && fb.expand < 0 && fb.dw == 1 &&
+        front_split_supported(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project])) {
+      how = 5;  // stem + features.1 in one kernel: the stem layer is interior to it
+      in_block[0] = 1;
+    } else if (split_tiles && enc_wr != nullptr && irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 4;
     else if ((int)bi < fused_blocks) how = 2;
     else if (split_tiles && fb.src != fb.dst && irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 3;
     if (how == 0) continue;
@@ -1215,6 +1219,9 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       else if (in_block[li] == 3)
         e = launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wsh, enc_wsl, ms, k0, kc, B,
                                   bufs[fb.src], bufs[fb.dst], s);
+      else if (in_block[li] == 5)
+        e = launch_front_split(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w,
+                               enc_wr + split_rows_layout(plan).off[block_of[li]], wr_stride, ms, k0, kc, B, visual, bufs[fb.dst], s);
       else
         e = launch_irb_split_rows(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w,
                                   enc_wr + split_rows_layout(plan).off[block_of[li]], wr_stride, ms, k0, kc, B, bufs[fb.src],

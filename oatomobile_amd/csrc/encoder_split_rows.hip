@@ -353,6 +353,221 @@ hipError_t launch_rows(RowsArgs a, int kc, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The front of the fp32 encoder in the same structure: stem (3x3, stride 2, C -> 32, fp32 on the vector unit) ->
+// features.1 (t = 1 block: depthwise 3x3 on 32 channels -> projection 32 -> 16, split-f16 MFMA) in one kernel.
+// Rounds 1-5: `stem_kernel` (0.44 ms at 512 observations x 4 models: 0.65 GB written) + `irb_kernel<2,32,false>` (0.90 ms).
+// The "expansion" of a step is the stem itself: two rows of its output are computed from five rows of the BEV (staged
+// in LDS one step ahead, zero columns either side) straight into the ring the depthwise reads.
+// ------------------------------------------------------------------------------------------------------------------
+struct FrontArgs {
+  const float* visual;  // [B][C][100][100]
+  float* y;             // [K][B][50][50][16]
+  const float* wbase;
+  const h16_t* wfrag;   // features.1's projection fragments of model 0, models wr_stride apart
+  size_t model_stride, wr_stride;
+  int k0;
+  size_t ws_off, bs_off, wd_off, bd_off, bp_off;
+  int B;
+};
+
+template <int C>
+struct FrontGeom {
+  static constexpr int HIN = 100, W = 50, HOUT = 50, PW = W + 2, HID = 32, COUT = 16;
+  static constexpr int R = 4, NS = HOUT / 2 + 1;  // step s: stem rows 2 s, 2 s + 1; depthwise / projection of rows 2 s - 1, 2 s
+  static constexpr int LDE = HID + 4, LDD = HID + 8;
+  static constexpr int NOP = RB * HOUT, NPO = (NOP + 15) / 16, DROWS = NPO * 16;
+  static constexpr int RAWW = 4 + HIN + 4, RAWR = 5;  // BEV window: rows 4 s - 1 .. 4 s + 3, column x at index x + 4
+  static constexpr size_t E_BYTES = (size_t)R * PW * LDE * sizeof(float);
+  static constexpr size_t D_PLANE = (size_t)DROWS * LDD;
+  static constexpr size_t D_BYTES = 2 * D_PLANE * sizeof(h16_t);
+  static constexpr size_t RAW_BYTES = (size_t)C * RAWR * RAWW * sizeof(float);
+  static constexpr size_t LDS_BYTES = E_BYTES + D_BYTES + RAW_BYTES + 2 * 1024 + 16 * sizeof(float);
+  static constexpr int NRAW4 = C * RAWR * (HIN / 4);  // float4 pieces of a window
+  static_assert(NRAW4 <= 512 && NPO <= 8, "one request per thread, one projection tile per wave");
+};
+
+template <int C>
+__global__ __launch_bounds__(512) void front_split_kernel(FrontArgs a) {
+  using Geo = FrontGeom<C>;
+  constexpr int HIN = Geo::HIN, W = Geo::W, HOUT = Geo::HOUT, PW = Geo::PW, HID = Geo::HID, COUT = Geo::COUT, R = Geo::R, NS = Geo::NS;
+  constexpr int LDE = Geo::LDE, LDD = Geo::LDD, NOP = Geo::NOP, NPO = Geo::NPO, RAWW = Geo::RAWW, RAWR = Geo::RAWR;
+  constexpr int NCG = HID / 4, PSL = 512 / NCG, JMAX = (NOP + PSL - 1) / PSL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* const E = reinterpret_cast<float*>(smem_raw);                                  // [R][PW][LDE]
+  h16_t* const Dh = reinterpret_cast<h16_t*>(smem_raw + Geo::E_BYTES);                  // [DROWS][LDD] hi
+  h16_t* const Dl = Dh + Geo::D_PLANE;
+  float* const RAW = reinterpret_cast<float*>(smem_raw + Geo::E_BYTES + Geo::D_BYTES);  // [C][RAWR][RAWW]
+  u32x4* const WP = reinterpret_cast<u32x4*>(smem_raw + Geo::E_BYTES + Geo::D_BYTES + Geo::RAW_BYTES);  // [2][64]
+  float* const PB = reinterpret_cast<float*>(WP + 128);                                  // bp [16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.z;
+  const float* Wf = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#ifdef RIP_ROWS_TICKS
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+  for (int e = tid; e < (int)(Geo::E_BYTES / 16); e += 512) reinterpret_cast<u32x4*>(E)[e] = zero4;
+  for (int e = tid; e < (int)(Geo::D_BYTES / 16); e += 512) reinterpret_cast<u32x4*>(Dh)[e] = zero4;
+  for (int e = tid; e < (int)(Geo::RAW_BYTES / 16); e += 512) reinterpret_cast<u32x4*>(RAW)[e] = zero4;
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.wfrag + (size_t)(a.k0 + k) * a.wr_stride);
+    if (tid < 128) WP[tid] = src[tid];
+    if (tid < 16) PB[tid] = Wf[a.bp_off + tid];
+  }
+  // this thread's four channels (of the stem's 32 outputs = the depthwise's 32 channels): stem taps, depthwise taps, biases
+  const int cg = tid % NCG, pslot = tid / NCG;
+  f32x2 ws[9 * C][2], bs[2], wt[9][2], bd[2];
+#pragma unroll
+  for (int t = 0; t < 9 * C; ++t) {
+    const float4 w0 = *reinterpret_cast<const float4*>(Wf + a.ws_off + (size_t)t * 32 + 4 * cg);  // [(ky 3 + kx) C + c][32]
+    ws[t][0] = f32x2{w0.x, w0.y};
+    ws[t][1] = f32x2{w0.z, w0.w};
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float4 w0 = *reinterpret_cast<const float4*>(Wf + a.wd_off + (size_t)t * HID + 4 * cg);
+    wt[t][0] = f32x2{w0.x, w0.y};
+    wt[t][1] = f32x2{w0.z, w0.w};
+  }
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(Wf + a.bs_off + 4 * cg), b1 = *reinterpret_cast<const float4*>(Wf + a.bd_off + 4 * cg);
+    bs[0] = f32x2{b0.x, b0.y};
+    bs[1] = f32x2{b0.z, b0.w};
+    bd[0] = f32x2{b1.x, b1.y};
+    bd[1] = f32x2{b1.z, b1.w};
+  }
+  // BEV window of step s: thread tid < NRAW4 owns the float4 (channel c, window row r, columns 4 i ..)
+  const int rw_c = tid / (RAWR * (HIN / 4)), rw_r = (tid / (HIN / 4)) % RAWR, rw_i = tid % (HIN / 4);
+  f32x4 rawv = {0.f, 0.f, 0.f, 0.f};
+  auto request_raw = [&](int b, int s) {
+    const int row = 4 * s - 1 + rw_r;
+    rawv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < Geo::NRAW4 && row >= 0 && row < HIN)
+      rawv = *reinterpret_cast<const f32x4*>(a.visual + (((size_t)b * C + rw_c) * HIN + row) * HIN + 4 * rw_i);
+  };
+  auto publish_raw = [&]() {
+    if (tid < Geo::NRAW4) *reinterpret_cast<f32x4*>(RAW + ((size_t)rw_c * RAWR + rw_r) * RAWW + 4 + 4 * rw_i) = rawv;
+  };
+  // projection role: wave w owns output pixel tile w
+  const bool pj_wave = w < NPO;
+  const int pj_j = 16 * w + n, pj_orow = pj_j / HOUT, pj_ox = pj_j - pj_orow * HOUT;
+  lds_barrier();
+  ROWS_TICK(0);
+
+  int b = blockIdx.x;
+  if (b < a.B) {
+    request_raw(b, 0);
+    publish_raw();
+    request_raw(b, 1);
+  }
+  lds_barrier();
+#pragma unroll 1
+  for (; b < a.B; b += gridDim.x) {
+    for (int e = tid; e < PW * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E + (size_t)(R - 1) * PW * LDE)[e] = zero4;  // stem row -1
+    float* yb = a.y + ((size_t)k * a.B + b) * HOUT * HOUT * COUT;
+    ROWS_TICK(1);
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      // ---------------- stem rows 2 s, 2 s + 1 -> E ring (rows >= 50: zero rows) ----------------
+#pragma unroll
+      for (int jj = 0; jj < JMAX; ++jj) {
+        const int j = pslot + jj * PSL;
+        if (j >= NOP) break;
+        const int r = j >= W ? 1 : 0, ox = j - r * W, row = 2 * s + r;
+        f32x2 s0 = bs[0], s1 = bs[1];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float* rp = RAW + ((size_t)c * RAWR + 2 * r + ky) * RAWW + 2 * ox + 3;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float v = rp[kx];
+              s0 = __builtin_elementwise_fma(f32x2{v, v}, ws[(ky * 3 + kx) * C + c][0], s0);
+              s1 = __builtin_elementwise_fma(f32x2{v, v}, ws[(ky * 3 + kx) * C + c][1], s1);
+            }
+          }
+        s0 = relu6_2(s0);
+        s1 = relu6_2(s1);
+        if (row >= HOUT) {
+          s0 = f32x2{0.f, 0.f};
+          s1 = f32x2{0.f, 0.f};
+        }
+        *reinterpret_cast<f32x4*>(E + (size_t)((row % R) * PW + ox + 1) * LDE + 4 * cg) = f32x4{s0.x, s0.y, s1.x, s1.y};
+      }
+      ROWS_TICK(2);
+      lds_barrier();
+      ROWS_TICK(3);
+      // the next step's BEV window (requested a step ago) into LDS, the one after it requested
+      publish_raw();
+      {
+        int nb = b, ns = s + 2;
+        if (ns >= NS) {
+          nb = b + (int)gridDim.x;
+          ns -= NS;
+        }
+        if (nb < a.B) request_raw(nb, ns);
+      }
+      // ---------------- depthwise: output rows 2 s - 1, 2 s -> D (hi, lo) ----------------
+      const int ob = 2 * s - 1;
+      int slotv[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) slotv[i] = (ob - 1 + i + R) % R;
+#pragma unroll
+      for (int jj = 0; jj < JMAX; ++jj) {
+        const int j = pslot + jj * PSL;
+        if (j >= NOP) break;
+        const int orow = j >= HOUT ? 1 : 0, ox = j - orow * HOUT;
+        f32x2 s0 = bd[0], s1 = bd[1];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int slot = orow ? slotv[1 + ky] : slotv[ky];
+          const float* rp = E + (size_t)(slot * PW + ox) * LDE + 4 * cg;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 e = *reinterpret_cast<const f32x4*>(rp + kx * LDE);
+            s0 = __builtin_elementwise_fma(f32x2{e[0], e[1]}, wt[ky * 3 + kx][0], s0);
+            s1 = __builtin_elementwise_fma(f32x2{e[2], e[3]}, wt[ky * 3 + kx][1], s1);
+          }
+        }
+        const u32x2 p0 = split2(relu6_2(s0)), p1 = split2(relu6_2(s1));
+        *reinterpret_cast<u32x2*>(Dh + (size_t)j * LDD + 4 * cg) = u32x2{p0.x, p1.x};
+        *reinterpret_cast<u32x2*>(Dl + (size_t)j * LDD + 4 * cg) = u32x2{p0.y, p1.y};
+      }
+      ROWS_TICK(4);
+      lds_barrier();
+      ROWS_TICK(5);
+      // ---------------- project the two rows -> y ----------------
+      if (pj_wave) {
+        const int o = ob + pj_orow;
+        const size_t od = (size_t)pj_j * LDD + 8 * q;
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(Dh + od), bl = *reinterpret_cast<const u32x4*>(Dl + od);
+        const u32x4 ah = WP[lane], al = WP[64 + lane];
+        f32x4 acc = mfmah(al, bh, f32x4{0.f, 0.f, 0.f, 0.f});
+        acc = mfmah(ah, bl, acc);
+        acc = mfmah(ah, bh, acc);
+        if (pj_j < NOP && o >= 0 && o < HOUT) {
+          const float4 bp = *reinterpret_cast<const float4*>(PB + 4 * q);
+          *reinterpret_cast<f32x4*>(yb + ((size_t)o * HOUT + pj_ox) * COUT + 4 * q) =
+              f32x4{fmaf(acc[0], W_INV, bp.x), fmaf(acc[1], W_INV, bp.y), fmaf(acc[2], W_INV, bp.z), fmaf(acc[3], W_INV, bp.w)};
+        }
+      }
+      ROWS_TICK(6);
+    }
+  }
+#ifdef RIP_ROWS_TICKS
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_rows_ticks[i], tk[i]);
+    atomicAdd(&g_rows_ticks[8], 1ull);
+  }
+#endif
+}
+
 struct RowsShape {
   int hin, stride, cin, hid, cout;
 };
@@ -370,14 +585,51 @@ int rows_shape_index(const Layer* le, const Layer& ld, const Layer& lp) {
 
 // operand fragments of one block: halves per model
 size_t rows_frag_halves(const Layer* le, const Layer& ld, const Layer& lp) {
-  const int nfe = ld.cout / 16 * 2, nfp = ((lp.cout + 15) / 16) * ((ld.cout + 31) / 32) * 2;
-  (void)le;
+  const int nfe = le != nullptr ? ld.cout / 16 * 2 : 0, nfp = ((lp.cout + 15) / 16) * ((ld.cout + 31) / 32) * 2;
   return (size_t)(nfe + nfp) * 512;
+}
+
+template <int C>
+hipError_t launch_front(FrontArgs a, int kc, hipStream_t s) {
+  using Geo = FrontGeom<C>;
+  static bool attr_set[64] = {};
+  auto kern = front_split_kernel<C>;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  int gx = device_cu_count() / kc;
+  if (gx < 1) gx = 1;
+  if (gx > a.B) gx = a.B;
+  note_kernel(dim3(gx, 1, kc), dim3(512), "front_split_kernel<%d>", C);
+  hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::LDS_BYTES, s, a);
+#ifdef RIP_ROWS_TICKS
+  {
+    unsigned long long t[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_rows_ticks), sizeof(t));
+    const double n = t[8] > 0 ? (double)t[8] : 1.0, imgs = (double)a.B * kc / n, st = imgs * Geo::NS;
+    fprintf(stderr, "split front<%d> cycles per workgroup (%.1f observations x %d steps): prologue %.0f | per observation: zero row %.0f | per step: "
+            "stem %.0f barrier %.0f depthwise %.0f barrier %.0f project %.0f\n",
+            C, imgs, Geo::NS, t[0] / n, t[1] / n / imgs, t[2] / n / st, t[3] / n / st, t[4] / n / st, t[5] / n / st, t[6] / n / st);
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_ticks), z, sizeof(z));
+  }
+#endif
+  return hipGetLastError();
 }
 
 }  // namespace
 
 bool irb_split_rows_supported(const Layer* le, const Layer& ld, const Layer& lp) { return rows_shape_index(le, ld, lp) >= 0; }
+
+bool front_split_supported(const Layer& ls, const Layer& ld, const Layer& lp) {
+  return ls.kind == L_STEM && ls.cin == 2 && ls.cout == 32 && ls.h_in == 100 && ls.stride == 2 && ld.kind == L_DW && ld.cout == 32 &&
+         ld.h_in == 50 && ld.stride == 1 && lp.cin == 32 && lp.cout == 16 && !lp.residual;
+}
 
 SplitRowsLayout split_rows_layout(const EncoderPlan& plan) {
   SplitRowsLayout L;
@@ -386,7 +638,8 @@ SplitRowsLayout split_rows_layout(const EncoderPlan& plan) {
   for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
-    if (!irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) continue;
+    const bool front = bi == 0 && fb.expand < 0 && fb.dw == 1 && front_split_supported(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project]);
+    if (!front && !irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) continue;
     L.off[bi] = off;
     off += rows_frag_halves(le, plan.layers[fb.dw], plan.layers[fb.project]);
   }
@@ -409,9 +662,10 @@ void pack_split_rows(const EncoderPlan& plan, const SplitRowsLayout& L, const fl
   for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
     if (L.off[bi] == (size_t)-1) continue;
     const FusedBlock& fb = plan.blocks[bi];
-    const Layer &le = plan.layers[fb.expand], &ld = plan.layers[fb.dw], &lp = plan.layers[fb.project];
+    const Layer &ld = plan.layers[fb.dw], &lp = plan.layers[fb.project];
+    const Layer& le = plan.layers[fb.expand >= 0 ? fb.expand : fb.dw];  // (the front's block has no expansion: no expansion fragments)
     const int cin = le.cin, hid = ld.cout, cout = lp.cout;
-    const int ncte = hid / 16, nctp = (cout + 15) / 16, nkp = (hid + 31) / 32;
+    const int ncte = fb.expand >= 0 ? hid / 16 : 0, nctp = (cout + 15) / 16, nkp = (hid + 31) / 32;
     size_t o = L.off[bi];
     for (int ct = 0; ct < ncte; ++ct)
       for (int term = 0; term < 2; ++term)
@@ -429,6 +683,27 @@ void pack_split_rows(const EncoderPlan& plan, const SplitRowsLayout& L, const fl
               put(o++, (row < cout && kk < hid) ? enc[lp.w_off + (size_t)row * hid + kk] : 0.f, term);
             }
   }
+}
+
+hipError_t launch_front_split(const Layer& ls, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wfrag,
+                              size_t wr_stride, size_t model_stride, int k0, int kc, int B, const float* visual, float* y,
+                              hipStream_t s) {
+  if (!front_split_supported(ls, ld, lp)) return hipErrorInvalidValue;
+  FrontArgs a;
+  a.visual = visual;
+  a.y = y;
+  a.wbase = enc_w;
+  a.wfrag = wfrag;
+  a.model_stride = model_stride;
+  a.wr_stride = wr_stride;
+  a.k0 = k0;
+  a.ws_off = ls.w_off;
+  a.bs_off = ls.b_off;
+  a.wd_off = ld.w_off;
+  a.bd_off = ld.b_off;
+  a.bp_off = lp.b_off;
+  a.B = B;
+  return launch_front<2>(a, kc, s);
 }
 
 hipError_t launch_irb_split_rows(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wfrag,
