@@ -194,8 +194,23 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
     }
   };
 
+  // The split of the next step's input sits BEHIND the depthwise barrier and IN FRONT of the projection's stores: the
+  // compiler's wait for the request (issued at the top of the step) cannot tell how many of the predicated stores of
+  // the projection were issued after it, so at the top of the next step it was `vmcnt(0)` — every projecting wave waiting
+  // for its own stores to be acknowledged (1-2 k cycles per step).
+  u32x4 xh[TIN], xl[TIN];
+  auto split_x = [&]() {
+#pragma unroll
+    for (int t = 0; t < TIN; ++t) {
+      const u32x2 s0 = split2(f32x2{xr[t][0][0], xr[t][0][1]}), s1 = split2(f32x2{xr[t][0][2], xr[t][0][3]});
+      const u32x2 s2 = split2(f32x2{xr[t][1][0], xr[t][1][1]}), s3 = split2(f32x2{xr[t][1][2], xr[t][1][3]});
+      xh[t] = u32x4{s0.x, s1.x, s2.x, s3.x};
+      xl[t] = u32x4{s0.y, s1.y, s2.y, s3.y};
+    }
+  };
   int b = blockIdx.x;
   if (b < a.B) request_x(b, 0);
+  split_x();
 #pragma unroll 1
   for (; b < a.B; b += gridDim.x) {
     // the ring slot of input row -1 is a zero row (slot R - 1; the last depthwise of the previous observation is behind its barrier)
@@ -206,16 +221,13 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
       // ---------------- expand the input rows s NRI .. s NRI + NRI - 1 -> E ring ----------------
-      u32x4 xh[TIN], xl[TIN];
-#pragma unroll
-      for (int t = 0; t < TIN; ++t) {
-        const u32x2 s0 = split2(f32x2{xr[t][0][0], xr[t][0][1]}), s1 = split2(f32x2{xr[t][0][2], xr[t][0][3]});
-        const u32x2 s2 = split2(f32x2{xr[t][1][0], xr[t][1][1]}), s3 = split2(f32x2{xr[t][1][2], xr[t][1][3]});
-        xh[t] = u32x4{s0.x, s1.x, s2.x, s3.x};
-        xl[t] = u32x4{s0.y, s1.y, s2.y, s3.y};
-      }
+      // (xh / xl hold this step's rows; the next step's — or the next observation's first — are requested now)
       if (s + 1 < NS) request_x(b, s + 1);
       else if (b + (int)gridDim.x < a.B) request_x(b + (int)gridDim.x, 0);
+      const int ob = S == 1 ? 2 * s - 1 : 2 * s;  // output rows of this step: ob, ob + 1
+      f32x4 res = {0.f, 0.f, 0.f, 0.f};              // the projection's residual, requested a step's length ahead
+      const bool pj_on = pj_wave && pj_j < NOP && ob + pj_orow >= 0 && ob + pj_orow < HOUT && pj_ch < COUT;
+      if (a.residual && pj_on) res = *reinterpret_cast<const f32x4*>(xb + ((size_t)(ob + pj_orow) * W + pj_ox) * CIN + pj_ch);  // (CIN == COUT, S == 1)
       int eoff[TIN];
       bool in_map[TIN];
 #pragma unroll
@@ -224,35 +236,54 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
         in_map[t] = row < HIN;
         eoff[t] = t_on[t] ? ((row % R) * PW + t_ix[t] + 1) * LDE : Geo::E_DUMP * LDE;
       }
+      // Channel tiles in batches of CB: all operand reads of a batch, then its MFMAs term by term (3 CB TIN independent
+      // chains instead of CB serial ones of three dependent MFMAs each — left as one loop the compiler emits read,
+      // MFMA, MFMA, MFMA, epilogue, store per tile and nothing overlaps: ~300 cycles per tile), then the epilogues.
+      // (A partition's missing last tile recomputes the previous one: the same values stored twice, no branch.)
+      constexpr int CB = NCTW > 5 ? (NCTW + 1) / 2 : NCTW;
 #pragma unroll
-      for (int ci = 0; ci < NCTW; ++ci) {
-        const int ct = ct_lo + ci;
-        if (ct >= ct_hi) break;
-        const u32x4 ah = WE[(size_t)(ct * 2) * 64 + lane], al = WE[(size_t)(ct * 2 + 1) * 64 + lane];
-        const float4 be = *reinterpret_cast<const float4*>(PB + 16 * ct + 4 * q);
-        f32x4 v[TIN];
+      for (int c0 = 0; c0 < NCTW; c0 += CB) {
+        u32x4 ah[CB], al[CB];
+        float4 be[CB];
+        int ctv[CB];
 #pragma unroll
-        for (int t = 0; t < TIN; ++t) v[t] = mfmah(al, xh[t], f32x4{0.f, 0.f, 0.f, 0.f});  // small terms first
-#pragma unroll
-        for (int t = 0; t < TIN; ++t) v[t] = mfmah(ah, xl[t], v[t]);
-#pragma unroll
-        for (int t = 0; t < TIN; ++t) v[t] = mfmah(ah, xh[t], v[t]);
-#pragma unroll
-        for (int t = 0; t < TIN; ++t) {
-          f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{v[t][0], v[t][1]}, f32x2{W_INV, W_INV}, f32x2{be.x, be.y}));
-          f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{v[t][2], v[t][3]}, f32x2{W_INV, W_INV}, f32x2{be.z, be.w}));
-          if (!in_map[t]) {  // a row below the map is a zero row of the EXPANDED tensor (the depthwise pads its input)
-            v0 = f32x2{0.f, 0.f};
-            v1 = f32x2{0.f, 0.f};
-          }
-          *reinterpret_cast<f32x4*>(E + eoff[t] + 16 * ct + 4 * q) = f32x4{v0.x, v0.y, v1.x, v1.y};
+        for (int ci = 0; ci < CB; ++ci) {
+          const int ct = ct_lo + c0 + ci < ct_hi ? ct_lo + c0 + ci : ct_hi - 1;
+          ctv[ci] = ct;
+          ah[ci] = WE[(size_t)(ct * 2) * 64 + lane];
+          al[ci] = WE[(size_t)(ct * 2 + 1) * 64 + lane];
+          be[ci] = *reinterpret_cast<const float4*>(PB + 16 * ct + 4 * q);
         }
+        f32x4 v[CB][TIN];
+#pragma unroll
+        for (int ci = 0; ci < CB; ++ci)
+#pragma unroll
+          for (int t = 0; t < TIN; ++t) v[ci][t] = mfmah(al[ci], xh[t], f32x4{0.f, 0.f, 0.f, 0.f});  // small terms first
+#pragma unroll
+        for (int ci = 0; ci < CB; ++ci)
+#pragma unroll
+          for (int t = 0; t < TIN; ++t) v[ci][t] = mfmah(ah[ci], xl[t], v[ci][t]);
+#pragma unroll
+        for (int ci = 0; ci < CB; ++ci)
+#pragma unroll
+          for (int t = 0; t < TIN; ++t) v[ci][t] = mfmah(ah[ci], xh[t], v[ci][t]);
+#pragma unroll
+        for (int ci = 0; ci < CB; ++ci)
+#pragma unroll
+          for (int t = 0; t < TIN; ++t) {
+            f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{v[ci][t][0], v[ci][t][1]}, f32x2{W_INV, W_INV}, f32x2{be[ci].x, be[ci].y}));
+            f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{v[ci][t][2], v[ci][t][3]}, f32x2{W_INV, W_INV}, f32x2{be[ci].z, be[ci].w}));
+            if (!in_map[t]) {  // a row below the map is a zero row of the EXPANDED tensor (the depthwise pads its input)
+              v0 = f32x2{0.f, 0.f};
+              v1 = f32x2{0.f, 0.f};
+            }
+            *reinterpret_cast<f32x4*>(E + eoff[t] + 16 * ctv[ci] + 4 * q) = f32x4{v0.x, v0.y, v1.x, v1.y};
+          }
       }
       ROWS_TICK(2);
       lds_barrier();
       ROWS_TICK(3);
       // ---------------- depthwise: output rows ob, ob + 1 -> D (hi, lo) ----------------
-      const int ob = S == 1 ? 2 * s - 1 : 2 * s;
       int slotv[R];  // ring slot of input row ob S - 1 + i
 #pragma unroll
       for (int i = 0; i < R; ++i) slotv[i] = (ob * S - 1 + i + R) % R;
@@ -263,16 +294,18 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
           if (j >= NOP) break;
           const int orow = j >= HOUT ? 1 : 0, ox = j - orow * HOUT;
           f32x2 s0 = bd[0], s1 = bd[1];
+          f32x4 e[9];  // all nine reads first: one LDS latency per pixel, not one per tap row
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const int slot = orow ? slotv[S + ky] : slotv[ky];
             const float* r = E + (size_t)(slot * PW + ox * S) * LDE + 4 * cg;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const f32x4 e = *reinterpret_cast<const f32x4*>(r + kx * LDE);
-              s0 = __builtin_elementwise_fma(f32x2{e[0], e[1]}, wt[ky * 3 + kx][0], s0);
-              s1 = __builtin_elementwise_fma(f32x2{e[2], e[3]}, wt[ky * 3 + kx][1], s1);
-            }
+            for (int kx = 0; kx < 3; ++kx) e[ky * 3 + kx] = *reinterpret_cast<const f32x4*>(r + kx * LDE);
+          }
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            s0 = __builtin_elementwise_fma(f32x2{e[t][0], e[t][1]}, wt[t][0], s0);
+            s1 = __builtin_elementwise_fma(f32x2{e[t][2], e[t][3]}, wt[t][1], s1);
           }
           const u32x2 p0 = split2(relu6_2(s0)), p1 = split2(relu6_2(s1));
           *reinterpret_cast<u32x2*>(Dh + (size_t)j * LDD + 4 * cg) = u32x2{p0.x, p1.x};
@@ -282,22 +315,23 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
       ROWS_TICK(4);
       lds_barrier();
       ROWS_TICK(5);
+      split_x();  // the next step's rows (requested at the top of this step)
       // ---------------- project the two rows -> y ----------------
       if (pj_wave) {
         const int o = ob + pj_orow;
-        const bool on = pj_j < NOP && o >= 0 && o < HOUT && pj_ch < COUT;
-        f32x4 res = {0.f, 0.f, 0.f, 0.f};
-        if (a.residual && on) res = *reinterpret_cast<const f32x4*>(xb + ((size_t)o * W + pj_ox) * CIN + pj_ch);  // (CIN == COUT, S == 1)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bool on = pj_on;
+        // one accumulator per term: three independent chains of NKP MFMAs instead of one of 3 NKP dependent ones
+        f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKP; ++ks) {
           const size_t od = (size_t)pj_j * LDD + 32 * ks + 8 * q;
           const u32x4 bh = *reinterpret_cast<const u32x4*>(Dh + od), bl = *reinterpret_cast<const u32x4*>(Dl + od);
           const u32x4 ah = WP[(size_t)((pj_ct * NKP + ks) * 2) * 64 + lane], al = WP[(size_t)((pj_ct * NKP + ks) * 2 + 1) * 64 + lane];
-          acc = mfmah(al, bh, acc);
-          acc = mfmah(ah, bl, acc);
+          acc_a = mfmah(al, bh, acc_a);
+          acc_b = mfmah(ah, bl, acc_b);
           acc = mfmah(ah, bh, acc);
         }
+        acc += acc_a + acc_b;  // (small terms first)
         if (on) {
           const float4 bp = *reinterpret_cast<const float4*>(PB + HID + pj_ch);
           const f32x4 v = {fmaf(acc[0], W_INV, bp.x) + res[0], fmaf(acc[1], W_INV, bp.y) + res[1], fmaf(acc[2], W_INV, bp.z) + res[2],
@@ -479,18 +513,20 @@ __global__ __launch_bounds__(512) void front_split_kernel(FrontArgs a) {
         if (j >= NOP) break;
         const int r = j >= W ? 1 : 0, ox = j - r * W, row = 2 * s + r;
         f32x2 s0 = bs[0], s1 = bs[1];
+        float rv[9 * C];
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const float* rp = RAW + ((size_t)c * RAWR + 2 * r + ky) * RAWW + 2 * ox + 3;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const float v = rp[kx];
-              s0 = __builtin_elementwise_fma(f32x2{v, v}, ws[(ky * 3 + kx) * C + c][0], s0);
-              s1 = __builtin_elementwise_fma(f32x2{v, v}, ws[(ky * 3 + kx) * C + c][1], s1);
-            }
+            for (int kx = 0; kx < 3; ++kx) rv[(ky * 3 + kx) * C + c] = rp[kx];
           }
+#pragma unroll
+        for (int t = 0; t < 9 * C; ++t) {  // (tap order (ky, kx) outer, channel inner: the layer-wise kernel's is channel outer — fp32 rounding order only)
+          s0 = __builtin_elementwise_fma(f32x2{rv[t], rv[t]}, ws[t][0], s0);
+          s1 = __builtin_elementwise_fma(f32x2{rv[t], rv[t]}, ws[t][1], s1);
+        }
         s0 = relu6_2(s0);
         s1 = relu6_2(s1);
         if (row >= HOUT) {
@@ -523,16 +559,18 @@ __global__ __launch_bounds__(512) void front_split_kernel(FrontArgs a) {
         if (j >= NOP) break;
         const int orow = j >= HOUT ? 1 : 0, ox = j - orow * HOUT;
         f32x2 s0 = bd[0], s1 = bd[1];
+        f32x4 e[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int slot = orow ? slotv[1 + ky] : slotv[ky];
           const float* rp = E + (size_t)(slot * PW + ox) * LDE + 4 * cg;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const f32x4 e = *reinterpret_cast<const f32x4*>(rp + kx * LDE);
-            s0 = __builtin_elementwise_fma(f32x2{e[0], e[1]}, wt[ky * 3 + kx][0], s0);
-            s1 = __builtin_elementwise_fma(f32x2{e[2], e[3]}, wt[ky * 3 + kx][1], s1);
-          }
+          for (int kx = 0; kx < 3; ++kx) e[ky * 3 + kx] = *reinterpret_cast<const f32x4*>(rp + kx * LDE);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          s0 = __builtin_elementwise_fma(f32x2{e[t][0], e[t][1]}, wt[t][0], s0);
+          s1 = __builtin_elementwise_fma(f32x2{e[t][2], e[t][3]}, wt[t][1], s1);
         }
         const u32x2 p0 = split2(relu6_2(s0)), p1 = split2(relu6_2(s1));
         *reinterpret_cast<u32x2*>(Dh + (size_t)j * LDD + 4 * cg) = u32x2{p0.x, p1.x};
