@@ -308,7 +308,11 @@ int rip_train_num_layers(const rip_trainer* t);
  *         than the one-wave shape, so auto never picks it).  All implement rip/agent.py:78-137.
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
- *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0.
+ *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0 — and,
+ *     round 6, from 32 (model, observation) pairs per call whatever the count: stem + features.1, features.2-7 and
+ *     features.8-17 as split-f16 blocks (fp32 activations, pointwise convolutions as three binary16 MFMAs on two-term
+ *     operands, depthwise / stem fp32: fp32-grade, z within 2e-5 of the fp32 oracle like the true-fp32 kernels), unless
+ *     a model's pointwise weights reach 240 in magnitude or RIP_OPT_ENCODER_VARIANT bit 16 is set.
  *     bf16 encoder: count >= 1 fuses the stem with features.1 (one kernel), blocks 1..6 of the count are the
  *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
  *     and 16 (features.17, round 5); features.18 runs as a GEMM with the pooled epilogue.  auto = everything, the tile kernel only when the call carries
@@ -334,6 +338,8 @@ int rip_train_num_layers(const rip_trainer* t);
  *     depthwise kernel is faster on all six blocks since the depthwise taps are bf16 values; accepted, no effect),
  *     8: features.17 as three layer-wise launches (round 4's persistent GEMMs + row-streaming depthwise) instead of a tile block.
  *     Same arithmetic definition; the teacher-forced block tests run every setting.
+ *     16 (fp32 encoder): no split-f16 blocks — the true-fp32 kernels of rounds 1-5 at every launch size (A/B runs, taps
+ *     of interior layers).
  *   RIP_OPT_KERNEL_LOG (tests; default 0): 1 = every rip_encode / rip_encode_raw* / rip_encode_tap* call records the
  *     encoder kernels it launches (name, template arguments, grid) — read with rip_kernel_log. */
 enum { RIP_OPT_SEARCH_KERNEL = 0, RIP_OPT_ENCODER_FUSED = 1, RIP_OPT_SEARCH_REGROUP = 2, RIP_OPT_ENCODER_MEGA = 3,

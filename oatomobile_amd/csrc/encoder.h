@@ -29,7 +29,7 @@ enum {
                                 // fused leading blocks as its own true-fp32 launch (rounds 1-5)
 };
 
-// The fp32 encoder's split-f16 blocks read the pointwise weights as two binary16 planes of w * 2^8 (rip_abi.hip: enc_ws);
+// The fp32 encoder's split-f16 blocks read the pointwise weights as two binary16 terms of w * 2^8 (rip_abi.hip: enc_wc, enc_wr);
 // a model whose pointwise weights reach this magnitude keeps the layer-wise fp32 kernels (binary16 max 65504 / 2^8).
 constexpr float SPLIT_ENC_W_SCALE = 256.0f;
 constexpr float SPLIT_ENC_W_LIMIT = 240.0f;
@@ -110,14 +110,15 @@ hipError_t launch_transform(const float* in, int B, int C, int H, int W, int cha
 //   enc_w: [K_total][plan.blob_floats]; visual [B,C,100,100]; vec [B,5]; bufs[4]: each >= kc*B*max_act floats.
 //   fused_blocks: the first `fused_blocks` inverted-residual blocks run as one kernel each (encoder_fused.hip),
 //   the rest layer by layer.
-//   enc_wsh / enc_wsl: binary16 (hi, lo) planes of the blobs times 2^8, or nullptr: with them features.8-17 run as
-//   split-f16 tile blocks (encoder_split_tile.hip) when the launch has >= SPLIT_TILE_MIN_PAIRS (model, observation) pairs.
+//   enc_wc: chunk records of the split-f16 tile blocks (features.8-17, encoder_split_tile.hip; `pack_split_tiles`, models
+//   wc_stride binary16 elements apart), or nullptr: with them the launch runs the split-f16 blocks when it has
+//   >= SPLIT_TILE_MIN_PAIRS (model, observation) pairs.
 //   enc_wr: operand fragments of the split-f16 row-streaming blocks (features.2-7, encoder_split_rows.hip;
 //   `pack_split_rows`, models wr_stride halves apart), or nullptr.
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s, EncoderTap* tap = nullptr, const unsigned short* enc_wsh = nullptr,
-                          const unsigned short* enc_wsl = nullptr, const unsigned short* enc_wr = nullptr, size_t wr_stride = 0);
+                          hipStream_t s, EncoderTap* tap = nullptr, const unsigned short* enc_wc = nullptr, size_t wc_stride = 0,
+                          const unsigned short* enc_wr = nullptr, size_t wr_stride = 0);
 
 // The whole fp32 encoder of a small batch as ONE persistent launch, model k on XCD k % 8 (encoder.hip:
 // encoder_mega_kernel).  arena: kc * arena_model_stride floats, arena_model_stride >= encoder_mega_arena_floats(B);
@@ -169,9 +170,14 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
 
 // fp32-grade tile blocks of the fp32 encoder (features.8-17): fp32 activations, two-term binary16 pointwise operands
 bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp);
-hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
-                                 const unsigned short* enc_wsh, const unsigned short* enc_wsl, size_t model_stride, int k0,
-                                 int kc, int B, const float* x, float* y, hipStream_t s);
+struct SplitTileLayout {
+  std::vector<size_t> off;  // per plan block: offset (binary16 elements) of its chunk records in a model's blob; (size_t)-1 = not a tile block
+  size_t total = 0;         // binary16 elements per model
+};
+SplitTileLayout split_tile_layout(const EncoderPlan& plan);
+void pack_split_tiles(const EncoderPlan& plan, const SplitTileLayout& L, const float* enc_blob, unsigned short* out);
+hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wc,
+                                 size_t wc_stride, size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);
 
 // fp32-grade row-streaming blocks of the fp32 encoder (features.2-7): encoder_split_rows.hip
 struct SplitRowsLayout {

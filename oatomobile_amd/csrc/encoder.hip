@@ -1171,7 +1171,7 @@ hipError_t launch_tap_copy(const void* src, bool src_bf16, size_t n, float* dst,
 
 hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, int kc, const float* visual,
                           const float* vec, int B, float* const bufs[4], float* z, float* feat, int fused_blocks,
-                          hipStream_t s, EncoderTap* tap, const unsigned short* enc_wsh, const unsigned short* enc_wsl,
+                          hipStream_t s, EncoderTap* tap, const unsigned short* enc_wc, size_t wc_stride,
                           const unsigned short* enc_wr, size_t wr_stride) {
   // the tap: after the launch that completes layer `li`, copy its output out and stop
   auto tapped = [&](size_t li) -> bool {
@@ -1189,7 +1189,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
   // row-streaming block (which takes features.2 / 3 over from the fused fp32 kernel when the launch is large enough)
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
-  const bool split_tiles = enc_wsh != nullptr && enc_wsl != nullptr && (long)B * kc >= SPLIT_TILE_MIN_PAIRS;
+  const bool split_tiles = enc_wc != nullptr && (long)B * kc >= SPLIT_TILE_MIN_PAIRS;
   for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
@@ -1217,8 +1217,8 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       if (in_block[li] == 2)
         e = launch_fused_block(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
       else if (in_block[li] == 3)
-        e = launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, enc_wsh, enc_wsl, ms, k0, kc, B,
-                                  bufs[fb.src], bufs[fb.dst], s);
+        e = launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w,
+                                  enc_wc + split_tile_layout(plan).off[block_of[li]], wc_stride, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
       else if (in_block[li] == 5)
         e = launch_front_split(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w,
                                enc_wr + split_rows_layout(plan).off[block_of[li]], wr_stride, ms, k0, kc, B, visual, bufs[fb.dst], s);

@@ -10,7 +10,7 @@
 //     owns G whole observations of one model and walks the hidden dimension in chunks of 64 channels);
 //   * a pointwise product is three v_mfma_f32_16x16x32_f16 (the plan search's scheme, flow_split_dev.h):
 //         W x ~= Whi xhi + Wlo xhi + Whi xlo,   fp32 accumulation, the dropped Wlo xlo term is 2^-22 relative.
-//     Weights are split on the host as w 2^8 = hi + lo (rip_abi.hip: enc_ws; |w| < 255 is checked there — a model
+//     Weights are split on the host as w 2^8 = hi + lo (`pack_split_tiles`; |w| < 240 is checked at load, rip_abi.hip — a model
 //     outside keeps the layer-wise kernels): the residual of an ordinary weight is then a normal binary16 and the 2^-8
 //     is one exact multiply in the epilogue.  Activations are split in the kernel, hi = f16(x), lo = f16(x - hi): the
 //     expanded / depthwise tensors are ReLU6-bounded; the block input must stay below 65504 in magnitude (a
@@ -25,6 +25,7 @@
 // Contract: the fp32 oracle at 1e-4 on z (tests/test_gpu_parity.py, the fp32 encoder gates); NOT bit-identical to the
 // layer-wise fp32 kernels (22 significant bits per operand instead of 24, another summation order).
 #include <cstdio>
+#include <cstring>
 
 #include "encoder.h"
 #include "flow.h"  // device_cu_count
@@ -77,9 +78,8 @@ struct SplitTileArgs {
   const float* x;       // [K][B][HIN][HIN][CIN] fp32
   float* y;             // [K][B][HOUT][HOUT][COUT] fp32
   const float* wbase;   // fp32 folded blobs (biases, depthwise taps)
-  const h16_t* wsh;     // binary16 hi plane of the blobs times 2^8 (pointwise weights), same offsets
-  const h16_t* wsl;     // lo plane: f16(w 2^8 - hi)
-  size_t model_stride;
+  const h16_t* wc;      // this block's chunk records of model 0 (pack_split_tiles), models wc_stride binary16 elements apart
+  size_t model_stride, wc_stride;
   int k0;
   size_t we_off, be_off, wd_off, bd_off, wp_off, bp_off;
   int B, HID, residual, G;
@@ -108,14 +108,22 @@ struct SplitGeom {
 // G: observations per workgroup at most (G * HOUT * 16 <= 512 depthwise threads: one per (observation, output column, 4 channels)).
 // WCH: the eight waves split as (8 / WCH pixel partitions) x (WCH channel partitions) in both matrix phases.
 //
-// WEIGHTS GO THROUGH LDS (round 6, second version).  The first version read a phase's A operands from global memory
-// into registers, every wave its own: 8 waves x 256 workgroups asking the same few L2 lines for 64-byte pieces — 4 k
-// requests per L2 channel and phase, 7 k + 3.3 k cycles of a 13.6 k cycle step waiting for them however early they were
-// requested (tools/dev/split_ticks.sh, profiles/r6/split_tile_v1.txt).  Now a chunk's weights are copied ONCE per
-// workgroup, as the MFMA operand fragments they will be used as (`global_load_lds`: lane (n, q) of fragment (tile, K
-// block, term) fetches its 16 bytes, they land lane-linear), while the depthwise runs:
-//   expand(c) | barrier | requests: projection weights of c, expansion weights and taps of c + 1 | depthwise(c) |
-//   wait for the own requests | barrier | project(c) | expand(c + 1) ...
+// WEIGHTS GO THROUGH LDS.  Version 1 read a phase's A operands from global memory into registers, every wave its own:
+// 8 waves x 256 workgroups asking the same few L2 lines for 64-byte pieces — ~4 k requests per L2 channel and phase, 7 k
+// + 3.3 k cycles of a 13.6 k cycle step waiting for them however early they were requested (tools/dev/split_ticks.sh,
+// profiles/r6/split_tile_v1.txt).  Version 2 copied a chunk's weights once per workgroup into LDS as operand fragments
+// (`__builtin_amdgcn_global_load_lds`, gathered from the weight planes by the waves without depthwise work — the
+// compiler puts `s_waitcnt vmcnt(0)` in front of the first LDS read that follows such a copy in program order, so a wave
+// that went on to the depthwise waited right there): 1626 -> 1259 us for the ten blocks, the steps still waiting 1.2-6.8 k
+// cycles for copies that had only the depthwise phase to land.  Version 3 (this one):
+//   * the host packs a chunk's operands as ONE contiguous record in the order they sit in LDS (`pack_split_tiles`:
+//     expansion fragments, projection fragments, 3 KB of taps / depthwise biases / expansion biases): a copy instruction
+//     moves 1 KB of consecutive bytes (8 full lines instead of 16 half lines);
+//   * the copies are issued from INLINE ASSEMBLY (the compiler's counter bookkeeping does not see them: no wait it did
+//     not mean; its own global loads only appear outside the chunk loop) by all eight waves, each the same number of
+//     instructions, and waited for with counted `s_waitcnt vmcnt(n)`:
+//       expand(c) | B1 | issue WE(c+1), TP(c+1) | depthwise(c) | wait WP(c) | B2 | project(c) | wait WE(c+1), TP(c+1) | B3 | issue WP(c+1)
+//     so every copy has two phases to land (the third barrier per step is what that costs).
 template <int HIN, int STRIDE, int CIN, int COUT, int G, int WCH>
 __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
   using Geo = SplitGeom<HIN, STRIDE, CIN, COUT, G>;
@@ -143,39 +151,30 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
   const int HID = a.HID;
   const int nch = HID / HC;
   const float* W = a.wbase + (size_t)(a.k0 + k) * a.model_stride;
-  const h16_t* Wsh = a.wsh + (size_t)(a.k0 + k) * a.model_stride;
-  const h16_t* Wsl = a.wsl + (size_t)(a.k0 + k) * a.model_stride;
+  const u32x4* const wcv = reinterpret_cast<const u32x4*>(a.wc + (size_t)(a.k0 + k) * a.wc_stride);  // [chunk][NFE + NFP + 3][64]
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  // requests.  The compiler puts `s_waitcnt vmcnt(0)` in front of the first LDS read that follows a `global_load_lds` in
-  // program order (it cannot tell the copy's destination from the rows that read addresses), so a wave that went on to
-  // the depthwise would wait for its copies right there.  The copies are therefore issued by the waves that have NO
-  // depthwise work (DWW .. 7: the depthwise occupies G * HOUT * 16 threads), which then wait for them and join the
-  // barrier.  Wave w issues the fragments w - DWW, + (8 - DWW), ...; fragment id = (tile * K blocks + K block) * 2 + term.
-  constexpr int DWW = (G * HOUT * 16 + 63) / 64, NDW = 8 - DWW;
-  static_assert(NDW >= 1, "a wave without depthwise work issues the weight copies");
-  auto dma_we = [&](int c, int w0, int nw) {
-    for (int id = w0; id < NFE; id += nw) {
-      const int term = id & 1, ks = (id >> 1) % KSX, ht = (id >> 1) / KSX;
-      const h16_t* src = (term ? Wsl : Wsh) + a.we_off + (size_t)(c * HC + 16 * ht + n) * CIN + 32 * ks + 8 * q;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(WE + (size_t)id * 64), 16, 0, 0);
-    }
+  // copies: fragment f of chunk c's record -> LDS (inline assembly, see the head of the kernel).  Every wave issues
+  // NFE / 8 + 1 instructions for (WE, TP) and NFP / 8 for WP: the waits below count on it.
+  constexpr int REC = NFE + NFP + 3;  // 1 KB pieces per chunk record
+  static_assert(NFE % 8 == 0 && NFP % 8 == 0, "every wave issues the same number of copies");
+  const unsigned lds_we = (unsigned)(size_t)(lds_ptr_t)WE, lds_wp = (unsigned)(size_t)(lds_ptr_t)WPj, lds_tp = (unsigned)(size_t)(lds_ptr_t)TP;
+  auto dma1 = [&](const u32x4* src, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(src + lane) : "memory");
   };
-  auto dma_wp = [&](int c, int w0, int nw) {
-    for (int id = w0; id < NFP; id += nw) {
-      const int term = id & 1, ks = (id >> 1) % NKP, ct = (id >> 1) / NKP;
-      const h16_t* src = (term ? Wsl : Wsh) + a.wp_off + (size_t)(16 * ct + n) * HID + c * HC + 32 * ks + 8 * q;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(WPj + (size_t)id * 64), 16, 0, 0);
-    }
-  };
-  auto dma_tp = [&](int c) {  // 160 lanes x 16 B: lane L fetches tap row L / 16 (9 = the biases), channels 4 (L % 16) ..; three copies
+  auto dma_we_tp = [&](int c) {
+    const u32x4* rec = wcv + (size_t)c * REC * 64;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int L = 64 * r + lane, t = L >> 4, i = L & 15;
-      const float* src = (t < 9 ? W + a.wd_off + (size_t)t * HID : W + a.bd_off) + c * HC + 4 * i;
-      if (L < 160) __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(TP + (size_t)(c & 1) * 768 + 256 * r), 16, 0, 0);
-    }
+    for (int i = 0; i < NFE / 8; ++i) dma1(rec + (size_t)(w + 8 * i) * 64, lds_we + (unsigned)(w + 8 * i) * 1024u);
+    const int r = w % 3;  // (three pieces; waves 3..7 repeat one: the same bytes to the same place, and the same count for every wave)
+    dma1(rec + (size_t)(NFE + NFP + r) * 64, lds_tp + (unsigned)(c & 1) * 3072u + (unsigned)r * 1024u);
   };
+  auto dma_wp = [&](int c) {
+    const u32x4* rec = wcv + ((size_t)c * REC + NFE) * 64;
+#pragma unroll
+    for (int i = 0; i < NFP / 8; ++i) dma1(rec + (size_t)(w + 8 * i) * 64, lds_wp + (unsigned)(w + 8 * i) * 1024u);
+  };
+  constexpr int N_WE_TP = NFE / 8 + 1;
 
 #ifdef RIP_SPLIT_TICKS
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -207,8 +206,7 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
 
     // the first chunk's expansion weights and taps (every wave is past the previous group's last expansion / depthwise:
     // they sit in front of that group's last two barriers)
-    dma_we(0, w, 8);
-    if (w == 7) dma_tp(0);
+    dma_we_tp(0);
     // block input of this wave's pixel tiles as two-term B operands, resident for all chunks
     u32x4 xh[TIN][KSX], xl[TIN][KSX];
     int erow[TIN];
@@ -240,8 +238,9 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
     for (int t = 0; t < TOUT; ++t)
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's requests have landed
-    lds_barrier();                       // ... and everybody's (also: the E zeroing of the prologue)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies have landed
+    lds_barrier();                                    // ... and everybody's (also: the E zeroing of the prologue)
+    dma_wp(0);  // (every wave is past the previous group's last projection)
     SPLIT_TICK(1);
 
 #pragma unroll 1
@@ -250,11 +249,7 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
       {
         float4 be[NHT];
 #pragma unroll
-        for (int ht = 0; ht < NHT; ++ht) {  // the bias of this lane's four channels: the taps' biases are the depthwise's; this one from global (L1 / L2)
-          int q_ = q;
-          asm volatile("" : "+v"(q_));
-          be[ht] = *reinterpret_cast<const float4*>(W + a.be_off + c * HC + 16 * (ht0 + ht) + 4 * q_);
-        }
+        for (int ht = 0; ht < NHT; ++ht) be[ht] = *reinterpret_cast<const float4*>(TP + (size_t)(c & 1) * 768 + 10 * 64 + 16 * (ht0 + ht) + 4 * q);
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht) {
           f32x4 v[TIN];
@@ -286,15 +281,9 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
       SPLIT_TICK(2);
       lds_barrier();
       SPLIT_TICK(3);
-      // requests that land under the depthwise: this chunk's projection weights (every wave is past project(c - 1)), the
-      // next chunk's expansion weights (every wave is past expand(c)) and taps (the other buffer)
-      if (w >= DWW) {
-        dma_wp(c, w - DWW, NDW);
-        if (c + 1 < nch) {
-          dma_we(c + 1, w - DWW, NDW);
-          if (w == 7) dma_tp(c + 1);
-        }
-      }
+      // copies that land under the depthwise and the projection: the next chunk's expansion weights (every wave is past
+      // expand(c)) and its taps / biases (the other buffer)
+      if (c + 1 < nch) dma_we_tp(c + 1);
       // ---------------- depthwise chunk c: E -> D (hi, lo) ----------------
       if (dw_on) {
         f32x2 wt[9][2], bd[2];
@@ -341,7 +330,10 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
         }
       }
       SPLIT_TICK(4);
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's weight / tap requests have landed
+      // this chunk's projection weights (requested behind the previous projection) have landed; the copies issued above may
+      // still be in flight (loads complete in order)
+      if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WE_TP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       SPLIT_TICK(5);
       // ---------------- project chunk c: D -> acc ----------------
@@ -375,8 +367,12 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
           }
       }
       SPLIT_TICK(6);
-      // (no barrier here: the next expansion writes E, which the depthwise is done with, and reads WE, published by the
-      // barrier above; the next requests / depthwise sit behind the barrier that follows that expansion)
+      if (c + 1 < nch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's expansion weights and taps have landed
+        lds_barrier();                                    // ... everybody's, and everybody is past this projection:
+        dma_wp(c + 1);                                    // its weights may be overwritten
+      }
+      SPLIT_TICK(7);
     }
 
     // ---------------- epilogue: 2^-8, bias (+ residual = block input), fp32 out ----------------
@@ -411,7 +407,7 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
         }
       }
     }
-    SPLIT_TICK(7);
+    SPLIT_TICK(1);
   }
 #ifdef RIP_SPLIT_TICKS
   if (tid == 0) {
@@ -473,10 +469,10 @@ hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_split_ticks), sizeof(t));
     const double n = t[8] > 0 ? (double)t[8] : 1.0, st = (double)(a.HID / HC) * (double)t[9] / n;
-    fprintf(stderr, "split tile<%d,%d,%d,%d,G%d,%d> cycles per workgroup (%.1f groups): prologue %.0f | per group: setup %.0f epilogue %.0f | per step (%d): "
-            "expand %.0f barrier %.0f depthwise %.0f barrier %.0f project %.0f\n",
-            HIN, STRIDE, CIN, COUT, G, WCH, t[9] / n, t[0] / n, t[1] / (double)t[9], t[7] / (double)t[9], a.HID / HC, t[2] / n / st, t[3] / n / st,
-            t[4] / n / st, t[5] / n / st, t[6] / n / st);
+    fprintf(stderr, "split tile<%d,%d,%d,%d,G%d,%d> cycles per workgroup (%.1f groups): prologue %.0f | per group: setup + epilogue %.0f | per step (%d): "
+            "expand %.0f barrier %.0f depthwise %.0f wait + barrier %.0f project %.0f wait + barrier %.0f\n",
+            HIN, STRIDE, CIN, COUT, G, WCH, t[9] / n, t[0] / n, t[1] / (double)t[9], a.HID / HC, t[2] / n / st, t[3] / n / st,
+            t[4] / n / st, t[5] / n / st, t[6] / n / st, t[7] / n / st);
     unsigned long long z[16] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_ticks), z, sizeof(z));
   }
@@ -496,15 +492,78 @@ bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp)
   return false;
 }
 
-hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w,
-                                 const unsigned short* enc_wsh, const unsigned short* enc_wsl, size_t model_stride, int k0,
-                                 int kc, int B, const float* x, float* y, hipStream_t s) {
+SplitTileLayout split_tile_layout(const EncoderPlan& plan) {
+  SplitTileLayout L;
+  L.off.assign(plan.blocks.size(), (size_t)-1);
+  size_t off = 0;
+  for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
+    const FusedBlock& fb = plan.blocks[bi];
+    const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
+    if (!irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) continue;
+    const int cin = le->cin, hid = plan.layers[fb.dw].cout, cout = plan.layers[fb.project].cout;
+    const size_t rec = (size_t)((HC / 16) * (cin / 32) * 2 + (cout / 16) * (HC / 32) * 2 + 3) * 512;  // binary16 elements per chunk record
+    L.off[bi] = off;
+    off += rec * (hid / HC);
+  }
+  L.total = off;
+  return L;
+}
+
+// One model's folded fp32 blob -> the chunk records of every tile block.  Record of chunk c (1 KB pieces, in LDS order):
+//   expansion fragments (ht, ks, term): lane (n, q), element j = We[64 c + 16 ht + n][32 ks + 8 q + j];
+//   projection fragments (ct, ks, term): Wp[16 ct + n][64 c + 32 ks + 8 q + j];
+//   (weights as w 2^8 split into hi = f16(.), lo = f16(. - hi): term 0 / 1)
+//   3 KB of fp32: depthwise taps [9][64], depthwise biases [64], expansion biases [64] of the chunk's channels (+ padding).
+void pack_split_tiles(const EncoderPlan& plan, const SplitTileLayout& L, const float* enc, unsigned short* out) {
+  auto put = [&](size_t idx, float wv, int term) {
+    const float v = wv * SPLIT_ENC_W_SCALE;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const _Float16 r = term ? lo : hi;
+    std::memcpy(&out[idx], &r, 2);
+  };
+  for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
+    if (L.off[bi] == (size_t)-1) continue;
+    const FusedBlock& fb = plan.blocks[bi];
+    const Layer &le = plan.layers[fb.expand], &ld = plan.layers[fb.dw], &lp = plan.layers[fb.project];
+    const int cin = le.cin, hid = ld.cout, cout = lp.cout, ksx = cin / 32, nctp = cout / 16;
+    const int nfe = (HC / 16) * ksx * 2, nfp = nctp * (HC / 32) * 2;
+    const size_t rec = (size_t)(nfe + nfp + 3) * 512;
+    for (int c = 0; c < hid / HC; ++c) {
+      size_t o = L.off[bi] + (size_t)c * rec;
+      for (int ht = 0; ht < HC / 16; ++ht)
+        for (int ks = 0; ks < ksx; ++ks)
+          for (int term = 0; term < 2; ++term)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j)
+                put(o++, enc[le.w_off + (size_t)(c * HC + 16 * ht + (lane & 15)) * cin + 32 * ks + 8 * (lane >> 4) + j], term);
+      for (int ct = 0; ct < nctp; ++ct)
+        for (int ks = 0; ks < HC / 32; ++ks)
+          for (int term = 0; term < 2; ++term)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j)
+                put(o++, enc[lp.w_off + (size_t)(16 * ct + (lane & 15)) * hid + c * HC + 32 * ks + 8 * (lane >> 4) + j], term);
+      float tp[768];
+      for (int i = 0; i < 768; ++i) tp[i] = 0.f;
+      for (int t = 0; t < 9; ++t)
+        for (int i = 0; i < HC; ++i) tp[t * HC + i] = enc[ld.w_off + (size_t)t * hid + c * HC + i];
+      for (int i = 0; i < HC; ++i) {
+        tp[9 * HC + i] = enc[ld.b_off + c * HC + i];
+        tp[10 * HC + i] = enc[le.b_off + c * HC + i];
+      }
+      std::memcpy(&out[o], tp, sizeof(tp));
+    }
+  }
+}
+
+hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wc,
+                                 size_t wc_stride, size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s) {
   SplitTileArgs a;
   a.x = x;
   a.y = y;
   a.wbase = enc_w;
-  a.wsh = enc_wsh;
-  a.wsl = enc_wsl;
+  a.wc = wc;
+  a.wc_stride = wc_stride;
   a.model_stride = model_stride;
   a.k0 = k0;
   a.we_off = le->w_off;

@@ -34,8 +34,9 @@ struct rip_handle {
   float* enc_wt = nullptr;  // [K][plan.blob_floats] the fp32 blob with the DEPTHWISE taps rounded to bf16 values (round 6): what the
                             // bf16 encoder reads its fp32 words from — "activations + weights bf16" (BASELINE configs[2]) for every
                             // convolution but the stem; biases and the stem's taps are the fp32 blob's
-  unsigned short* enc_ws = nullptr;  // [2][K][plan.blob_floats] binary16 (hi, lo) planes of the fp32 blob times 2^8: the two-term pointwise
-                                     // operands of the fp32 encoder's split-f16 tile blocks (encoder_split_tile.hip)
+  unsigned short* enc_wc = nullptr;  // [K][tile_layout.total] chunk records of the fp32 encoder's split-f16 tile blocks (encoder_split_tile.hip:
+                                     // two-term binary16 operand fragments of w * 2^8, taps, biases)
+  SplitTileLayout tile_layout;
   unsigned short* enc_wr = nullptr;  // [K][rows_layout.total] operand fragments of the split-f16 row-streaming blocks (encoder_split_rows.hip)
   SplitRowsLayout rows_layout;
   bool enc_split_ok[RIP_MAX_MODELS] = {false};  // the model's pointwise weights are inside SPLIT_ENC_W_LIMIT
@@ -245,10 +246,11 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     ALLOC(tmp, ((size_t)K * h->plan.blob_floats + 1) / 2);
     h->enc_wh = reinterpret_cast<unsigned short*>(tmp);
   }
+  h->tile_layout = split_tile_layout(h->plan);
   {
     float* tmp = nullptr;
-    ALLOC(tmp, (size_t)K * h->plan.blob_floats);  // two 2-byte planes
-    h->enc_ws = reinterpret_cast<unsigned short*>(tmp);
+    ALLOC(tmp, ((size_t)K * h->tile_layout.total + 1) / 2);
+    h->enc_wc = reinterpret_cast<unsigned short*>(tmp);
   }
   h->rows_layout = split_rows_layout(h->plan);
   {
@@ -313,7 +315,7 @@ int rip_destroy(rip_handle* h) {
   if (h->mega_status != nullptr) (void)hipHostFree(h->mega_status);
   if (h->mega_sync != nullptr) (void)hipFree(h->mega_sync);
   if (h->mega_arena != nullptr) (void)hipFree(h->mega_arena);
-  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), reinterpret_cast<float*>(h->enc_ws), reinterpret_cast<float*>(h->enc_wr), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
+  float* ptrs[] = {h->enc_w, h->enc_wt, reinterpret_cast<float*>(h->enc_wh), reinterpret_cast<float*>(h->enc_wc), reinterpret_cast<float*>(h->enc_wr), h->flow_w, h->mfma_w, reinterpret_cast<float*>(h->split_w), h->bufs[0], h->bufs[1], h->bufs[2], h->bufs[3], h->visual,
                    h->z,     h->plans,  h->loss_best, h->trace_loss, h->trace_x, reinterpret_cast<float*>(h->stats)};
   for (float* p : ptrs)
     if (p != nullptr) (void)hipFree(p);
@@ -446,24 +448,17 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
     HIP_TRY(hipMemcpy(h->enc_wt + (size_t)k * h->plan.blob_floats, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   {
-    // two-term binary16 planes of w * 2^8 (encoder.h: SPLIT_ENC_W_SCALE): hi = f16(256 w), lo = f16(256 w - hi)
-    std::vector<unsigned short> hi(enc.size()), lo(enc.size());
-    for (size_t i = 0; i < enc.size(); ++i) {
-      const float v = enc[i] * SPLIT_ENC_W_SCALE;
-      const _Float16 a = (_Float16)v;
-      const _Float16 b = (_Float16)(v - (float)a);
-      std::memcpy(&hi[i], &a, 2);
-      std::memcpy(&lo[i], &b, 2);
-    }
-    bool ok = true;  // only the pointwise layers are read from these planes
+    // the fp32 encoder's split-f16 blocks: two-term binary16 operands of w * 2^8 (encoder.h: SPLIT_ENC_W_SCALE), packed as the
+    // kernels read them; only the pointwise layers go through them
+    bool ok = true;
     for (const Layer& l : h->plan.layers) {
       if (l.kind != L_PW) continue;
       for (size_t i = 0; i < (size_t)l.cin * l.cout; ++i) ok = ok && std::fabs(enc[l.w_off + i]) < SPLIT_ENC_W_LIMIT;  // (false for NaN)
     }
     h->enc_split_ok[k] = ok;
-    const size_t plane = (size_t)h->K * h->plan.blob_floats;
-    HIP_TRY(hipMemcpy(h->enc_ws + (size_t)k * h->plan.blob_floats, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->enc_ws + plane + (size_t)k * h->plan.blob_floats, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    std::vector<unsigned short> rec(h->tile_layout.total);
+    pack_split_tiles(h->plan, h->tile_layout, enc.data(), rec.data());
+    HIP_TRY(hipMemcpy(h->enc_wc + (size_t)k * h->tile_layout.total, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
     std::vector<unsigned short> frag(h->rows_layout.total);
     pack_split_rows(h->plan, h->rows_layout, enc.data(), frag.data());
     HIP_TRY(hipMemcpy(h->enc_wr + (size_t)k * h->rows_layout.total, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
@@ -510,12 +505,12 @@ int rip_encoder_status(rip_handle* h) {
   return *h->mega_status;
 }
 
-// The two-term binary16 weight planes of the fp32 encoder's split-f16 tile blocks, or NULLs (layer-wise fp32 kernels):
+// The packed two-term binary16 operands of the fp32 encoder's split-f16 blocks, or NULLs (layer-wise fp32 kernels):
 // every model of the launch must be inside the operand range, and RIP_OPT_ENCODER_VARIANT bit 16 turns the blocks off.
 struct SplitPlanes {
-  const unsigned short* hi = nullptr;
-  const unsigned short* lo = nullptr;
-  const unsigned short* rows = nullptr;  // operand fragments of the row-streaming blocks
+  const unsigned short* tiles = nullptr;  // chunk records of the tile blocks
+  size_t tiles_stride = 0;
+  const unsigned short* rows = nullptr;   // operand fragments of the row-streaming blocks
   size_t rows_stride = 0;
 };
 static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
@@ -523,8 +518,8 @@ static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
   if (h->encoder_variant & ENC_VAR_FP32_LAYERWISE) return sp;
   for (int k = k_begin; k < k_begin + k_count; ++k)
     if (!h->enc_split_ok[k]) return sp;
-  sp.hi = h->enc_ws;
-  sp.lo = h->enc_ws + (size_t)h->K * h->plan.blob_floats;
+  sp.tiles = h->enc_wc;
+  sp.tiles_stride = h->tile_layout.total;
   sp.rows = h->enc_wr;
   sp.rows_stride = h->rows_layout.total;
   return sp;
@@ -553,7 +548,7 @@ int rip_encode(rip_handle* h, const float* visual_dev, const float* vec_dev, int
   }
   const SplitPlanes sp = split_planes(h, k_begin, k_count);
   HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, vec_dev, B, h->bufs, z_dev, feat_dev,
-                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, nullptr, sp.hi, sp.lo, sp.rows, sp.rows_stride));
+                         h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, nullptr, sp.tiles, sp.tiles_stride, sp.rows, sp.rows_stride));
   return RIP_OK;
 }
 
@@ -588,7 +583,7 @@ int rip_encode_tap_k(rip_handle* h, const float* visual_dev, int B, int k_begin,
   else {
     const SplitPlanes sp = split_planes(h, k_begin, k_count);  // the same kernel selection as rip_encode
     HIP_TRY(launch_encoder(h->plan, h->enc_w, k_begin, k_count, visual_dev, nullptr, B, h->bufs, nullptr, nullptr,
-                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap, sp.hi, sp.lo, sp.rows, sp.rows_stride));
+                           h->encoder_fused >= 0 ? h->encoder_fused : (B >= 8 ? 3 : 0), (hipStream_t)stream, &tap, sp.tiles, sp.tiles_stride, sp.rows, sp.rows_stride));
   }
   if (!tap.served)
     return fail(RIP_EINVAL, "layer %d is inside a fused block under the current RIP_OPT_ENCODER_FUSED setting / kernel selection: its output "
