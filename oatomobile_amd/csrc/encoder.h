@@ -172,8 +172,13 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
 bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp);
 struct SplitTileLayout {
   std::vector<size_t> off;  // per plan block: offset (binary16 elements) of its chunk records in a model's blob; (size_t)-1 = not a tile block
+  size_t head_off = (size_t)-1;  // features.18's chunk records (head_split_kernel)
   size_t total = 0;         // binary16 elements per model
 };
+// features.18 + the 4x4 average pool on two-term binary16 operands (encoder_split_tile.hip: head_split_kernel)
+bool head_split_supported(const Layer& l, int final_hw);
+hipError_t launch_head_split(const Layer& l, const unsigned short* wc, size_t wc_stride, int k0, int kc, int B, const float* x,
+                             float* y, hipStream_t s);
 SplitTileLayout split_tile_layout(const EncoderPlan& plan);
 void pack_split_tiles(const EncoderPlan& plan, const SplitTileLayout& L, const float* enc_blob, unsigned short* out);
 hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& lp, const float* enc_w, const unsigned short* wc,

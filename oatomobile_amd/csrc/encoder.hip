@@ -1244,7 +1244,12 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       const int M = B * l.h_out * l.h_out;
       const float* res = l.residual ? bufs[l.res] : nullptr;
       const bool pool = li + 1 == plan.layers.size() && plan.final_hw == 4;  // features.18: fuse the 4x4 average pool
-      dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, pool, s);
+      if (pool && split_tiles && head_split_supported(l, plan.final_hw)) {
+        hipError_t e = launch_head_split(l, enc_wc + split_tile_layout(plan).head_off, wc_stride, k0, kc, B, (const float*)bufs[l.src], dst, s);
+        if (e != hipSuccess) return e;
+      } else {
+        dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, pool, s);
+      }
     }
     if (tapped(li)) return hipGetLastError();
   }

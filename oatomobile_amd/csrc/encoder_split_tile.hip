@@ -480,7 +480,151 @@ hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// features.18 (1x1, 320 -> 1280, ReLU6) + the 4x4 average pool of the fp32 encoder in the same number format: the last
+// true-fp32 GEMM of the fp32 mode (`pw_kernel` with the pooled epilogue, 285 us at 512 observations x 4 models).
+// A wave owns ONE observation (its 16 pixels = one MFMA pixel tile; block input resident as two-term B operands, 80
+// registers); the 1280 output channels stream through LDS in chunks of 32 (`pack_split_tiles`: 40 KB of operand
+// fragments + the biases per chunk, one contiguous record), three buffers deep: the copy of chunk c + 2 is issued (inline
+// assembly, all eight waves, six instructions each) where chunk c starts.  Epilogue per chunk: 2^-8, bias, ReLU6, mean
+// over the tile's 16 pixels (a butterfly over the 16 lanes of a row), one float4 per (observation, 4 channels).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int HD_CIN = 320, HD_COUT = 1280, HD_CH = 32, HD_KS = HD_CIN / 32, HD_NF = (HD_CH / 16) * HD_KS * 2, HD_REC = HD_NF + 1;
+constexpr int HD_NCH = HD_COUT / HD_CH, HD_G = 8;
+constexpr size_t HD_LDS = (size_t)3 * HD_REC * 1024;
+
+struct HeadArgs {
+  const float* x;    // [K][B][16][320] fp32
+  float* y;          // [K][B][1280] fp32 (pooled)
+  const h16_t* wc;   // the head's chunk records of model 0, models wc_stride binary16 elements apart
+  size_t wc_stride;
+  int k0, B;
+};
+
+__global__ __launch_bounds__(512) void head_split_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* const WB = reinterpret_cast<u32x4*>(smem_raw);  // [3][HD_REC][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.z;
+  const u32x4* const wcv = reinterpret_cast<const u32x4*>(a.wc + (size_t)(a.k0 + k) * a.wc_stride);  // [chunk][HD_REC][64]
+  const unsigned lds_wb = (unsigned)(size_t)(lds_ptr_t)WB;
+  static_assert(HD_NF % 8 == 0, "every wave issues the same number of copies");
+  constexpr int N_DMA = HD_NF / 8 + 1;
+  auto dma_chunk = [&](int c) {
+    const u32x4* rec = wcv + (size_t)c * HD_REC * 64;
+    const unsigned dst = lds_wb + (unsigned)(c % 3) * (unsigned)(HD_REC * 1024);
+#pragma unroll
+    for (int i = 0; i < HD_NF / 8; ++i) {
+      const int f = w + 8 * i;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst + (unsigned)f * 1024u), "v"(rec + (size_t)f * 64 + lane) : "memory");
+    }
+    // (the biases' piece by every wave: the same bytes to the same place, and the same count for every wave)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst + (unsigned)HD_NF * 1024u), "v"(rec + (size_t)HD_NF * 64 + lane) : "memory");
+  };
+  const int n_groups = (a.B + HD_G - 1) / HD_G;
+#pragma unroll 1
+  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int img = g * HD_G + w;
+    const bool on = img < a.B;
+    dma_chunk(0);
+    dma_chunk(1);
+    u32x4 xh[HD_KS], xl[HD_KS];
+    {
+      const float* xp = a.x + (((size_t)k * a.B + (on ? img : 0)) * 16 + n) * HD_CIN + 8 * q;
+#pragma unroll
+      for (int ks = 0; ks < HD_KS; ++ks) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (on) {
+          v0 = *reinterpret_cast<const f32x4*>(xp + 32 * ks);
+          v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 4);
+        }
+        const u32x2 s0 = split2(f32x2{v0[0], v0[1]}), s1 = split2(f32x2{v0[2], v0[3]});
+        const u32x2 s2 = split2(f32x2{v1[0], v1[1]}), s3 = split2(f32x2{v1[2], v1[3]});
+        xh[ks] = u32x4{s0.x, s1.x, s2.x, s3.x};
+        xl[ks] = u32x4{s0.y, s1.y, s2.y, s3.y};
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    float* yp = a.y + ((size_t)k * a.B + (on ? img : 0)) * HD_COUT + 4 * q;
+#pragma unroll 1
+    for (int c = 0; c < HD_NCH; ++c) {
+      if (c + 2 < HD_NCH) dma_chunk(c + 2);  // (its buffer was chunk c - 1's: every wave is behind the barrier that ended it)
+      const u32x4* wb = WB + (size_t)(c % 3) * HD_REC * 64;
+      f32x4 acc[2][3];
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[ht][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD_KS; ++ks)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+          const u32x4 ah = wb[(size_t)((ht * HD_KS + ks) * 2) * 64 + lane], al = wb[(size_t)((ht * HD_KS + ks) * 2 + 1) * 64 + lane];
+          acc[ht][0] = mfmah(al, xh[ks], acc[ht][0]);  // one accumulator per term: six independent chains
+          acc[ht][1] = mfmah(ah, xl[ks], acc[ht][1]);
+          acc[ht][2] = mfmah(ah, xh[ks], acc[ht][2]);
+        }
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht) {
+        const float4 bb = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wb + (size_t)HD_NF * 64) + 16 * ht + 4 * q);
+        const f32x4 s4 = acc[ht][2] + (acc[ht][0] + acc[ht][1]);  // (small terms first)
+        f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{s4[0], s4[1]}, f32x2{W_INV, W_INV}, f32x2{bb.x, bb.y}));
+        f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{s4[2], s4[3]}, f32x2{W_INV, W_INV}, f32x2{bb.z, bb.w}));
+        float r[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // sum over the 16 pixels = the 16 lanes n of this q
+          r[e] += __shfl_xor(r[e], 1);
+          r[e] += __shfl_xor(r[e], 2);
+          r[e] += __shfl_xor(r[e], 4);
+          r[e] += __shfl_xor(r[e], 8);
+        }
+        if (on && n == 0)
+          *reinterpret_cast<f32x4*>(yp + HD_CH * c + 16 * ht) = f32x4{r[0] * 0.0625f, r[1] * 0.0625f, r[2] * 0.0625f, r[3] * 0.0625f};
+      }
+      // chunk c + 1 (requested where chunk c - 1 started) has landed; the six copies issued above may still be in flight
+      // (loads complete in order; this wave's stores only make the wait longer)
+      if (c + 2 < HD_NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+    }
+  }
+}
+
 }  // namespace
+
+bool head_split_supported(const Layer& l, int final_hw) {
+  return l.kind == L_PW && l.cin == HD_CIN && l.cout == HD_COUT && l.h_in == 4 && final_hw == 4 && l.relu6 && !l.residual;
+}
+
+hipError_t launch_head_split(const Layer& l, const unsigned short* wc, size_t wc_stride, int k0, int kc, int B, const float* x,
+                             float* y, hipStream_t s) {
+  (void)l;
+  HeadArgs a;
+  a.x = x;
+  a.y = y;
+  a.wc = wc;
+  a.wc_stride = wc_stride;
+  a.k0 = k0;
+  a.B = B;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HD_LDS);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  const int n_groups = (B + HD_G - 1) / HD_G;
+  int gx = device_cu_count() / kc;
+  if (gx < 1) gx = 1;
+  if (gx > n_groups) gx = n_groups;
+  note_kernel(dim3(gx, 1, kc), dim3(512), "head_split_kernel");
+  hipLaunchKernelGGL(head_split_kernel, dim3(gx, 1, kc), dim3(512), HD_LDS, s, a);
+  return hipGetLastError();
+}
 
 bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp) {
   if (le == nullptr) return false;
@@ -504,6 +648,11 @@ SplitTileLayout split_tile_layout(const EncoderPlan& plan) {
     const size_t rec = (size_t)((HC / 16) * (cin / 32) * 2 + (cout / 16) * (HC / 32) * 2 + 3) * 512;  // binary16 elements per chunk record
     L.off[bi] = off;
     off += rec * (hid / HC);
+  }
+  const Layer& last = plan.layers.back();
+  if (head_split_supported(last, plan.final_hw)) {
+    L.head_off = off;
+    off += (size_t)HD_NCH * HD_REC * 512;
   }
   L.total = off;
   return L;
@@ -552,6 +701,21 @@ void pack_split_tiles(const EncoderPlan& plan, const SplitTileLayout& L, const f
         tp[10 * HC + i] = enc[le.b_off + c * HC + i];
       }
       std::memcpy(&out[o], tp, sizeof(tp));
+    }
+  }
+  if (L.head_off != (size_t)-1) {  // features.18: chunk c = output channels 32 c ..: fragments (ht, ks, term), then 1 KB with the 32 biases
+    const Layer& l = plan.layers.back();
+    for (int c = 0; c < HD_NCH; ++c) {
+      size_t o = L.head_off + (size_t)c * HD_REC * 512;
+      for (int ht = 0; ht < HD_CH / 16; ++ht)
+        for (int ks = 0; ks < HD_KS; ++ks)
+          for (int term = 0; term < 2; ++term)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j)
+                put(o++, enc[l.w_off + (size_t)(c * HD_CH + 16 * ht + (lane & 15)) * HD_CIN + 32 * ks + 8 * (lane >> 4) + j], term);
+      float bb[256];
+      for (int i = 0; i < 256; ++i) bb[i] = i < HD_CH ? enc[l.b_off + c * HD_CH + i] : 0.f;
+      std::memcpy(&out[o], bb, sizeof(bb));
     }
   }
 }

@@ -201,12 +201,13 @@ def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
   assert sum(l.startswith("irb_split_tile_kernel") for l in log) == 10, log
   assert sum(l.startswith("irb_split_rows_kernel") for l in log) == 6, log  # features.2-7
   assert sum(l.startswith("front_split_kernel<2>") for l in log) == 1 and not any(l.startswith(("stem_kernel", "irb_kernel")) for l in log), log
+  assert sum(l.startswith("head_split_kernel") for l in log) == 1 and not any(l.startswith(("pw_kernel", "dw_kernel")) for l in log), log  # features.18 + pool
   zo = O.params(mo, **{k: v.cpu() for k, v in ctx.items()}).numpy()
   print("fp32 encoder with split-f16 tile blocks vs fp32 oracle (40 observations): max|dz| = %.3g of max|z| = %.3g" % (np.abs(z - zo).max(), np.abs(zo).max()))
   np.testing.assert_allclose(z, zo, atol=TOL)
   m._handle().set_option(_lib.OPT_ENCODER_VARIANT, _lib.ENC_VAR_FP32_LAYERWISE)
   z_lw = m._params(**ctx).cpu().numpy()
-  assert not any(l.startswith(("irb_split_", "front_split_")) for l in m._handle().kernel_log())
+  assert not any(l.startswith(("irb_split_", "front_split_", "head_split_")) for l in m._handle().kernel_log())
   print("   the layer-wise fp32 kernels on the same observations: max|dz| = %.3g" % np.abs(z_lw - zo).max())
 
   K, B, C = 3, 601, 2
@@ -230,7 +231,7 @@ def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
   tiles = [l for l in log_s if l.startswith("irb_split_tile_kernel")]
   assert len(tiles) == 10 and {l.split(" ")[1] for l in tiles} == {"G=3", "G=4", "G=2"}, tiles
   assert sum(l.startswith("irb_split_rows_kernel") for l in log_s) == 6, log_s
-  assert not any(l.startswith(("irb_split_", "front_split_")) for l in log_l)
+  assert not any(l.startswith(("irb_split_", "front_split_", "head_split_")) for l in log_l)
   assert np.isfinite(z_s).all()
   d = np.abs(z_s - z_l).max()
   print("K = 3 x B = 601, split-f16 tile blocks vs layer-wise fp32: max|dz| = %.3g of max|z| = %.3g" % (d, np.abs(z_l).max()))
