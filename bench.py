@@ -608,10 +608,10 @@ def main():
               "encoder_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in e32])),
               "bf16_vs_fp32_plan_deviation_m": {"max_abs": float((plan - p32).abs().max()), "mean_abs": float((plan - p32).abs().mean()),
                                                 "plan_scale_m": scale},
-              "encoder_kernels": "fp32 activations; stem + features.1 / features.2-7 / features.8-17 as fused blocks whose pointwise "
-                                 "convolutions run on the binary16 matrix pipe with two-term operands (fp32-grade: z against the "
-                                 "fp32 oracle 1.5e-5, the true-fp32 layer-wise kernels 1.7e-5), depthwise and stem fp32 on the "
-                                 "vector unit; features.18 and the head true fp32 MFMA",
+              "encoder_kernels": "fp32 activations; stem + features.1 / features.2-7 / features.8-17 / features.18 + pool as fused kernels "
+                                 "whose pointwise convolutions run on the binary16 matrix pipe with two-term operands (fp32-grade: z "
+                                 "against the fp32 oracle 1.65e-5, the true-fp32 layer-wise kernels 1.68e-5), depthwise and stem "
+                                 "fp32 on the vector unit; classifier and merger true fp32",
               "note": "the same whole-unit step with the fp32 encoder: the mode in which z, plans and log-probs hold the "
                       "1e-4 parity contract.  `bf16_vs_fp32_plan_deviation_m`: what the bf16 encoder of `value` (the "
                       "precision BASELINE configs[2] names) moves the winning plans by on this batch"}
