@@ -195,6 +195,35 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
   const int ng = (n_groups - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
   auto tile_on = [&](int t, int npt) { return !(WP * t + WP - 1 >= npt && wpix + WP * t >= npt); };  // compile-time but for the last t
 
+  // The block input of group j + 1 is requested (raw fp32, unconditional clamped addresses: a fixed number of loads, the
+  // counted wait below relies on it) where the LAST chunk of group j enters its depthwise, and split where group j + 1
+  // starts: a first-touch HBM request takes 3-4 k cycles here, which used to stand in front of every group.
+  // The raw values land in the registers of the two-term operands themselves (xh = first four channels, xl = the other
+  // four, as bits): those are dead behind the group's last expansion, a second register set would not fit.
+  constexpr int N_X = TIN * KSX * 2;
+  u32x4 xh[TIN][KSX], xl[TIN][KSX];
+  auto request_x = [&](int jn) {
+    const int img0n = ((int)blockIdx.x + jn * (int)gridDim.x) * a.G;
+    const int m_inn = min(a.G, a.B - img0n) * HWI;
+    const float* xgn = a.x + ((size_t)k * a.B + img0n) * HWI * CIN;
+    int n_ = n, q_ = q;  // (opaque copies: the per-lane offsets are group-invariant and would be hoisted and spilled)
+    asm volatile("" : "+v"(n_), "+v"(q_));
+#pragma unroll
+    for (int t = 0; t < TIN; ++t) {
+      const int px = 16 * (wpix + WP * t) + n_;
+      const float* p = xgn + (size_t)(px < m_inn ? px : 0) * CIN + 8 * q_;
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) {
+        xh[t][ks] = *reinterpret_cast<const u32x4*>(p + 32 * ks);
+        xl[t][ks] = *reinterpret_cast<const u32x4*>(p + 32 * ks + 4);
+      }
+    }
+  };
+  if (ng > 0) {
+    request_x(0);
+    dma_we_tp(0);  // (behind the prologue's barrier?  no LDS reader yet: E is zeroed, WE / TP are not read before the group's first barrier)
+  }
+
 #pragma unroll 1
   for (int j = 0; j < ng; ++j) {
     const int img0 = ((int)blockIdx.x + j * (int)gridDim.x) * a.G;
@@ -204,25 +233,23 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
     float* yg = a.y + ((size_t)k * a.B + img0) * HWO * COUT;
     const bool dw_on = dimg < G && dimg * HWI < m_in;
 
-    // the first chunk's expansion weights and taps (every wave is past the previous group's last expansion / depthwise:
-    // they sit in front of that group's last two barriers)
-    dma_we_tp(0);
+    // (the first chunk's expansion weights and taps were requested behind the previous group's last depthwise, or in
+    // front of the group loop)
     // block input of this wave's pixel tiles as two-term B operands, resident for all chunks
-    u32x4 xh[TIN][KSX], xl[TIN][KSX];
     int erow[TIN];
     {
-      int n_ = n, q_ = q;  // (opaque copies: the per-lane offsets are group-invariant and would be hoisted and spilled)
-      asm volatile("" : "+v"(n_), "+v"(q_));
+      int n_ = n;
+      asm volatile("" : "+v"(n_));
 #pragma unroll
       for (int t = 0; t < TIN; ++t) {
         const int px = 16 * (wpix + WP * t) + n_;
         const bool on = px < m_in;
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
-          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-          if (on) {
-            v0 = *reinterpret_cast<const f32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q_);
-            v1 = *reinterpret_cast<const f32x4*>(xg + (size_t)px * CIN + 32 * ks + 8 * q_ + 4);
+          f32x4 v0 = __builtin_bit_cast(f32x4, xh[t][ks]), v1 = __builtin_bit_cast(f32x4, xl[t][ks]);
+          if (!on) {  // (a lane without a pixel read pixel 0's values)
+            v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            v1 = f32x4{0.f, 0.f, 0.f, 0.f};
           }
           const u32x2 s0 = split2(f32x2{v0[0], v0[1]}), s1 = split2(f32x2{v0[2], v0[3]});
           const u32x2 s2 = split2(f32x2{v1[0], v1[1]}), s3 = split2(f32x2{v1[2], v1[3]});
@@ -284,6 +311,8 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
       // copies that land under the depthwise and the projection: the next chunk's expansion weights (every wave is past
       // expand(c)) and its taps / biases (the other buffer)
       if (c + 1 < nch) dma_we_tp(c + 1);
+      const bool x_ahead = c + 1 == nch && j + 1 < ng;
+      if (x_ahead) request_x(j + 1);
       // ---------------- depthwise chunk c: E -> D (hi, lo) ----------------
       if (dw_on) {
         f32x2 wt[9][2], bd[2];
@@ -333,9 +362,11 @@ __global__ __launch_bounds__(512) void irb_split_tile_kernel(SplitTileArgs a) {
       // this chunk's projection weights (requested behind the previous projection) have landed; the copies issued above may
       // still be in flight (loads complete in order)
       if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WE_TP) : "memory");
+      else if (x_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_X) : "memory");  // (the next group's block input stays in flight)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       SPLIT_TICK(5);
+      if (x_ahead) dma_we_tp(0);  // the NEXT group's first chunk (its model's, the same): WE and both tap buffers are free behind this barrier
       // ---------------- project chunk c: D -> acc ----------------
       {
         u32x4 bh[TOUT][NKP], bl[TOUT][NKP];  // (a ragged group's missing pixels read rows of D nobody wrote: never stored)
