@@ -238,6 +238,11 @@ def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
   assert d <= TOL
   z_r, _ = encode(0, B - 1)
   np.testing.assert_array_equal(z_r, z_s[:, :B - 1])
+  # a launch that starts in the middle of the handle's models (k_begin = 1: the packed operand blobs are indexed per model)
+  zz = torch.full((2, B, 64), float("nan"), device=dev)
+  _lib.check(lib.rip_encode(h.raw, _lib.ptr(vis), _lib.ptr(vec), B, 1, 2, _lib.ENC_DTYPES["fp32"], _lib.ptr(zz), None, h.stream()))
+  assert sum(l.startswith(("irb_split_", "front_split_", "head_split_")) for l in h.kernel_log()) == 18
+  np.testing.assert_array_equal(zz.cpu().numpy(), z_s[1:3])
   # every block output (the selection differs in features.8-17 only; the inputs of a block differ by the blocks before it)
   layers = arch.conv_layers(C)
   worst = 0.0
