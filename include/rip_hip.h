@@ -309,7 +309,7 @@ int rip_train_num_layers(const rip_trainer* t);
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0 — and,
- *     round 6, from 32 (model, observation) pairs per call whatever the count: stem + features.1, features.2-7 and
+ *     round 6, from 64 (model, observation) pairs per call whatever the count: stem + features.1, features.2-7 and
  *     features.8-17 as split-f16 blocks (fp32 activations, pointwise convolutions as three binary16 MFMAs on two-term
  *     operands, depthwise / stem fp32: fp32-grade, z within 2e-5 of the fp32 oracle like the true-fp32 kernels), unless
  *     a model's pointwise weights reach 240 in magnitude or RIP_OPT_ENCODER_VARIANT bit 16 is set.

@@ -33,8 +33,13 @@ enum {
 // a model whose pointwise weights reach this magnitude keeps the layer-wise fp32 kernels (binary16 max 65504 / 2^8).
 constexpr float SPLIT_ENC_W_SCALE = 256.0f;
 constexpr float SPLIT_ENC_W_LIMIT = 240.0f;
-// (model, observation) pairs from which the split-f16 tile blocks replace the layer-wise fp32 launches
-constexpr int SPLIT_TILE_MIN_PAIRS = 32;
+// (model, observation) pairs from which the split-f16 TILE blocks and head replace the layer-wise fp32 launches: they walk an
+// observation serially (one workgroup each up to 256 pairs: ~0.3 ms for features.8-18 whatever the launch size), which the
+// layer-wise kernels beat on small launches.  The ROW-STREAMING blocks and the front cut an observation into row bands when the
+// launch is small and win at every size (profiles/r6/fp32_crossover_v1.txt: one observation x 4 models 245 -> 220 us, 8
+// observations 457 -> 324; with the tile blocks as well 459 / 481 us there, 545 against 602 at 32 observations).
+constexpr int SPLIT_TILE_MIN_PAIRS = 96;
+constexpr int SPLIT_ROWS_MIN_PAIRS = 1;
 
 // Workgroup barrier for kernels whose waves talk to each other through LDS only.  `__syncthreads()` is a workgroup-scope
 // release / acquire fence over ALL address spaces: the compiler puts `s_waitcnt vmcnt(0)` in front of the s_barrier, so

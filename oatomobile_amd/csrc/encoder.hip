@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace rip {
@@ -1189,16 +1190,20 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
   // row-streaming block (which takes features.2 / 3 over from the fused fp32 kernel when the launch is large enough)
   std::vector<char> in_block(plan.layers.size(), 0);
   std::vector<int> block_of(plan.layers.size(), -1);
-  const bool split_tiles = enc_wc != nullptr && (long)B * kc >= SPLIT_TILE_MIN_PAIRS;
+  // (development: RIP_SPLIT_TILE_MIN / RIP_SPLIT_ROWS_MIN override the two thresholds, tools/dev/fp32_cross.sh)
+  static const int tile_min = getenv("RIP_SPLIT_TILE_MIN") ? atoi(getenv("RIP_SPLIT_TILE_MIN")) : SPLIT_TILE_MIN_PAIRS;
+  static const int rows_min = getenv("RIP_SPLIT_ROWS_MIN") ? atoi(getenv("RIP_SPLIT_ROWS_MIN")) : SPLIT_ROWS_MIN_PAIRS;
+  const bool split_tiles = enc_wc != nullptr && (long)B * kc >= tile_min;
+  const bool split_rows = enc_wr != nullptr && (long)B * kc >= rows_min;
   for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
     int how = 0;
-    if (split_tiles && enc_wr != nullptr && bi == 0 && fb.expand < 0 && fb.dw == 1 &&
+    if (split_rows && bi == 0 && fb.expand < 0 && fb.dw == 1 &&
         front_split_supported(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project])) {
       how = 5;  // stem + features.1 in one kernel: the stem layer is interior to it
       in_block[0] = 1;
-    } else if (split_tiles && enc_wr != nullptr && irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 4;
+    } else if (split_rows && irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 4;
     else if ((int)bi < fused_blocks) how = 2;
     else if (split_tiles && fb.src != fb.dst && irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 3;
     if (how == 0) continue;

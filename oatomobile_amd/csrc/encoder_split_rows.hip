@@ -103,6 +103,7 @@ struct RowsArgs {
   int k0;
   size_t be_off, wd_off, bd_off, bp_off;
   int B, residual;
+  int NB;  // row bands per observation (small launches: a workgroup walks (observation, band) items; a band = a run of steps)
 };
 
 template <int HIN, int S, int CIN, int HID, int COUT>
@@ -208,25 +209,48 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
       xl[t] = u32x4{s0.y, s1.y, s2.y, s3.y};
     }
   };
-  int b = blockIdx.x;
-  if (b < a.B) request_x(b, 0);
+  // Work items = (observation, band of steps).  One band per observation when the launch fills the device; a small launch
+  // cuts an observation into NB bands (launcher: `pick_bands`) so that its rows are streamed by NB workgroups at once.  A
+  // band that does not start at the top runs the step in front of it as a WARM-UP: expansion only, which leaves the 3 - S
+  // rows its first step shares with that step in the ring.
+  const int NB = a.NB, SPB = (NS + NB - 1) / NB, n_items = a.B * NB;
+  auto item_of = [&](int item, int& b_, int& s0_, int& s1_, int& sa_) {
+    b_ = item / NB;
+    s0_ = (item - b_ * NB) * SPB;
+    s1_ = s0_ + SPB < NS ? s0_ + SPB : NS;
+    sa_ = s0_ > 0 ? s0_ - 1 : 0;
+  };
+  int item = blockIdx.x;
+  {
+    int b_, s0_, s1_, sa_;
+    item_of(item < n_items ? item : 0, b_, s0_, s1_, sa_);
+    if (item < n_items) request_x(b_, sa_);
+  }
   split_x();
 #pragma unroll 1
-  for (; b < a.B; b += gridDim.x) {
-    // the ring slot of input row -1 is a zero row (slot R - 1; the last depthwise of the previous observation is behind its barrier)
-    for (int e = tid; e < PW * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E + (size_t)(R - 1) * PW * LDE)[e] = zero4;
+  for (; item < n_items; item += gridDim.x) {
+    int b, s0, s1, sa;
+    item_of(item, b, s0, s1, sa);
+    // the ring slot of input row -1 is a zero row (slot R - 1; the last depthwise of the previous item is behind its barrier)
+    if (s0 == 0)
+      for (int e = tid; e < PW * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E + (size_t)(R - 1) * PW * LDE)[e] = zero4;
     float* yb = a.y + ((size_t)k * a.B + b) * HOUT * HOUT * COUT;
     const float* xb = a.x + ((size_t)k * a.B + b) * HIN * W * CIN;
     ROWS_TICK(1);
 #pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
+    for (int s = sa; s < s1; ++s) {
+      const bool warm = s < s0;
       // ---------------- expand the input rows s NRI .. s NRI + NRI - 1 -> E ring ----------------
-      // (xh / xl hold this step's rows; the next step's — or the next observation's first — are requested now)
-      if (s + 1 < NS) request_x(b, s + 1);
-      else if (b + (int)gridDim.x < a.B) request_x(b + (int)gridDim.x, 0);
+      // (xh / xl hold this step's rows; the next step's — or the next item's first — are requested now)
+      if (s + 1 < s1) request_x(b, s + 1);
+      else if (item + (int)gridDim.x < n_items) {
+        int b_, s0_, s1_, sa_;
+        item_of(item + (int)gridDim.x, b_, s0_, s1_, sa_);
+        request_x(b_, sa_);
+      }
       const int ob = S == 1 ? 2 * s - 1 : 2 * s;  // output rows of this step: ob, ob + 1
       f32x4 res = {0.f, 0.f, 0.f, 0.f};              // the projection's residual, requested a step's length ahead
-      const bool pj_on = pj_wave && pj_j < NOP && ob + pj_orow >= 0 && ob + pj_orow < HOUT && pj_ch < COUT;
+      const bool pj_on = !warm && pj_wave && pj_j < NOP && ob + pj_orow >= 0 && ob + pj_orow < HOUT && pj_ch < COUT;
       if (a.residual && pj_on) res = *reinterpret_cast<const f32x4*>(xb + ((size_t)(ob + pj_orow) * W + pj_ox) * CIN + pj_ch);  // (CIN == COUT, S == 1)
       int eoff[TIN];
       bool in_map[TIN];
@@ -281,6 +305,10 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
           }
       }
       ROWS_TICK(2);
+      if (warm) {  // (uniform) the rows are in the ring; the first real step's barrier orders them in front of its depthwise
+        split_x();
+        continue;
+      }
       lds_barrier();
       ROWS_TICK(3);
       // ---------------- depthwise: output rows ob, ob + 1 -> D (hi, lo) ----------------
@@ -353,6 +381,24 @@ __global__ __launch_bounds__(512) void irb_split_rows_kernel(RowsArgs a) {
 #endif
 }
 
+// Row bands per observation: `slots` resident workgroups walk B * bands items; an item costs its steps plus one warm-up step
+// when the observation is cut.  The count that minimises rounds x (steps + warm-up); ties go to fewer bands.
+int pick_bands(int B, int steps, int slots) {
+  int best = 1;
+  long best_cost = -1;
+  for (int nb = 1; nb <= steps; ++nb) {
+    const int spb = (steps + nb - 1) / nb, nbe = (steps + spb - 1) / spb;
+    if (nbe != nb) continue;  // (the same cut as a smaller count)
+    const long rounds = ((long)B * nbe + slots - 1) / slots;
+    const long cost = rounds * (spb + (nbe > 1 ? 1 : 0));
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = nbe;
+    }
+  }
+  return best;
+}
+
 template <int HIN, int S, int CIN, int HID, int COUT>
 hipError_t launch_rows(RowsArgs a, int kc, hipStream_t s) {
   using Geo = RowsGeom<HIN, S, CIN, HID, COUT>;
@@ -365,11 +411,13 @@ hipError_t launch_rows(RowsArgs a, int kc, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  // one workgroup per CU is resident (LDS); each walks the observations wgx, wgx + gx, ... of its model
-  int gx = device_cu_count() / kc;
-  if (gx < 1) gx = 1;
-  if (gx > a.B) gx = a.B;
-  note_kernel(dim3(gx, 1, kc), dim3(512), "irb_split_rows_kernel<%d,%d,%d,%d,%d>", HIN, S, CIN, HID, COUT);
+  // one workgroup per CU is resident (LDS); each walks the (observation, band) items wgx, wgx + gx, ... of its model
+  int slots = device_cu_count() / kc;
+  if (slots < 1) slots = 1;
+  a.NB = pick_bands(a.B, Geo::NS, slots);
+  int gx = slots;
+  if (gx > a.B * a.NB) gx = a.B * a.NB;
+  note_kernel(dim3(gx, 1, kc), dim3(512), "irb_split_rows_kernel<%d,%d,%d,%d,%d> NB=%d", HIN, S, CIN, HID, COUT, a.NB);
   hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::LDS_BYTES, s, a);
 #ifdef RIP_ROWS_TICKS
   {
@@ -403,6 +451,7 @@ struct FrontArgs {
   int k0;
   size_t ws_off, bs_off, wd_off, bd_off, bp_off;
   int B;
+  int NB;  // row bands per observation (see irb_split_rows_kernel)
 };
 
 template <int C>
@@ -492,20 +541,54 @@ __global__ __launch_bounds__(512) void front_split_kernel(FrontArgs a) {
   lds_barrier();
   ROWS_TICK(0);
 
-  int b = blockIdx.x;
-  if (b < a.B) {
-    request_raw(b, 0);
+  // (observation, band) items and warm-up steps as in irb_split_rows_kernel; the BEV windows follow the sequence of
+  // EXECUTED steps across items: `rq` = the step whose window is in flight (two steps ahead of the one that runs)
+  const int NB = a.NB, SPB = (NS + NB - 1) / NB, n_items = a.B * NB;
+  auto item_of = [&](int item_, int& b_, int& s0_, int& s1_, int& sa_) {
+    b_ = item_ / NB;
+    s0_ = (item_ - b_ * NB) * SPB;
+    s1_ = s0_ + SPB < NS ? s0_ + SPB : NS;
+    sa_ = s0_ > 0 ? s0_ - 1 : 0;
+  };
+  int rq_item = blockIdx.x, rq_s = 0;
+  auto rq_request = [&]() {  // request the window of step (rq_item, rq_s), if there is one
+    if (rq_item < n_items) request_raw(rq_item / NB, rq_s);
+  };
+  auto rq_advance = [&]() {
+    if (rq_item >= n_items) return;
+    int b_, s0_, s1_, sa_;
+    item_of(rq_item, b_, s0_, s1_, sa_);
+    if (rq_s + 1 < s1_) {
+      ++rq_s;
+    } else {
+      rq_item += (int)gridDim.x;
+      if (rq_item < n_items) {
+        item_of(rq_item, b_, s0_, s1_, sa_);
+        rq_s = sa_;
+      }
+    }
+  };
+  {
+    int b_, s0_, s1_, sa_;
+    item_of(rq_item < n_items ? rq_item : 0, b_, s0_, s1_, sa_);
+    rq_s = sa_;
+    rq_request();
     publish_raw();
-    request_raw(b, 1);
+    rq_advance();
+    rq_request();
   }
   lds_barrier();
 #pragma unroll 1
-  for (; b < a.B; b += gridDim.x) {
-    for (int e = tid; e < PW * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E + (size_t)(R - 1) * PW * LDE)[e] = zero4;  // stem row -1
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    int b, s0b, s1b, sab;
+    item_of(item, b, s0b, s1b, sab);
+    if (s0b == 0)
+      for (int e = tid; e < PW * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E + (size_t)(R - 1) * PW * LDE)[e] = zero4;  // stem row -1
     float* yb = a.y + ((size_t)k * a.B + b) * HOUT * HOUT * COUT;
     ROWS_TICK(1);
 #pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
+    for (int s = sab; s < s1b; ++s) {
+      const bool warm = s < s0b;
       // ---------------- stem rows 2 s, 2 s + 1 -> E ring (rows >= 50: zero rows) ----------------
 #pragma unroll
       for (int jj = 0; jj < JMAX; ++jj) {
@@ -538,15 +621,13 @@ __global__ __launch_bounds__(512) void front_split_kernel(FrontArgs a) {
       ROWS_TICK(2);
       lds_barrier();
       ROWS_TICK(3);
-      // the next step's BEV window (requested a step ago) into LDS, the one after it requested
+      // the next executed step's BEV window (requested a step ago) into LDS, the one after it requested
       publish_raw();
-      {
-        int nb = b, ns = s + 2;
-        if (ns >= NS) {
-          nb = b + (int)gridDim.x;
-          ns -= NS;
-        }
-        if (nb < a.B) request_raw(nb, ns);
+      rq_advance();
+      rq_request();
+      if (warm) {  // (uniform) a band's warm-up: its stem rows are in the ring, no output rows yet
+        lds_barrier();
+        continue;
       }
       // ---------------- depthwise: output rows 2 s - 1, 2 s -> D (hi, lo) ----------------
       const int ob = 2 * s - 1;
@@ -639,10 +720,12 @@ hipError_t launch_front(FrontArgs a, int kc, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  int gx = device_cu_count() / kc;
-  if (gx < 1) gx = 1;
-  if (gx > a.B) gx = a.B;
-  note_kernel(dim3(gx, 1, kc), dim3(512), "front_split_kernel<%d>", C);
+  int slots = device_cu_count() / kc;
+  if (slots < 1) slots = 1;
+  a.NB = pick_bands(a.B, Geo::NS, slots);
+  int gx = slots;
+  if (gx > a.B * a.NB) gx = a.B * a.NB;
+  note_kernel(dim3(gx, 1, kc), dim3(512), "front_split_kernel<%d> NB=%d", C, a.NB);
   hipLaunchKernelGGL(kern, dim3(gx, 1, kc), dim3(512), Geo::LDS_BYTES, s, a);
 #ifdef RIP_ROWS_TICKS
   {
@@ -741,6 +824,7 @@ hipError_t launch_front_split(const Layer& ls, const Layer& ld, const Layer& lp,
   a.bd_off = ld.b_off;
   a.bp_off = lp.b_off;
   a.B = B;
+  a.NB = 1;
   return launch_front<2>(a, kc, s);
 }
 
@@ -761,6 +845,7 @@ hipError_t launch_irb_split_rows(const Layer* le, const Layer& ld, const Layer& 
   a.bp_off = lp.b_off;
   a.B = B;
   a.residual = lp.residual;
+  a.NB = 1;
   switch (rows_shape_index(le, ld, lp)) {
     case 0: return launch_rows<50, 2, 16, 96, 24>(a, kc, s);    // features.2
     case 1: return launch_rows<25, 1, 24, 144, 24>(a, kc, s);   // features.3

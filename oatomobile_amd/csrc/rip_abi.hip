@@ -516,6 +516,7 @@ struct SplitPlanes {
 static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
   SplitPlanes sp;
   if (h->encoder_variant & ENC_VAR_FP32_LAYERWISE) return sp;
+  if (h->encoder_fused >= 0) return sp;  // an explicit RIP_OPT_ENCODER_FUSED count asks for exactly that split of the true-fp32 kernels
   for (int k = k_begin; k < k_begin + k_count; ++k)
     if (!h->enc_split_ok[k]) return sp;
   sp.tiles = h->enc_wc;
