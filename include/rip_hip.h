@@ -309,10 +309,12 @@ int rip_train_num_layers(const rip_trainer* t);
  *   RIP_OPT_ENCODER_FUSED: how many leading MobileNetV2 inverted-residual blocks (0..17) run as ONE fused
  *     kernel each (expand -> LDS -> depthwise -> LDS -> project); the remaining, weight-dominated blocks run
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0 — and,
- *     round 6, from 64 (model, observation) pairs per call whatever the count: stem + features.1, features.2-7 and
- *     features.8-17 as split-f16 blocks (fp32 activations, pointwise convolutions as three binary16 MFMAs on two-term
- *     operands, depthwise / stem fp32: fp32-grade, z within 2e-5 of the fp32 oracle like the true-fp32 kernels), unless
- *     a model's pointwise weights reach 240 in magnitude or RIP_OPT_ENCODER_VARIANT bit 16 is set.
+ *     round 6, in the auto setting: stem + features.1 and features.2-7 as split-f16 row-streaming kernels at every
+ *     launch size (small launches cut an observation into row bands), features.8-17 and features.18 + pool as split-f16
+ *     tile / head kernels from 96 (model, observation) pairs per call (fp32 activations, pointwise convolutions as three
+ *     binary16 MFMAs on two-term operands, depthwise / stem fp32: fp32-grade, z within 2e-5 of the fp32 oracle like the
+ *     true-fp32 kernels), unless a model's pointwise weights reach 240 in magnitude or RIP_OPT_ENCODER_VARIANT bit 16 is
+ *     set.  An explicit count (>= 0) runs exactly that split of the true-fp32 kernels of rounds 1-5.
  *     bf16 encoder: count >= 1 fuses the stem with features.1 (one kernel), blocks 1..6 of the count are the
  *     row-streaming kernel (features.2 .. features.7), blocks 7..15 the tile kernel (features.8 .. features.16);
  *     and 16 (features.17, round 5); features.18 runs as a GEMM with the pooled epilogue.  auto = everything, the tile kernel only when the call carries
