@@ -74,7 +74,21 @@ struct FusedBlock {
   int src, dst;             // workspace buffers (block input / output)
 };
 
+// operand blobs of the fp32 encoder's split-f16 kernels (offsets in binary16 elements into a model's blob; (size_t)-1 = the
+// block is not one of that family's): encoder_split_rows.hip / encoder_split_tile.hip
+struct SplitRowsLayout {
+  std::vector<size_t> off;  // per plan block: its operand fragments (row-streaming blocks; block 0 = the front's projection)
+  size_t total = 0;         // binary16 elements per model
+};
+struct SplitTileLayout {
+  std::vector<size_t> off;       // per plan block: its chunk records (tile blocks)
+  size_t head_off = (size_t)-1;  // features.18's chunk records (head_split_kernel)
+  size_t total = 0;
+};
+
 struct EncoderPlan {
+  SplitRowsLayout split_rows;  // (filled by build_encoder_plan)
+  SplitTileLayout split_tiles;
   int in_channels;
   std::vector<Layer> layers;
   std::vector<FusedBlock> blocks;
@@ -175,11 +189,6 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
 
 // fp32-grade tile blocks of the fp32 encoder (features.8-17): fp32 activations, two-term binary16 pointwise operands
 bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp);
-struct SplitTileLayout {
-  std::vector<size_t> off;  // per plan block: offset (binary16 elements) of its chunk records in a model's blob; (size_t)-1 = not a tile block
-  size_t head_off = (size_t)-1;  // features.18's chunk records (head_split_kernel)
-  size_t total = 0;         // binary16 elements per model
-};
 // features.18 + the 4x4 average pool on two-term binary16 operands (encoder_split_tile.hip: head_split_kernel)
 bool head_split_supported(const Layer& l, int final_hw);
 hipError_t launch_head_split(const Layer& l, const unsigned short* wc, size_t wc_stride, int k0, int kc, int B, const float* x,
@@ -190,10 +199,6 @@ hipError_t launch_irb_split_tile(const Layer* le, const Layer& ld, const Layer& 
                                  size_t wc_stride, size_t model_stride, int k0, int kc, int B, const float* x, float* y, hipStream_t s);
 
 // fp32-grade row-streaming blocks of the fp32 encoder (features.2-7): encoder_split_rows.hip
-struct SplitRowsLayout {
-  std::vector<size_t> off;  // per plan block: offset (binary16 elements) of its operand fragments in a model's blob; (size_t)-1 = not a row-streaming block
-  size_t total = 0;         // binary16 elements per model
-};
 SplitRowsLayout split_rows_layout(const EncoderPlan& plan);
 void pack_split_rows(const EncoderPlan& plan, const SplitRowsLayout& L, const float* enc_blob, unsigned short* out);
 bool irb_split_rows_supported(const Layer* le, const Layer& ld, const Layer& lp);

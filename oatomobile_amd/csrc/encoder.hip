@@ -979,6 +979,8 @@ EncoderPlan build_encoder_plan(int in_channels) {
   }
   p.blob_floats = off;
   p.max_act_floats = max_act;
+  p.split_rows = split_rows_layout(p);
+  p.split_tiles = split_tile_layout(p);
   return p;
 }
 
@@ -1223,13 +1225,13 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
         e = launch_fused_block(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
       else if (in_block[li] == 3)
         e = launch_irb_split_tile(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w,
-                                  enc_wc + split_tile_layout(plan).off[block_of[li]], wc_stride, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
+                                  enc_wc + plan.split_tiles.off[block_of[li]], wc_stride, ms, k0, kc, B, bufs[fb.src], bufs[fb.dst], s);
       else if (in_block[li] == 5)
         e = launch_front_split(plan.layers[0], plan.layers[fb.dw], plan.layers[fb.project], enc_w,
-                               enc_wr + split_rows_layout(plan).off[block_of[li]], wr_stride, ms, k0, kc, B, visual, bufs[fb.dst], s);
+                               enc_wr + plan.split_rows.off[block_of[li]], wr_stride, ms, k0, kc, B, visual, bufs[fb.dst], s);
       else
         e = launch_irb_split_rows(le, plan.layers[fb.dw], plan.layers[fb.project], enc_w,
-                                  enc_wr + split_rows_layout(plan).off[block_of[li]], wr_stride, ms, k0, kc, B, bufs[fb.src],
+                                  enc_wr + plan.split_rows.off[block_of[li]], wr_stride, ms, k0, kc, B, bufs[fb.src],
                                   bufs[fb.dst], s);
       if (e != hipSuccess) return e;
       if (tapped(li)) return hipGetLastError();
@@ -1250,7 +1252,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
       const float* res = l.residual ? bufs[l.res] : nullptr;
       const bool pool = li + 1 == plan.layers.size() && plan.final_hw == 4;  // features.18: fuse the 4x4 average pool
       if (pool && split_tiles && head_split_supported(l, plan.final_hw)) {
-        hipError_t e = launch_head_split(l, enc_wc + split_tile_layout(plan).head_off, wc_stride, k0, kc, B, (const float*)bufs[l.src], dst, s);
+        hipError_t e = launch_head_split(l, enc_wc + plan.split_tiles.head_off, wc_stride, k0, kc, B, (const float*)bufs[l.src], dst, s);
         if (e != hipSuccess) return e;
       } else {
         dispatch_pw((const float*)bufs[l.src], enc_w, ms, k0, kc, l, res, dst, M, pool, s);

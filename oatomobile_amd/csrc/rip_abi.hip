@@ -36,9 +36,7 @@ struct rip_handle {
                             // convolution but the stem; biases and the stem's taps are the fp32 blob's
   unsigned short* enc_wc = nullptr;  // [K][tile_layout.total] chunk records of the fp32 encoder's split-f16 tile blocks (encoder_split_tile.hip:
                                      // two-term binary16 operand fragments of w * 2^8, taps, biases)
-  SplitTileLayout tile_layout;
   unsigned short* enc_wr = nullptr;  // [K][rows_layout.total] operand fragments of the split-f16 row-streaming blocks (encoder_split_rows.hip)
-  SplitRowsLayout rows_layout;
   bool enc_split_ok[RIP_MAX_MODELS] = {false};  // the model's pointwise weights are inside SPLIT_ENC_W_LIMIT
   float* flow_w = nullptr;  // [K][FW_SIZE]
   float* mfma_w = nullptr;  // [K][MW_SIZE] operands of the fp32 MFMA search kernels
@@ -246,16 +244,14 @@ int rip_create(rip_handle** out, int K, int in_channels, int max_batch, int max_
     ALLOC(tmp, ((size_t)K * h->plan.blob_floats + 1) / 2);
     h->enc_wh = reinterpret_cast<unsigned short*>(tmp);
   }
-  h->tile_layout = split_tile_layout(h->plan);
   {
     float* tmp = nullptr;
-    ALLOC(tmp, ((size_t)K * h->tile_layout.total + 1) / 2);
+    ALLOC(tmp, ((size_t)K * h->plan.split_tiles.total + 1) / 2);
     h->enc_wc = reinterpret_cast<unsigned short*>(tmp);
   }
-  h->rows_layout = split_rows_layout(h->plan);
   {
     float* tmp = nullptr;
-    ALLOC(tmp, ((size_t)K * h->rows_layout.total + 1) / 2);
+    ALLOC(tmp, ((size_t)K * h->plan.split_rows.total + 1) / 2);
     h->enc_wr = reinterpret_cast<unsigned short*>(tmp);
   }
   ALLOC(h->flow_w, (size_t)K * FW_SIZE);
@@ -456,12 +452,12 @@ int rip_load_model(rip_handle* h, int k, const float* packed_host, size_t numel)
       for (size_t i = 0; i < (size_t)l.cin * l.cout; ++i) ok = ok && std::fabs(enc[l.w_off + i]) < SPLIT_ENC_W_LIMIT;  // (false for NaN)
     }
     h->enc_split_ok[k] = ok;
-    std::vector<unsigned short> rec(h->tile_layout.total);
-    pack_split_tiles(h->plan, h->tile_layout, enc.data(), rec.data());
-    HIP_TRY(hipMemcpy(h->enc_wc + (size_t)k * h->tile_layout.total, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
-    std::vector<unsigned short> frag(h->rows_layout.total);
-    pack_split_rows(h->plan, h->rows_layout, enc.data(), frag.data());
-    HIP_TRY(hipMemcpy(h->enc_wr + (size_t)k * h->rows_layout.total, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+    std::vector<unsigned short> rec(h->plan.split_tiles.total);
+    pack_split_tiles(h->plan, h->plan.split_tiles, enc.data(), rec.data());
+    HIP_TRY(hipMemcpy(h->enc_wc + (size_t)k * h->plan.split_tiles.total, rec.data(), rec.size() * 2, hipMemcpyHostToDevice));
+    std::vector<unsigned short> frag(h->plan.split_rows.total);
+    pack_split_rows(h->plan, h->plan.split_rows, enc.data(), frag.data());
+    HIP_TRY(hipMemcpy(h->enc_wr + (size_t)k * h->plan.split_rows.total, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemcpy(h->flow_w + (size_t)k * FW_SIZE, flow.data(), flow.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->mfma_w + (size_t)k * MW_SIZE, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -520,9 +516,9 @@ static SplitPlanes split_planes(const rip_handle* h, int k_begin, int k_count) {
   for (int k = k_begin; k < k_begin + k_count; ++k)
     if (!h->enc_split_ok[k]) return sp;
   sp.tiles = h->enc_wc;
-  sp.tiles_stride = h->tile_layout.total;
+  sp.tiles_stride = h->plan.split_tiles.total;
   sp.rows = h->enc_wr;
-  sp.rows_stride = h->rows_layout.total;
+  sp.rows_stride = h->plan.split_rows.total;
   return sp;
 }
 
