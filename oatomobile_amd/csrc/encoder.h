@@ -33,12 +33,14 @@ enum {
 // a model whose pointwise weights reach this magnitude keeps the layer-wise fp32 kernels (binary16 max 65504 / 2^8).
 constexpr float SPLIT_ENC_W_SCALE = 256.0f;
 constexpr float SPLIT_ENC_W_LIMIT = 240.0f;
-// (model, observation) pairs from which the split-f16 TILE blocks and head replace the layer-wise fp32 launches: they walk an
-// observation serially (one workgroup each up to 256 pairs: ~0.3 ms for features.8-18 whatever the launch size), which the
-// layer-wise kernels beat on small launches.  The ROW-STREAMING blocks and the front cut an observation into row bands when the
-// launch is small and win at every size (profiles/r6/fp32_crossover_v1.txt: one observation x 4 models 245 -> 220 us, 8
-// observations 457 -> 324; with the tile blocks as well 459 / 481 us there, 545 against 602 at 32 observations).
-constexpr int SPLIT_TILE_MIN_PAIRS = 96;
+// (model, observation) pairs from which the split-f16 TILE blocks and head run: they walk an observation serially (one
+// workgroup each up to 256 pairs: ~0.3 ms for features.8-18 whatever the launch size).  Below it features.8-17 are two
+// launches per block — expansion + depthwise of one (observation, 64-channel chunk) per workgroup (`irb_split_expdw_kernel`),
+// then the layer-wise projection — and features.18 the layer-wise GEMM.  The ROW-STREAMING blocks and the front cut an
+// observation into row bands when the launch is small and run at every size.  profiles/r6/fp32_crossover_v1.txt: one
+// observation x 4 models 245 (layer-wise) -> 193 us, 8: 457 -> 256, 32: 850 -> 474 (every split kernel: 547), 40: 581 (596), 48: 690
+// against 617.
+constexpr int SPLIT_TILE_MIN_PAIRS = 176;
 constexpr int SPLIT_ROWS_MIN_PAIRS = 1;
 
 // Workgroup barrier for kernels whose waves talk to each other through LDS only.  `__syncthreads()` is a workgroup-scope
@@ -189,6 +191,10 @@ hipError_t launch_irb_tile_bf16(const Layer* le, const Layer& ld, const Layer& l
 
 // fp32-grade tile blocks of the fp32 encoder (features.8-17): fp32 activations, two-term binary16 pointwise operands
 bool irb_split_tile_supported(const Layer* le, const Layer& ld, const Layer& lp);
+// small launches of the tile-block layers: expansion + depthwise of one (observation, 64-channel chunk) per workgroup, the
+// depthwise output to memory (the projection stays a layer-wise launch)
+hipError_t launch_irb_split_expdw(const Layer* le, const Layer& ld, const Layer& lp, const unsigned short* wc, size_t wc_stride,
+                                  int k0, int kc, int B, const float* x, float* d, hipStream_t s);
 // features.18 + the 4x4 average pool on two-term binary16 operands (encoder_split_tile.hip: head_split_kernel)
 bool head_split_supported(const Layer& l, int final_hw);
 hipError_t launch_head_split(const Layer& l, const unsigned short* wc, size_t wc_stride, int k0, int kc, int B, const float* x,

@@ -1197,6 +1197,7 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
   static const int rows_min = getenv("RIP_SPLIT_ROWS_MIN") ? atoi(getenv("RIP_SPLIT_ROWS_MIN")) : SPLIT_ROWS_MIN_PAIRS;
   const bool split_tiles = enc_wc != nullptr && (long)B * kc >= tile_min;
   const bool split_rows = enc_wr != nullptr && (long)B * kc >= rows_min;
+  const bool split_small = enc_wc != nullptr && !split_tiles && tap == nullptr && (long)B * kc >= rows_min;
   for (size_t bi = 0; bi < plan.blocks.size(); ++bi) {
     const FusedBlock& fb = plan.blocks[bi];
     const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;
@@ -1208,7 +1209,16 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
     } else if (split_rows && irb_split_rows_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 4;
     else if ((int)bi < fused_blocks) how = 2;
     else if (split_tiles && fb.src != fb.dst && irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) how = 3;
-    if (how == 0) continue;
+    if (how == 0) {
+      // small launches of the tile-block layers: expansion + depthwise as one launch (launched where the depthwise sits), the
+      // projection stays its own layer-wise launch
+      if (split_small && le != nullptr && irb_split_tile_supported(le, plan.layers[fb.dw], plan.layers[fb.project])) {
+        in_block[fb.expand] = 1;
+        in_block[fb.dw] = 6;
+        block_of[fb.dw] = (int)bi;
+      }
+      continue;
+    }
     if (fb.expand >= 0) in_block[fb.expand] = 1;
     in_block[fb.dw] = 1;
     in_block[fb.project] = (char)how;  // the block is launched where its last layer sits
@@ -1217,6 +1227,13 @@ hipError_t launch_encoder(const EncoderPlan& plan, const float* enc_w, int k0, i
   for (size_t li = 0; li < plan.layers.size(); ++li) {
     const Layer& l = plan.layers[li];
     if (in_block[li] == 1) continue;
+    if (in_block[li] == 6) {
+      const FusedBlock& fb = plan.blocks[block_of[li]];
+      hipError_t e = launch_irb_split_expdw(&plan.layers[fb.expand], plan.layers[fb.dw], plan.layers[fb.project],
+                                            enc_wc + plan.split_tiles.off[block_of[li]], wc_stride, k0, kc, B, bufs[fb.src], bufs[l.dst], s);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     if (in_block[li] >= 2) {
       const FusedBlock& fb = plan.blocks[block_of[li]];
       const Layer* le = fb.expand >= 0 ? &plan.layers[fb.expand] : nullptr;

@@ -512,6 +512,121 @@ hipError_t launch_split_tile(SplitTileArgs a, int kc, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// SMALL LAUNCHES of the tile-block layers (under SPLIT_TILE_MIN_PAIRS pairs: a single observation is 4 pairs): the tile
+// kernel above walks an observation's chunks serially (25 us per block), the layer-wise kernels are three dependent
+// latency-bound launches (~5 us each).  This kernel is the first TWO of them in one: a workgroup = (observation, 64-channel
+// chunk of the hidden dimension) expands its chunk (split-f16 MFMA, the chunk's record of `pack_split_tiles`: expansion
+// fragments + taps / biases, copied into LDS while the block input is fetched and split), runs the depthwise on it in LDS
+// and writes the depthwise OUTPUT (fp32, ReLU6) where the layer-wise `dw_kernel` would: the projection stays the layer-wise
+// K-split `pw_kernel`.  No cross-workgroup reduction, no atomics; one memory latency + two short phases.
+// ------------------------------------------------------------------------------------------------------------------
+struct ExpDwArgs {
+  const float* x;      // [K][B][HIN][HIN][CIN] fp32
+  float* d;            // [K][B][HOUT][HOUT][HID] fp32: the depthwise layer's output
+  const h16_t* wc;     // the block's chunk records of model 0
+  size_t wc_stride;
+  int k0, B, HID, cout;  // (cout: the record's projection fragments are skipped)
+};
+
+template <int HIN, int STRIDE, int CIN>
+__global__ __launch_bounds__(512) void irb_split_expdw_kernel(ExpDwArgs a) {
+  constexpr int HOUT = STRIDE == 1 ? HIN : (HIN + 1) / 2, HWI = HIN * HIN, PW = HIN + 2;
+  constexpr int E_DUMP = HIN * PW, E_ROWS = E_DUMP + 1;
+  constexpr int NPT = (HWI + 15) / 16, KSX = CIN / 32, NFE = (HC / 16) * KSX * 2;
+  constexpr int WPX = NPT > 2 ? 4 : 2, WCH = 8 / WPX, NHT = (HC / 16) / WCH;  // 4 pixel tiles x 2 channel halves (7x7), 2 x 4 -> 1 tile x 1..2 channel tiles (4x4: one pixel tile)
+  static_assert(NPT <= WPX && (HC / 16) % WCH == 0 && NFE % 8 == 0 && HOUT * HOUT * 16 <= 1024, "shapes");
+  __shared__ __attribute__((aligned(16))) float E[E_ROWS * LDE];
+  __shared__ __attribute__((aligned(16))) u32x4 WE[NFE * 64];
+  __shared__ __attribute__((aligned(16))) float TP[768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int k = blockIdx.z, nch = a.HID / HC;
+  const int b = blockIdx.x / nch, c = blockIdx.x - b * nch;
+  const int nfp = (a.cout / 16) * (HC / 32) * 2, rec = NFE + nfp + 3;
+  const u32x4* const recp = reinterpret_cast<const u32x4*>(a.wc + (size_t)(a.k0 + k) * a.wc_stride) + (size_t)c * rec * 64;
+  // the chunk's expansion fragments and taps / biases -> LDS (every wave the same number of copies)
+  {
+    const unsigned lds_we = (unsigned)(size_t)(lds_ptr_t)WE, lds_tp = (unsigned)(size_t)(lds_ptr_t)TP;
+#pragma unroll
+    for (int i = 0; i < NFE / 8; ++i) {
+      const int f = w + 8 * i;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_we + (unsigned)f * 1024u), "v"(recp + (size_t)f * 64 + lane) : "memory");
+    }
+    const int r = w % 3;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_tp + (unsigned)r * 1024u), "v"(recp + (size_t)(NFE + nfp + r) * 64 + lane) : "memory");
+  }
+  for (int e = tid; e < E_ROWS * LDE / 4; e += 512) reinterpret_cast<u32x4*>(E)[e] = u32x4{0u, 0u, 0u, 0u};
+  // block input of this wave's pixel tile as two-term B operands
+  const int wpx = w % WPX, wch = w / WPX;
+  const int px = 16 * wpx + n;
+  const bool on = wpx < NPT && px < HWI;
+  u32x4 xh[KSX], xl[KSX];
+  {
+    const float* xp = a.x + (((size_t)k * a.B + b) * HWI + (on ? px : 0)) * CIN + 8 * q;
+#pragma unroll
+    for (int ks = 0; ks < KSX; ++ks) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + 32 * ks), v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 4);
+      if (!on) {
+        v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const u32x2 s0 = split2(f32x2{v0[0], v0[1]}), s1 = split2(f32x2{v0[2], v0[3]});
+      const u32x2 s2 = split2(f32x2{v1[0], v1[1]}), s3 = split2(f32x2{v1[2], v1[3]});
+      xh[ks] = u32x4{s0.x, s1.x, s2.x, s3.x};
+      xl[ks] = u32x4{s0.y, s1.y, s2.y, s3.y};
+    }
+  }
+  const int iy = px / HIN, ix = px - iy * HIN;
+  const int erow = on ? iy * PW + ix + 1 : E_DUMP;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  // ---------------- expand -> E ----------------
+  if (wpx < NPT) {
+#pragma unroll
+    for (int hi = 0; hi < NHT; ++hi) {
+      const int ht = wch * NHT + hi;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f}, vc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) {
+        const u32x4 ah = WE[(size_t)((ht * KSX + ks) * 2) * 64 + lane], al = WE[(size_t)((ht * KSX + ks) * 2 + 1) * 64 + lane];
+        va = mfmah(al, xh[ks], va);
+        vb = mfmah(ah, xl[ks], vb);
+        vc = mfmah(ah, xh[ks], vc);
+      }
+      const f32x4 v = vc + (va + vb);
+      const float4 be = *reinterpret_cast<const float4*>(TP + 10 * 64 + 16 * ht + 4 * q);
+      const f32x2 v0 = relu6_2(__builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{W_INV, W_INV}, f32x2{be.x, be.y}));
+      const f32x2 v1 = relu6_2(__builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{W_INV, W_INV}, f32x2{be.z, be.w}));
+      *reinterpret_cast<f32x4*>(E + (size_t)erow * LDE + 16 * ht + 4 * q) = f32x4{v0.x, v0.y, v1.x, v1.y};
+    }
+  }
+  lds_barrier();
+  // ---------------- depthwise -> global (thread = (output pixel, 4 channels); HOUT^2 * 16 items) ----------------
+  float* dp = a.d + ((size_t)k * a.B + b) * HOUT * HOUT * a.HID + (size_t)c * HC;
+  for (int it = tid; it < HOUT * HOUT * 16; it += 512) {
+    const int cg = it & 15, op = it >> 4, oy = op / HOUT, ox = op - oy * HOUT;
+    const float4 b0 = *reinterpret_cast<const float4*>(TP + 9 * 64 + 4 * cg);
+    f32x2 s0 = {b0.x, b0.y}, s1 = {b0.z, b0.w};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int r = oy * STRIDE - 1 + ky;
+      if (r < 0 || r >= HIN) continue;  // (rows off the map: zero contributions; columns off the map are E's zero columns)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f32x4 e = *reinterpret_cast<const f32x4*>(E + (size_t)(r * PW + ox * STRIDE + kx) * LDE + 4 * cg);
+        const float4 wv = *reinterpret_cast<const float4*>(TP + (ky * 3 + kx) * 64 + 4 * cg);
+        s0 = __builtin_elementwise_fma(f32x2{e[0], e[1]}, f32x2{wv.x, wv.y}, s0);
+        s1 = __builtin_elementwise_fma(f32x2{e[2], e[3]}, f32x2{wv.z, wv.w}, s1);
+      }
+    }
+    s0 = relu6_2(s0);
+    s1 = relu6_2(s1);
+    *reinterpret_cast<f32x4*>(dp + (size_t)op * a.HID + 4 * cg) = f32x4{s0.x, s0.y, s1.x, s1.y};
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // features.18 (1x1, 320 -> 1280, ReLU6) + the 4x4 average pool of the fp32 encoder in the same number format: the last
 // true-fp32 GEMM of the fp32 mode (`pw_kernel` with the pooled epilogue, 285 us at 512 observations x 4 models).
 // A wave owns ONE observation (its 16 pixels = one MFMA pixel tile; block input resident as two-term B operands, 80
@@ -625,6 +740,38 @@ __global__ __launch_bounds__(512) void head_split_kernel(HeadArgs a) {
 }
 
 }  // namespace
+
+hipError_t launch_irb_split_expdw(const Layer* le, const Layer& ld, const Layer& lp, const unsigned short* wc, size_t wc_stride,
+                                  int k0, int kc, int B, const float* x, float* d, hipStream_t s) {
+  if (!irb_split_tile_supported(le, ld, lp)) return hipErrorInvalidValue;
+  ExpDwArgs a;
+  a.x = x;
+  a.d = d;
+  a.wc = wc;
+  a.wc_stride = wc_stride;
+  a.k0 = k0;
+  a.B = B;
+  a.HID = ld.cout;
+  a.cout = lp.cout;
+  const dim3 grid((unsigned)(B * (ld.cout / HC)), 1, kc);
+  const int cin = le->cin;
+  if (ld.h_in == 7 && ld.stride == 1 && cin == 64) {
+    note_kernel(grid, dim3(512), "irb_split_expdw_kernel<7,1,64>");
+    hipLaunchKernelGGL((irb_split_expdw_kernel<7, 1, 64>), grid, dim3(512), 0, s, a);
+  } else if (ld.h_in == 7 && ld.stride == 1 && cin == 96) {
+    note_kernel(grid, dim3(512), "irb_split_expdw_kernel<7,1,96>");
+    hipLaunchKernelGGL((irb_split_expdw_kernel<7, 1, 96>), grid, dim3(512), 0, s, a);
+  } else if (ld.h_in == 7 && ld.stride == 2 && cin == 96) {
+    note_kernel(grid, dim3(512), "irb_split_expdw_kernel<7,2,96>");
+    hipLaunchKernelGGL((irb_split_expdw_kernel<7, 2, 96>), grid, dim3(512), 0, s, a);
+  } else if (ld.h_in == 4 && ld.stride == 1 && cin == 160) {
+    note_kernel(grid, dim3(512), "irb_split_expdw_kernel<4,1,160>");
+    hipLaunchKernelGGL((irb_split_expdw_kernel<4, 1, 160>), grid, dim3(512), 0, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 
 bool head_split_supported(const Layer& l, int final_hw) {
   return l.kind == L_PW && l.cin == HD_CIN && l.cout == HD_COUT && l.h_in == 4 && final_hw == 4 && l.relu6 && !l.residual;

@@ -184,18 +184,19 @@ def test_layerwise_encoder_matches_fused(golden, dev):
 
 def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
   """Round 6: features.8-17 of the fp32 encoder as split-f16 tile blocks (encoder_split_tile.hip: fp32 activations,
-  two-term binary16 pointwise operands, fp32 accumulation) from 96 (model, observation) pairs per launch; stem + features.1-7 as
-  row-streaming kernels at every launch size (small launches cut an observation into row bands).
-  (a) 100 observations of one model against the fp32 ORACLE at the suite's 1e-4 (one observation per workgroup), and the first
-      1 / 3 / 7 of them as launches of their own (13 / 5 / 2 row bands per observation, features.8-18 layer-wise);
+  two-term binary16 pointwise operands, fp32 accumulation) from 176 (model, observation) pairs per launch; stem + features.1-7 as
+  row-streaming kernels at every launch size (small launches cut an observation into row bands), features.8-17 of a small
+  launch as expansion + depthwise kernels (one (observation, 64-channel chunk) per workgroup) + layer-wise projections.
+  (a) 180 observations of one model against the fp32 ORACLE at the suite's 1e-4 (one observation per workgroup), and the first
+      1 / 3 / 7 of them as launches of their own (row bands, expansion + depthwise kernels);
   (b) K = 3 models x B = 601 observations (1803 pairs: 3 / 4 / 2 observations per workgroup, every block's last group
       ragged, persistent workgroups walking two groups) against the layer-wise true-fp32 kernels of the same handle
       (`RIP_OPT_ENCODER_VARIANT` bit 16), z and every block output that reaches memory; B - 1 observations reproduce
       the first B - 1 rows bit for bit (observations are independent, the LDS rows of a ragged group are stale)."""
   from oatomobile_amd import _lib, RIPAgent, arch
   from oracle import reference_cpu as O
-  m, mo = hip_model(31, dev, max_batch=100), oracle_model(31)
-  obs = [synth_observation(np.random.default_rng(3100 + i)) for i in range(100)]
+  m, mo = hip_model(31, dev, max_batch=180), oracle_model(31)
+  obs = [synth_observation(np.random.default_rng(3100 + i)) for i in range(180)]
   ctx = ctx_tensors(obs, dev)
   m._handle().set_option(_lib.OPT_KERNEL_LOG, 1)
   z = m._params(**ctx).cpu().numpy()
@@ -205,13 +206,14 @@ def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
   assert sum(l.startswith("front_split_kernel<2>") for l in log) == 1 and not any(l.startswith(("stem_kernel", "irb_kernel")) for l in log), log
   assert sum(l.startswith("head_split_kernel") for l in log) == 1 and not any(l.startswith(("pw_kernel", "dw_kernel")) for l in log), log  # features.18 + pool
   zo = O.params(mo, **{k: v.cpu() for k, v in ctx.items()}).numpy()
-  print("fp32 encoder with split-f16 tile blocks vs fp32 oracle (100 observations): max|dz| = %.3g of max|z| = %.3g" % (np.abs(z - zo).max(), np.abs(zo).max()))
+  print("fp32 encoder with split-f16 tile blocks vs fp32 oracle (180 observations): max|dz| = %.3g of max|z| = %.3g" % (np.abs(z - zo).max(), np.abs(zo).max()))
   np.testing.assert_allclose(z, zo, atol=TOL)
   for nb in (1, 3, 7):  # small launches: row bands, tile blocks / head layer-wise
     zs = m._params(**{k: v[:nb].contiguous() for k, v in ctx.items()}).cpu().numpy()
     logs = m._handle().kernel_log()
     rows = [l for l in logs if l.startswith(("irb_split_rows_kernel", "front_split_kernel"))]
     assert len(rows) == 7 and all(" NB=1 " not in l for l in rows) and not any(l.startswith(("irb_split_tile", "head_split")) for l in logs), logs
+    assert sum(l.startswith("irb_split_expdw_kernel") for l in logs) == 10 and not any(l.startswith("dw_kernel") for l in logs), logs
     np.testing.assert_allclose(zs, zo[:nb], atol=TOL)
     print("   %d observation(s) as a launch of its own (%s): max|dz| = %.3g" % (nb, rows[1].split(" ")[1], np.abs(zs - zo[:nb]).max()))
   m._handle().set_option(_lib.OPT_ENCODER_VARIANT, _lib.ENC_VAR_FP32_LAYERWISE)
@@ -241,6 +243,7 @@ def test_fp32_split_tile_blocks_vs_oracle_and_layerwise(dev):
   assert len(tiles) == 10 and {l.split(" ")[1] for l in tiles} == {"G=3", "G=4", "G=2"}, tiles
   assert sum(l.startswith("irb_split_rows_kernel") for l in log_s) == 6, log_s
   assert not any(l.startswith(("irb_split_", "front_split_", "head_split_")) for l in log_l)
+  assert not any(l.startswith("irb_split_expdw") for l in log_s)  # (a large launch: the tile blocks)
   assert np.isfinite(z_s).all()
   d = np.abs(z_s - z_l).max()
   print("K = 3 x B = 601, split-f16 tile blocks vs layer-wise fp32: max|dz| = %.3g of max|z| = %.3g" % (d, np.abs(z_l).max()))
