@@ -311,7 +311,8 @@ int rip_train_num_layers(const rip_trainer* t);
  *     as one batched kernel per conv layer.  -1 (default) = auto.  fp32 encoder: 3 when B >= 8, else 0 — and,
  *     round 6, in the auto setting: stem + features.1 and features.2-7 as split-f16 row-streaming kernels at every
  *     launch size (small launches cut an observation into row bands), features.8-17 and features.18 + pool as split-f16
- *     tile / head kernels from 96 (model, observation) pairs per call (fp32 activations, pointwise convolutions as three
+ *     tile / head kernels from 176 (model, observation) pairs per call — below that features.8-17 are an expansion +
+ *     depthwise kernel and a layer-wise projection per block — (fp32 activations, pointwise convolutions as three
  *     binary16 MFMAs on two-term operands, depthwise / stem fp32: fp32-grade, z within 2e-5 of the fp32 oracle like the
  *     true-fp32 kernels), unless a model's pointwise weights reach 240 in magnitude or RIP_OPT_ENCODER_VARIANT bit 16 is
  *     set.  An explicit count (>= 0) runs exactly that split of the true-fp32 kernels of rounds 1-5.
